@@ -1,0 +1,225 @@
+"""bench.py -- train sentences/sec of the ELBO fwd+bwd step on synthetic token batches (BASELINE.json),
+plus the roofline fraction of the dominant hand-written kernel and a CPU baseline.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c5|c1]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = the reference's `_train_batch` (training/trainers/trainer.py:277-303): forward ELBO of the
+non-autoregressive VAE (transformer encoder/decoder on stock PyTorch-ROCm ops, latent path on the HIP
+kernels), backward, bucketed RCCL gradient all-reduce overlapped with backward, clip (norm 5, value 2),
+Adam step.  Inputs are resident in HBM before the timed region.  Weak scaling: the per-GPU batch is
+fixed; value = global sentences / max-over-ranks time.
+
+Workload at N=1 = BASELINE configs[1] ("C2"): B=256, S=64, D=64, K=4 NICE-FF steps (H=64), bf16.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+
+CONFIGS = {
+    #        B    S    D    H    K   dtype   ragged
+    "c1": (32, 32, 64, 64, 4, "f32", False),
+    "c2": (256, 64, 64, 64, 4, "bf16", False),
+    "c3": (256, 128, 256, 256, 16, "bf16", False),
+    "c5": (64, 512, 512, 512, 32, "bf16", True),
+}
+VOCAB = 8192
+
+
+def model_config(D, H, K):
+    return dict(
+        type="nonauto",
+        embedder=dict(embedding_dim=D),
+        encoder=dict(type="transformer", input_size=D, hidden_size=2 * D, num_layers=2, num_heads=4),
+        decoder=dict(type="nonauto-transformer", input_size=D, hidden_size=2 * D, num_layers=2, num_heads=4),
+        posterior=dict(type="default", input_size=D, features=D, samples=1),
+        prior=dict(type="flow", features=D, flows=[
+            dict(type="nice", coupling=dict(type="feed-forward", input_size=D // 2, hidden_sizes=[H],
+                                            activation="gelu", dropout=0.0)) for _ in range(K)]),
+        kl_loss=dict(type="default"),
+        recon_scheduler=dict(type="constant", weight=1.0),
+        kl_scheduler=dict(type="constant", weight=1.0),
+    )
+
+
+def synthetic_tokens(B, S, ragged, seed):
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(max(2, S // 4), S + 1, (B,), generator=g) if ragged else torch.full((B,), S)
+    tok = torch.randint(4, VOCAB, (B, S), generator=g)
+    return tok * (torch.arange(S)[None, :] < lens[:, None])
+
+
+def cpu_baseline(model, tokens, D, H, K, budget_s=20.0):
+    """The same ELBO fwd+bwd step on the host cores: stock PyTorch encoder/decoder + the CPU oracle's
+    latent path (oracle/latent_path.py, pinned against the reference's golden vectors), fp32.
+    Bounded sample: a slice of the batch sized so a few steps take ~10-30 s."""
+    import nonauto_lm_amd as M
+    from oracle import latent_path as O
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    m = M.VAELmModel.from_params(vocab=M.SimpleVocab(VOCAB), **model_config(D, H, K)).train()
+    m.load_state_dict({k: v.detach().float().cpu() for k, v in model.state_dict().items()})
+    B = min(tokens.size(0), 64)
+    tok = tokens[:B].cpu()
+
+    def step():
+        m.zero_grad(set_to_none=True)
+        mask = O.tokens_mask(tok)
+        enc = m._encoder.encoder(m._encoder._preprocess_embedding(m._embedder(tok)), mask)
+        mu = m._posterior._mu_net(enc)
+        sigma = m._posterior._sigma_net(enc)
+        eps = torch.randn(B, 1, *mu.shape[1:])
+        z, mrep = O.posterior_sample(mu, sigma, eps, mask, 1)
+        logq = O.posterior_log_prob(z, mu, sigma, mrep, 1)
+        logits = m._vocab_projection(m._decoder(z, mrep))
+        recon = O.label_smoothing_nll(logits, tok, mrep.float(), 0.0, True)
+        sd = dict(m._prior.named_parameters())
+        ps = [O.NiceParams.from_state_dict(sd, f"_flows.{k}.") for k in range(K)]
+        _, logp = O.flow_prior_forward(z, O.nice_steps(ps), mrep)
+        out = O.elbo_tail(recon, O.kl_default(logq, logp), B, 1)
+        out["batch-loss"].backward()
+
+    step()
+    t0 = time.perf_counter()
+    n = 0
+    while n < 3 or (time.perf_counter() - t0 < budget_s / 2 and n < 20):
+        step()
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {"value": B / dt, "unit": "sentences/s", "cores": cores, "kind": "port",
+            "sample": f"{n} fp32 steps of the same model on a {B}-sentence slice of the batch "
+                      f"({dt * 1e3:.1f} ms/step); latent path = oracle/latent_path.py, enc/dec = stock PyTorch CPU"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bucket-mb", type=int, default=32)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import nonauto_lm_amd as M
+    from nonauto_lm_amd import dp, ops
+    M._lib.lib()                                   # the HIP extension is mandatory
+
+    B, S, D, H, K, dtype_name, ragged = CONFIGS[args.config]
+    amp_dtype = torch.bfloat16 if dtype_name == "bf16" else None
+    torch.manual_seed(13)                          # identical init on every rank (train_worker.py:48)
+    model = M.VAELmModel.from_params(vocab=M.SimpleVocab(VOCAB), **model_config(D, H, K)).to(dev).train()
+    model.training_outputs_only = True             # skip probs/preds, unused by the loss
+    dp.broadcast_parameters(model)
+    reducer = dp.GradReducer(model.parameters(), bucket_bytes=args.bucket_mb << 20)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, foreach=True)
+    scalars = dp.PackedScalars(["batch-loss", "batch-kl", "batch-nll", "done"], dev)
+    tokens = synthetic_tokens(B, S, ragged, 13 + rank).to(dev)     # per-rank shard of the global batch
+
+    def step():
+        with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
+            out = model(tokens, tokens)
+        info = out["loss_info"]
+        info["batch-loss"].backward()
+        reducer.finish()
+        reducer.clip_(5.0, 2.0)
+        opt.step()
+        reducer.zero_grad()
+        scalars.reduce({"batch-loss": info["batch-loss"], "batch-kl": info["batch-kl"],
+                        "batch-nll": info["batch-nll"], "done": 0.0})
+        return info
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ops.profile_kernels(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ops.profile_kernels(False)
+    loss = scalars.means()["batch-loss"]
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        e = 2 if dtype_name == "bf16" else 4
+        N = B * S
+        h = D // 2
+        w_bytes = K * 2 * (2 * h * H + H + h) * e
+        # algorithmic bytes per launch (DESIGN.md "Kernels"): fused K-step forward reads z and
+        # writes z' once (+ int64 mask, per-token value, packed weights); backward reads z', dz', writes dz.
+        algo = {
+            "nice_stack_fwd": 2 * N * D * e + 8 * N + 4 * N + w_bytes,
+            "nice_stack_bwd": 3 * N * D * e + 8 * N + 4 * N + 2 * w_bytes,
+        }
+        flops = {"nice_stack_fwd": 4 * K * N * D * H, "nice_stack_bwd": 12 * K * N * D * H}
+        kern = {}
+        for name, evs in (prof or {}).items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            kern[name] = {"launches": len(ms), "avg_us": 1e3 * sum(ms) / len(ms)}
+        roofline = None
+        if kern:
+            dom = max(kern, key=lambda k: kern[k]["avg_us"] * kern[k]["launches"])
+            us = kern[dom]["avg_us"]
+            ach = algo[dom] / (us * 1e-6) / 1e9
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "avg_us": round(us, 2), "algorithmic_bytes": algo[dom],
+                        "mfma_tflops": round(flops[dom] / (us * 1e-6) / 1e12, 2)}
+            for k in kern:
+                kern[k]["GBps_algorithmic"] = round(algo[k] / (kern[k]["avg_us"] * 1e-6) / 1e9, 1)
+                kern[k]["avg_us"] = round(kern[k]["avg_us"], 2)
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline(model, tokens, D, H, K)
+        line = {
+            "metric": "train sentences/sec (ELBO fwd+bwd)", "value": round(world * B * args.steps / elapsed, 1),
+            "unit": "sentences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
+            "config": {"workload": f"{args.config}: NAR VAE B={B}/GPU S={S} D={D} K={K} NICE-FF H={H} V={VOCAB} "
+                                   f"2+2 transformer layers, fwd+bwd+allreduce+clip+Adam",
+                       "global_batch": world * B, "seq_len": S, "latent_dim": D, "flow_steps": K,
+                       "parallelism": f"dp{world}"},
+            "roofline": roofline, "kernels": kern, "cpu_baseline": cpu, "final_loss": round(loss, 4),
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

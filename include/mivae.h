@@ -1,0 +1,161 @@
+/* libmivae -- C ABI of the MI355X (gfx950) latent hot path of Nemexur/nonauto-lm.
+ *
+ * Boundary contract:
+ *  - plain pointers and sizes only; no torch types.  All tensor pointers are DEVICE pointers to
+ *    contiguous row-major buffers that the caller owns (borrowed for the duration of the launch);
+ *    outputs are pre-allocated by the caller.  The library never allocates or frees tensor memory
+ *    and keeps no mutable global state besides a thread-local error string.
+ *  - every entry point enqueues its kernels on `stream` (a hipStream_t passed as void*) and returns
+ *    immediately: 0 = MIVAE_OK, <0 = error (mivae_last_error() has the text).  No device sync.
+ *  - `dtype`: 0 = float32, 1 = bfloat16 latents.  Log-dets, log-probs, KL and ELBO are always fp32.
+ *  - masks are int64 0/1 `(B, S)` exactly as vae_lm/nn/utils.py:12-14 produces them, or NULL.
+ *    `mask_div` = posterior samples n when a `(B, S)` mask addresses `(B*n, S)` rows (row b*n+j uses
+ *    mask row b, the einops `repeat "b s -> (b n) s"` of posterior.py:125-127), else 1.
+ *  - a 2-D `(B, D)` latent (autoregressive model) is passed as S = 1, mask = NULL.
+ *
+ * Citations are file:line under the reference tree (vae_lm/...).
+ */
+#ifndef MIVAE_H
+#define MIVAE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIVAE_OK 0
+#define MIVAE_EINVAL (-1)
+#define MIVAE_ELAUNCH (-2)
+#define MIVAE_EUNSUPPORTED (-3)
+#define MIVAE_F32 0
+#define MIVAE_BF16 1
+
+/* activation ids of the fused coupling MLP (subset of nn/activation.py:59-77) */
+#define MIVAE_ACT_LINEAR 0
+#define MIVAE_ACT_GELU 1 /* erf GELU, nn/activation.py:9-16 */
+#define MIVAE_ACT_SWISH 2 /* nn/activation.py:21-23 */
+#define MIVAE_ACT_RELU 3
+#define MIVAE_ACT_TANH 4
+#define MIVAE_ACT_SIGMOID 5
+
+int mivae_version(void);
+/* thread-local text of the last error on the calling thread (replaces the reference's Python
+ * exceptions, training/trainers/trainer.py:110-113) */
+const char* mivae_last_error(void);
+
+/* ---- integer helpers (bit exact) ------------------------------------------------------------ */
+/* mask[i] = tokens[i] != 0.  Replaces get_tokens_mask, nn/utils.py:12-14. */
+int mivae_tokens_mask(const int64_t* tokens, int64_t* mask, int64_t n, void* stream);
+/* last_idx[b] = sum_s mask[b,s] - 1; ctx[b,:] = out[b, last_idx[b], :] (index -1 wraps like torch).
+ * Replaces Encoder.forward's gather, models/base/encoders/encoder.py:35-37.  last_idx may be NULL. */
+int mivae_gather_last(const void* out, const int64_t* mask, void* ctx, int64_t* last_idx, int64_t B,
+                      int64_t S, int64_t E, int dtype, void* stream);
+/* count[bn] = sum_s mask[bn / mask_div, s]  (the integer token count of actnorm.py:35-38 and
+ * invertible_flows.py:30-31). */
+int mivae_mask_count(const int64_t* mask, int64_t* count, int64_t Bn, int64_t mask_div, int64_t S,
+                     void* stream);
+/* out[b] = sum_s tok[b, s] (+ add[b]); one wave per segment, fixed order (the reduction
+ * `einsum("b...->b")` of posterior.py:170-172 / prior.py:156-158 over tokens). */
+int mivae_segment_sum(const float* tok, const float* add, float* out, int64_t nseg, int64_t S,
+                      void* stream);
+
+/* ---- posterior: reparameterised sample + log q ---------------------------------------------- */
+/* z[(b n), s, :] = (mu[b,s,:] + eps[(b n),s,:] * sigma[b,s,:]) * mask[b,s]  and
+ * tok_logq[(b n), s] = mask * sum_d -1/2((z-mu)^2/sigma^2 + 2 log sigma + log 2pi).
+ * Replaces Posterior.sample (nonauto posterior.py:115-133, auto :107-119) and
+ * Posterior.log_probability (nonauto :157-172, auto :141-156).  eps NULL = zeros (random=False). */
+int mivae_reparam_logq_fwd(const void* mu, const void* sigma, const void* eps, const int64_t* mask,
+                           void* z, float* tok_logq, int64_t B, int64_t n, int64_t S, int64_t D,
+                           int dtype, void* stream);
+/* backward of the pair above w.r.t. mu and sigma (autograd of posterior.py:115-172); dz (B n,S,D)
+ * and dlogq (B n) may each be NULL. */
+int mivae_reparam_logq_bwd(const void* dz, const float* dlogq, const void* sigma, const void* eps,
+                           const int64_t* mask, void* dmu, void* dsigma, int64_t B, int64_t n,
+                           int64_t S, int64_t D, int dtype, void* stream);
+
+/* ---- base distribution ----------------------------------------------------------------------- */
+/* tok[bn, s] = mask * sum_d Normal(mu, std).log_prob(z).  Replaces DefaultPrior.masked_log_prob,
+ * nonauto priors/prior.py:148-158; auto priors/prior.py:93. */
+int mivae_gauss_logprob_fwd(const void* z, const int64_t* mask, float* tok, int64_t Bn,
+                            int64_t mask_div, int64_t S, int64_t D, float mu, float std, int dtype,
+                            void* stream);
+int mivae_gauss_logprob_bwd(const void* z, const int64_t* mask, const float* dlogp, void* dz,
+                            int64_t Bn, int64_t mask_div, int64_t S, int64_t D, float mu, float std,
+                            int dtype, void* stream);
+
+/* ---- NICE affine tail given s, t (any coupling net) ------------------------------------------- */
+/* out = cat(x0, exp(s) x1 + t) * mask, tok_ld = mask * sum_d s   (inverse: (x1 - t) exp(-s), -s).
+ * Replaces NICECoupling.forward couplings.py:151-162 and .backward :172-183 after the s/t nets. */
+int mivae_nice_affine_fwd(const void* z, const void* s, const void* t, const int64_t* mask, void* out,
+                          float* tok_ld, int64_t Bn, int64_t mask_div, int64_t S, int64_t D, int dtype,
+                          int inverse, void* stream);
+int mivae_nice_affine_bwd(const void* dout, const float* dld, const void* z, const void* s,
+                          const void* t, const int64_t* mask, void* dz, void* ds, void* dt, int64_t Bn,
+                          int64_t mask_div, int64_t S, int64_t D, int dtype, int inverse, void* stream);
+
+/* ---- fused NICE feed-forward stack (the dominant kernel) --------------------------------------- */
+/* Bytes of packed weights for ONE step (two nets), MFMA fragment order. */
+int64_t mivae_nice_pack_bytes(int64_t h, int64_t H, int dtype);
+/* ptr_table: device int64[K][8] of fp32 parameter addresses {W1s,b1s,W2s,b2s,W1t,b1t,W2t,b2t} in
+ * torch.nn.Linear layout (W1 (H,h), W2 (h,H)) -- the tensors behind the state-dict keys
+ * `_flows.{k}._{s,t}_net._feedforward.{_linear_layers.0,_output}.{weight,bias}` (couplings.py:26-48). */
+int mivae_nice_pack(const int64_t* ptr_table, void* packed, int64_t K, int64_t h, int64_t H, int dtype,
+                    void* stream);
+/* K NICE steps with one-hidden-layer feed-forward nets in ONE launch.  Replaces the loop of
+ * FlowPrior.forward_pass (nonauto flow_prior.py:45-52, auto :43-50) / .backward_pass (:65-69) over
+ * NICECoupling(FeedForwardCoupling) steps, incl. FeedForward.forward (nn/feedforward.py:93-98).
+ * tok_val[token] = mask * (sum_k sum_d s_k  [+ base log-prob of z_K when base != 0]).
+ * x1_hist (K, N, h): per-step input of the transformed half, saved for the backward (or NULL).
+ * inverse != 0 runs steps K-1..0 in the sampling direction (x1_hist must be NULL). */
+int mivae_nice_stack_fwd(const void* z_in, void* z_out, void* x1_hist, const int64_t* mask,
+                         const void* packed, float* tok_val, int64_t Bn, int64_t mask_div, int64_t S,
+                         int64_t D, int64_t H, int64_t K, int act, int inverse, int base, float mu,
+                         float std, int dtype, void* stream);
+/* token count padded to the wave tile (leading dimension of Gt / Ht / dSt) */
+int64_t mivae_nice_stack_npad(int64_t N);
+/* Backward of the forward direction.  dz_out (N,D) / dlogp (Bn) may be NULL.  Emits dz_in and the
+ * token-contiguous operands of the weight-gradient GEMMs: Gt, Ht (K,2,Hp,Npad) = d pre-activation and
+ * hidden activations, dSt (K,2,hp,Npad) = ds / dt; Hp, hp = H, h rounded up to 32. */
+int mivae_nice_stack_bwd(const void* z_in, const void* z_out, const void* x1_hist, const int64_t* mask,
+                         const void* packed, const void* dz_out, const float* dlogp, void* dz_in,
+                         void* Gt, void* Ht, void* dSt, int64_t Bn, int64_t mask_div, int64_t S,
+                         int64_t D, int64_t H, int64_t K, int act, int base, float mu, float std,
+                         int dtype, void* stream);
+
+/* ---- ActNorm ------------------------------------------------------------------------------------- */
+/* out = (z exp(log_scale) + bias) * mask  (inverse: ((z - bias) * mask) / (exp(log_scale) + 1e-13));
+ * logdet[i] = +-sum(log_scale) * (count_weighted ? token count of row i : 1), i < n_logdet.
+ * Replaces ActNorm.forward actnorm.py:31-39 and .backward :45-54 (after init). */
+int mivae_actnorm_fwd(const void* z, const float* log_scale, const float* bias, const int64_t* mask,
+                      void* out, float* logdet, int64_t Bn, int64_t mask_div, int64_t S, int64_t D,
+                      int64_t n_logdet, int count_weighted, int dtype, int inverse, void* stream);
+/* floats of workspace needed by mivae_actnorm_bwd / mivae_actnorm_stats */
+int64_t mivae_col_workspace_floats(int64_t rows, int64_t D, int dtype);
+/* dz and dparams = [dlog_scale (D) | dbias (D)] of the forward direction (autograd of :31-33). */
+int mivae_actnorm_bwd(const void* dout, const void* z, const float* log_scale, const int64_t* mask,
+                      void* dz, float* dparams, float* workspace, int64_t Bn, int64_t mask_div,
+                      int64_t S, int64_t D, int dtype, void* stream);
+/* column mean and unbiased std over all rows, padding included: the data-dependent init statistics
+ * of actnorm.py:22-28. */
+int mivae_actnorm_stats(const void* z, float* mean, float* std, float* workspace, int64_t rows,
+                        int64_t D, int dtype, void* stream);
+
+/* ---- KL / ELBO tail -------------------------------------------------------------------------------- */
+/* kl = clamp(logq - logp, min = free_bits) (clamp only if use_fb).  Replaces DefaultKLLoss.forward
+ * nn/kl_loss.py:38-49 and _free_bits_kl :14-21. */
+int mivae_kl_fwd(const float* logq, const float* logp, float* kl, int64_t n, int use_fb,
+                 float free_bits, void* stream);
+int mivae_kl_bwd(const float* logq, const float* logp, const float* dkl, float* dq, float* dp,
+                 int64_t n, int use_fb, float free_bits, void* stream);
+/* out3 = {batch-loss, batch-kl, batch-nll}: loss = wr*recon + wk*kl per (b, j); IWAE softmax-weighted
+ * sum over the n samples (weights not detached); means.  Replaces VAELmModel.forward's tail,
+ * models/base/model.py:171-193. */
+int mivae_elbo_fwd(const float* recon, const float* kl, float* out3, int64_t B, int64_t n,
+                   float recon_weight, float kl_weight, int iwae, void* stream);
+int mivae_elbo_bwd(const float* recon, const float* kl, const float* gout3, float* drecon, float* dkl,
+                   int64_t B, int64_t n, float recon_weight, float kl_weight, int iwae, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIVAE_H */

@@ -1,0 +1,14 @@
+"""nonauto_lm_amd: MI355X-native latent hot path of Nemexur/nonauto-lm (flow stack, posterior
+reparameterisation + log q, base log p, KL / ELBO) behind the reference's module API.
+
+HIP kernels + C ABI: csrc/ -> lib/libmivae.so (include/mivae.h); host mirror: this package."""
+from . import _lib, ops
+from .flows import (ActNorm, Coupling, FeedForwardCoupling, Flow, InvertibleLinear,
+                    InvertibleLinearFlow, InvertibleMultiHeadFlow, NICECoupling)
+from .latent import (DefaultKLLoss, DefaultPosterior, DefaultPrior, FlowPrior, KLLoss, LatentSample,
+                     Posterior, PosteriorSample, Prior, PriorSample)
+from .model import NonAutoModel, SimpleVocab, VAELmModel, WeightScheduler
+from .nn_bracket import Activation, FeedForward, LabelSmoothingNLL
+from .registrable import FromParams, Registrable
+
+__all__ = [n for n in dir() if not n.startswith("_")]

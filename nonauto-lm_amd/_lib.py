@@ -1,0 +1,104 @@
+"""ctypes binding of libmivae.so -- the C-ABI boundary declared in include/mivae.h.
+
+No torch types cross the boundary: raw device pointers, sizes and the HIP stream handle only.
+The library is mandatory: there is no CPU or eager-PyTorch fallback for the hot path.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmivae.so")
+
+P = ctypes.c_void_p
+I64 = ctypes.c_int64
+I32 = ctypes.c_int
+F32 = ctypes.c_float
+
+# name -> argument ctypes (every entry returns int status unless listed in _RET)
+SIGNATURES = {
+    "mivae_version": [],
+    "mivae_last_error": [],
+    "mivae_tokens_mask": [P, P, I64, P],
+    "mivae_gather_last": [P, P, P, P, I64, I64, I64, I32, P],
+    "mivae_reparam_logq_fwd": [P, P, P, P, P, P, I64, I64, I64, I64, I32, P],
+    "mivae_reparam_logq_bwd": [P, P, P, P, P, P, P, I64, I64, I64, I64, I32, P],
+    "mivae_gauss_logprob_fwd": [P, P, P, I64, I64, I64, I64, F32, F32, I32, P],
+    "mivae_gauss_logprob_bwd": [P, P, P, P, I64, I64, I64, I64, F32, F32, I32, P],
+    "mivae_segment_sum": [P, P, P, I64, I64, P],
+    "mivae_mask_count": [P, P, I64, I64, I64, P],
+    "mivae_nice_affine_fwd": [P, P, P, P, P, P, I64, I64, I64, I64, I32, I32, P],
+    "mivae_nice_affine_bwd": [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I32, I32, P],
+    "mivae_actnorm_fwd": [P, P, P, P, P, P, I64, I64, I64, I64, I64, I32, I32, I32, P],
+    "mivae_col_workspace_floats": [I64, I64, I32],
+    "mivae_actnorm_bwd": [P, P, P, P, P, P, P, I64, I64, I64, I64, I32, P],
+    "mivae_actnorm_stats": [P, P, P, P, I64, I64, I32, P],
+    "mivae_kl_fwd": [P, P, P, I64, I32, F32, P],
+    "mivae_kl_bwd": [P, P, P, P, P, I64, I32, F32, P],
+    "mivae_elbo_fwd": [P, P, P, I64, I64, F32, F32, I32, P],
+    "mivae_elbo_bwd": [P, P, P, P, P, I64, I64, F32, F32, I32, P],
+    "mivae_nice_pack_bytes": [I64, I64, I32],
+    "mivae_nice_pack": [P, P, I64, I64, I64, I32, P],
+    "mivae_nice_stack_fwd": [P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I32, I32, I32, F32, F32, I32, P],
+    "mivae_nice_stack_npad": [I64],
+    "mivae_nice_stack_bwd": [P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I32, I32, F32, F32, I32, P],
+}
+_RET = {
+    "mivae_last_error": ctypes.c_char_p,
+    "mivae_col_workspace_floats": I64,
+    "mivae_nice_pack_bytes": I64,
+    "mivae_nice_stack_npad": I64,
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: run `python nonauto-lm_amd/build.py` (hipcc, gfx950). "
+                "The HIP extension is mandatory; there is no fallback path.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(handle, name)      # AttributeError if the .so lacks a declared symbol
+            fn.argtypes = args
+            fn.restype = _RET.get(name, ctypes.c_int)
+        _lib = handle
+    return _lib
+
+
+def dtype_code(dtype):
+    if dtype == torch.float32:
+        return 0
+    if dtype == torch.bfloat16:
+        return 1
+    raise TypeError(f"libmivae supports float32 and bfloat16 latents, got {dtype}")
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "nonauto_lm_amd: the latent hot path runs only on the GPU (HIP kernels via "
+                "libmivae.so); got a CPU tensor. There is no CPU fallback by design.")
+
+
+def call(name, *args):
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {lib().mivae_last_error().decode()}")
+
+
+def query(name, *args):
+    return getattr(lib(), name)(*args)

@@ -1,0 +1,56 @@
+"""In-tree build of libmivae.so (hand-written HIP kernels + C ABI) for gfx950.
+
+hipcc cross-compiles without a GPU; the .so is git-ignored but travels with the gpurun snapshot.
+Usage:  python nonauto-lm_amd/build.py [--force]
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libmivae.so")
+SOURCES = ["elementwise.hip", "nice_fused.hip", "gemm_nt.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
+         "-Wno-unused-result"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(LIBDIR, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    objs = [os.path.join(LIBDIR, os.path.basename(s)[:-4] + ".o") for s in srcs]
+
+    def compile_one(pair):
+        src, obj = pair
+        if force or _newer(obj, [src] + headers):
+            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            return True
+        return False
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        rebuilt = list(ex.map(compile_one, zip(srcs, objs)))
+    if force or any(rebuilt) or _newer(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,951 @@
+// HBM-bound kernels of the latent path: masks, posterior reparameterisation + log q, base log p,
+// NICE affine tail, ActNorm, per-sentence (segment) sums, KL / ELBO tail.
+//
+// Common shape: a latent tensor is `rows x D` with rows = (B*n)*S tokens, row-major.  L lanes
+// (power of two <= 64) cooperate on one token row with 16-byte accesses; per-token sums are reduced
+// with wavefront shuffles (__shfl_xor over the L-lane group) and written as one fp32 per token;
+// per-sentence sums are a second, fixed-order pass (segment_sum) -- no float atomics anywhere, so
+// results are run-to-run deterministic.  All accumulation is fp32 regardless of the I/O dtype.
+#include "common.hpp"
+#include <stdarg.h>
+
+using namespace mivae;
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing (thread-local last error, SURVEY 8b "Error convention")
+static thread_local char g_err[512] = "";
+void mivae_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* mivae_last_error(void) { return g_err; }
+extern "C" int mivae_version(void) { return 100; }
+
+namespace {
+
+constexpr int kBlock = 256;
+
+struct RowCfg {
+  int vec;
+  int L;
+  unsigned grid;
+};
+
+// vec_max = 4 (f32) or 8 (bf16); `width` is the row width the lanes tile (D, or h for half rows).
+static RowCfg row_cfg(int64_t rows, int64_t width, int dtype, bool aligned) {
+  RowCfg c;
+  int vmax = dtype == MIVAE_BF16 ? 8 : 4;
+  c.vec = (aligned && width % vmax == 0) ? vmax : 1;
+  c.L = lanes_per_row(width, c.vec);
+  int rows_per_block = kBlock / c.L;
+  c.grid = (unsigned)((rows + rows_per_block - 1) / rows_per_block);
+  if (c.grid == 0) c.grid = 1;
+  return c;
+}
+
+#define DISPATCH(dtype, vec, FN, ...)                                  \
+  do {                                                                   \
+    if ((dtype) == MIVAE_F32) {                                          \
+      if ((vec) == 4) FN<float, 4>(__VA_ARGS__);                         \
+      else FN<float, 1>(__VA_ARGS__);                                    \
+    } else {                                                             \
+      if ((vec) == 8) FN<unsigned short, 8>(__VA_ARGS__);                \
+      else FN<unsigned short, 1>(__VA_ARGS__);                           \
+    }                                                                    \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// a1: get_tokens_mask  (vae_lm/nn/utils.py:12-14)  -- integer, bit exact
+__global__ void k_tokens_mask(const int64_t* __restrict__ tok, int64_t* __restrict__ mask, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) mask[i] = tok[i] != 0 ? 1 : 0;
+}
+
+// a2: last-token gather (encoders/encoder.py:35-37).  One block per batch row.
+template <typename T>
+__global__ void k_gather_last(const T* __restrict__ out, const int64_t* __restrict__ mask,
+                              T* __restrict__ ctx, int64_t* __restrict__ last_idx, int S, int E) {
+  __shared__ long long s_cnt[kBlock / 64];
+  __shared__ long long s_total;
+  int b = blockIdx.x;
+  long long c = 0;
+  for (int s = threadIdx.x; s < S; s += blockDim.x) c += mask[(int64_t)b * S + s];
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+  if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    long long t = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += s_cnt[w];
+    s_total = t;
+  }
+  __syncthreads();
+  long long idx = s_total - 1;
+  if (threadIdx.x == 0 && last_idx) last_idx[b] = idx;
+  if (idx < 0) idx += S;  // torch advanced indexing wraps -1 to the last position
+  if (idx >= S) idx = S - 1;
+  const T* src = out + ((int64_t)b * S + idx) * E;
+  for (int e = threadIdx.x; e < E; e += blockDim.x) ctx[(int64_t)b * E + e] = src[e];
+}
+
+// ------------------------------------------------------------------------------------------------
+// a4 + a5: z = (mu + eps * sigma) * mask ; tok_logq = mask * sum_d -1/2 ((z-mu)^2 / sigma^2 + 2 log sigma + log 2pi)
+// rows over (b, j, s); mu/sigma are (B, S, D), eps/z are ((B n), S, D).  posterior.py:119-133,157-172.
+template <typename T, int VEC>
+__global__ void k_reparam_fwd(const T* __restrict__ mu, const T* __restrict__ sigma,
+                              const T* __restrict__ eps, const int64_t* __restrict__ mask,
+                              T* __restrict__ z, float* __restrict__ tok_logq, int64_t rows, int n,
+                              int S, int D, int L) {
+  int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t row = tid / L;
+  int lig = (int)(tid % L);
+  float acc = 0.f;
+  if (row < rows) {
+    int64_t bn = row / S;
+    int s = (int)(row - bn * S);
+    int64_t b = bn / n;
+    int64_t prow = b * S + s;
+    float m = mask ? (float)mask[prow] : 1.f;
+    for (int c = lig * VEC; c < D; c += L * VEC) {
+      float vm[VEC], vs[VEC], ve[VEC], vz[VEC];
+      RowIO<T, VEC>::load(mu + prow * D + c, vm);
+      RowIO<T, VEC>::load(sigma + prow * D + c, vs);
+      if (eps) RowIO<T, VEC>::load(eps + row * D + c, ve);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        float e = eps ? ve[i] : 0.f;
+        float zz = (vm[i] + e * vs[i]) * m;
+        float d = zz - vm[i];
+        float sg = vs[i];
+        acc += -0.5f * (d * d * (1.0f / (sg * sg)) + 2.0f * logf(sg) + kLog2Pi);
+        vz[i] = zz;
+      }
+      RowIO<T, VEC>::store(z + row * D + c, vz);
+    }
+    acc *= m;
+  }
+  acc = group_sum(acc, L);
+  if (row < rows && lig == 0) tok_logq[row] = acc;
+}
+
+// backward: rows over (b, s); sums the n samples in fixed order.
+//   dmu = sum_j dz_j * m ; dsigma = sum_j (dz_j * eps_j - dlogq_j / sigma) * m
+template <typename T, int VEC>
+__global__ void k_reparam_bwd(const T* __restrict__ dz, const float* __restrict__ dlogq,
+                              const T* __restrict__ sigma, const T* __restrict__ eps,
+                              const int64_t* __restrict__ mask, T* __restrict__ dmu,
+                              T* __restrict__ dsigma, int64_t prows, int n, int S, int D, int L) {
+  int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t prow = tid / L;
+  int lig = (int)(tid % L);
+  if (prow >= prows) return;
+  int64_t b = prow / S;
+  int s = (int)(prow - b * S);
+  float m = mask ? (float)mask[prow] : 1.f;
+  for (int c = lig * VEC; c < D; c += L * VEC) {
+    float vs[VEC], am[VEC], as[VEC];
+    RowIO<T, VEC>::load(sigma + prow * D + c, vs);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { am[i] = 0.f; as[i] = 0.f; }
+    for (int j = 0; j < n; ++j) {
+      int64_t bn = b * n + j;
+      int64_t row = bn * S + s;
+      float g[VEC], e[VEC];
+      if (dz) RowIO<T, VEC>::load(dz + row * D + c, g);
+      if (eps) RowIO<T, VEC>::load(eps + row * D + c, e);
+      float dq = dlogq ? dlogq[bn] : 0.f;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        float gi = dz ? g[i] : 0.f;
+        float ei = eps ? e[i] : 0.f;
+        am[i] += gi;
+        as[i] += gi * ei - dq / vs[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { am[i] *= m; as[i] *= m; }
+    RowIO<T, VEC>::store(dmu + prow * D + c, am);
+    RowIO<T, VEC>::store(dsigma + prow * D + c, as);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a15: base Gaussian log prob per token: tok = m * sum_d ( -(z-mu)^2/(2 std^2) - log std - 1/2 log 2pi )
+// (torch.distributions.Normal.log_prob; nonauto priors/prior.py:148-158).  If tok_add != null the
+// per-token value is added to it (used to fold in per-token log-dets).
+template <typename T, int VEC>
+__global__ void k_gauss_logprob_fwd(const T* __restrict__ z, const int64_t* __restrict__ mask,
+                                    float* __restrict__ tok, int64_t rows, int mask_div, int S,
+                                    int D, int L, float mu, float inv2var, float cst) {
+  int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t row = tid / L;
+  int lig = (int)(tid % L);
+  float acc = 0.f;
+  float m = 1.f;
+  if (row < rows) {
+    if (mask) {
+      int64_t bn = row / S;
+      m = (float)mask[(bn / mask_div) * S + (row - bn * S)];
+    }
+    for (int c = lig * VEC; c < D; c += L * VEC) {
+      float v[VEC];
+      RowIO<T, VEC>::load(z + row * D + c, v);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        float d = v[i] - mu;
+        acc += -(d * d) * inv2var - cst;
+      }
+    }
+    acc *= m;
+  }
+  acc = group_sum(acc, L);
+  if (row < rows && lig == 0) tok[row] = acc;
+}
+
+// dz = dlogp[bn] * m * (-(z - mu) / std^2)
+template <typename T, int VEC>
+__global__ void k_gauss_logprob_bwd(const T* __restrict__ z, const int64_t* __restrict__ mask,
+                                    const float* __restrict__ dlogp, T* __restrict__ dz,
+                                    int64_t rows, int mask_div, int S, int D, int L, float mu,
+                                    float invvar) {
+  int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t row = tid / L;
+  int lig = (int)(tid % L);
+  if (row >= rows) return;
+  int64_t bn = row / S;
+  float m = mask ? (float)mask[(bn / mask_div) * S + (row - bn * S)] : 1.f;
+  float g = dlogp[bn] * m;
+  for (int c = lig * VEC; c < D; c += L * VEC) {
+    float v[VEC], o[VEC];
+    RowIO<T, VEC>::load(z + row * D + c, v);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) o[i] = -g * (v[i] - mu) * invvar;
+    RowIO<T, VEC>::store(dz + row * D + c, o);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-sentence sums: out[b] = scale * sum_s tok[b, s] (+ add[b]).  One wave per sentence, lanes
+// stride over s, shuffle tree at the end: fixed order for a given S.
+__global__ void k_segment_sum(const float* __restrict__ tok, const float* __restrict__ add,
+                              float* __restrict__ out, int64_t nseg, int S) {
+  int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int lane = threadIdx.x & 63;
+  float acc = 0.f;
+  if (wave < nseg)
+    for (int s = lane; s < S; s += 64) acc += tok[wave * S + s];
+  acc = group_sum(acc, 64);
+  if (wave < nseg && lane == 0) out[wave] = acc + (add ? add[wave] : 0.f);
+}
+
+// integer token counts per (repeated) sentence: count[bn] = sum_s mask[bn / mask_div, s]
+__global__ void k_mask_count(const int64_t* __restrict__ mask, int64_t* __restrict__ count,
+                             int64_t nseg, int mask_div, int S) {
+  int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int lane = threadIdx.x & 63;
+  long long acc = 0;
+  if (wave < nseg)
+    for (int s = lane; s < S; s += 64) acc += mask[(wave / mask_div) * S + s];
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (wave < nseg && lane == 0) count[wave] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a8/a9 affine tail of NICECoupling given s,t (rows x h): couplings.py:151-162 / :172-183.
+template <typename T, int VEC>
+__global__ void k_nice_affine_fwd(const T* __restrict__ z, const T* __restrict__ s,
+                                  const T* __restrict__ t, const int64_t* __restrict__ mask,
+                                  T* __restrict__ out, float* __restrict__ tok_ld, int64_t rows,
+                                  int mask_div, int S, int h, int L, int inverse) {
+  int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t row = tid / L;
+  int lig = (int)(tid % L);
+  float acc = 0.f;
+  if (row < rows) {
+    float m = 1.f;
+    if (mask) {
+      int64_t bn = row / S;
+      m = (float)mask[(bn / mask_div) * S + (row - bn * S)];
+    }
+    const int D = 2 * h;
+    for (int c = lig * VEC; c < h; c += L * VEC) {
+      float x0[VEC], x1[VEC], vs[VEC], vt[VEC], y1[VEC];
+      RowIO<T, VEC>::load(z + row * D + c, x0);
+      RowIO<T, VEC>::load(z + row * D + h + c, x1);
+      RowIO<T, VEC>::load(s + row * h + c, vs);
+      RowIO<T, VEC>::load(t + row * h + c, vt);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        if (!inverse) {
+          y1[i] = (expf(vs[i]) * x1[i] + vt[i]) * m;
+          acc += vs[i];
+        } else {
+          y1[i] = ((x1[i] - vt[i]) * expf(-vs[i])) * m;
+          acc -= vs[i];
+        }
+        x0[i] *= m;
+      }
+      RowIO<T, VEC>::store(out + row * D + c, x0);
+      RowIO<T, VEC>::store(out + row * D + h + c, y1);
+    }
+    acc *= m;
+  }
+  acc = group_sum(acc, L);
+  if (row < rows && lig == 0) tok_ld[row] = acc;
+}
+
+template <typename T, int VEC>
+__global__ void k_nice_affine_bwd(const T* __restrict__ dout, const float* __restrict__ dld,
+                                  const T* __restrict__ z, const T* __restrict__ s,
+                                  const T* __restrict__ t, const int64_t* __restrict__ mask,
+                                  T* __restrict__ dz, T* __restrict__ ds, T* __restrict__ dt,
+                                  int64_t rows, int mask_div, int S, int h, int L, int inverse) {
+  int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t row = tid / L;
+  int lig = (int)(tid % L);
+  if (row >= rows) return;
+  int64_t bn = row / S;
+  float m = mask ? (float)mask[(bn / mask_div) * S + (row - bn * S)] : 1.f;
+  float gl = dld ? dld[bn] * m : 0.f;
+  const int D = 2 * h;
+  for (int c = lig * VEC; c < h; c += L * VEC) {
+    float g0[VEC], g1[VEC], x1[VEC], vs[VEC], vt[VEC], o1[VEC], os[VEC], ot[VEC];
+    RowIO<T, VEC>::load(dout + row * D + c, g0);
+    RowIO<T, VEC>::load(dout + row * D + h + c, g1);
+    RowIO<T, VEC>::load(z + row * D + h + c, x1);
+    RowIO<T, VEC>::load(s + row * h + c, vs);
+    if (inverse) RowIO<T, VEC>::load(t + row * h + c, vt);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      float g = g1[i] * m;
+      if (!inverse) {
+        float e = expf(vs[i]);
+        o1[i] = g * e;
+        os[i] = g * e * x1[i] + gl;
+        ot[i] = g;
+      } else {
+        float e = expf(-vs[i]);
+        o1[i] = g * e;
+        ot[i] = -g * e;
+        os[i] = -g * (x1[i] - vt[i]) * e - gl;
+      }
+      g0[i] *= m;
+    }
+    RowIO<T, VEC>::store(dz + row * D + c, g0);
+    RowIO<T, VEC>::store(dz + row * D + h + c, o1);
+    RowIO<T, VEC>::store(ds + row * h + c, os);
+    RowIO<T, VEC>::store(dt + row * h + c, ot);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a12/a13 ActNorm (actnorm.py:31-33 forward, :45-48 inverse).  Parameters are fp32.
+template <typename T, int VEC>
+__global__ void k_actnorm_fwd(const T* __restrict__ z, const float* __restrict__ log_scale,
+                              const float* __restrict__ bias, const int64_t* __restrict__ mask,
+                              T* __restrict__ out, int64_t rows, int mask_div, int S, int D, int L,
+                              int inverse) {
+  int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t row = tid / L;
+  int lig = (int)(tid % L);
+  if (row >= rows) return;
+  float m = 1.f;
+  if (mask) {
+    int64_t bn = row / S;
+    m = (float)mask[(bn / mask_div) * S + (row - bn * S)];
+  }
+  for (int c = lig * VEC; c < D; c += L * VEC) {
+    float v[VEC], o[VEC];
+    RowIO<T, VEC>::load(z + row * D + c, v);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      float e = expf(log_scale[c + i]);
+      if (!inverse) o[i] = (v[i] * e + bias[c + i]) * m;
+      else o[i] = ((v[i] - bias[c + i]) * m) / (e + 1e-13f);
+    }
+    RowIO<T, VEC>::store(out + row * D + c, o);
+  }
+}
+
+// log_det[bn] = sign * (sum_d log_scale[d]) * count[bn]   (count = integer token count, or 1 when
+// there is no mask / 2-D input, in which case the caller passes nseg = 1).  One wave per output.
+__global__ void k_actnorm_logdet(const float* __restrict__ log_scale, const int64_t* __restrict__ mask,
+                                 float* __restrict__ out, int64_t nseg, int mask_div, int S, int D,
+                                 float sign) {
+  int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int lane = threadIdx.x & 63;
+  float acc = 0.f;
+  for (int d = lane; d < D; d += 64) acc += log_scale[d];
+  acc = group_sum(acc, 64);
+  long long cnt = 0;
+  if (mask && wave < nseg)
+    for (int s = lane; s < S; s += 64) cnt += mask[(wave / mask_div) * S + s];
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+  if (wave < nseg && lane == 0) out[wave] = sign * acc * (mask ? (float)cnt : 1.f);
+}
+
+// Column reductions over token rows (two stage, fixed order).  Each block owns a contiguous chunk
+// of rows; lanes own VEC columns; partial[block][NV][D] then k_col_finish sums blocks in order.
+//   MODE 0: v0 = x                       (mean pass of the ActNorm init)
+//   MODE 1: v0 = (x - aux[c])^2          (variance pass)
+//   MODE 2: ActNorm backward: g = dout*m ; dz = g*exp(ls) ; v0 = g*x*exp(ls) ; v1 = g
+template <typename T, int VEC, int MODE>
+__global__ void k_col_partial(const T* __restrict__ x, const T* __restrict__ dout,
+                              const float* __restrict__ aux, const int64_t* __restrict__ mask,
+                              T* __restrict__ dz, float* __restrict__ partial, int64_t rows,
+                              int rows_per_block, int mask_div, int S, int D, int L) {
+  constexpr int NV = MODE == 2 ? 2 : 1;
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [rows_in_flight][NV][L*VEC]
+  const int rif = blockDim.x / L;                               // rows in flight
+  const int rg = threadIdx.x / L;
+  const int lig = threadIdx.x % L;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
+  for (int cbase = 0; cbase < D; cbase += L * VEC) {
+    const int c = cbase + lig * VEC;
+    float a0[VEC], a1[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { a0[i] = 0.f; a1[i] = 0.f; }
+    if (c < D) {
+      float ax[VEC];
+      if (MODE != 0) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) ax[i] = MODE == 2 ? expf(aux[c + i]) : aux[c + i];
+      }
+      for (int64_t row = r0 + rg; row < r1; row += rif) {
+        float v[VEC];
+        RowIO<T, VEC>::load(x + row * D + c, v);
+        if (MODE == 0) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) a0[i] += v[i];
+        } else if (MODE == 1) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) { float d = v[i] - ax[i]; a0[i] += d * d; }
+        } else {
+          float m = 1.f;
+          if (mask) {
+            int64_t bn = row / S;
+            m = (float)mask[(bn / mask_div) * S + (row - bn * S)];
+          }
+          float g[VEC], o[VEC];
+          RowIO<T, VEC>::load(dout + row * D + c, g);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) {
+            float gi = g[i] * m;
+            o[i] = gi * ax[i];
+            a0[i] += gi * v[i] * ax[i];
+            a1[i] += gi;
+          }
+          RowIO<T, VEC>::store(dz + row * D + c, o);
+        }
+      }
+    }
+    // combine the row groups of this block in fixed order
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      smem[(rg * NV + 0) * (L * VEC) + lig * VEC + i] = a0[i];
+      if (NV == 2) smem[(rg * NV + 1) * (L * VEC) + lig * VEC + i] = a1[i];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < NV * L * VEC; idx += blockDim.x) {
+      int v = idx / (L * VEC);
+      int cc = idx % (L * VEC);
+      if (cbase + cc < D) {
+        float sum = 0.f;
+        for (int g = 0; g < rif; ++g) sum += smem[(g * NV + v) * (L * VEC) + cc];
+        partial[((int64_t)blockIdx.x * NV + v) * D + cbase + cc] = sum;
+      }
+    }
+  }
+}
+
+// out[v][c] = scale * sum_blocks partial[blk][v][c]; MODE_FIN 1: std = sqrt(sum / (rows - 1))
+__global__ void k_col_finish(const float* __restrict__ partial, float* __restrict__ out, int nblk,
+                             int nv, int D, float scale, int take_sqrt) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nv * D) return;
+  int v = idx / D, c = idx % D;
+  float sum = 0.f;
+  for (int b = 0; b < nblk; ++b) sum += partial[((int64_t)b * nv + v) * D + c];
+  sum *= scale;
+  out[idx] = take_sqrt ? sqrtf(sum) : sum;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a16: DefaultKLLoss (kl_loss.py:38-49): kl = clamp(logq - logp, min=free_bits)
+__global__ void k_kl_fwd(const float* __restrict__ logq, const float* __restrict__ logp,
+                         float* __restrict__ kl, int64_t n, int use_fb, float fb) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = logq[i] - logp[i];
+  if (use_fb) v = v < fb ? fb : v;   // NaN propagates like torch.clamp
+  kl[i] = v;
+}
+__global__ void k_kl_bwd(const float* __restrict__ logq, const float* __restrict__ logp,
+                         const float* __restrict__ dkl, float* __restrict__ dq,
+                         float* __restrict__ dp, int64_t n, int use_fb, float fb) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = logq[i] - logp[i];
+  float g = (use_fb && !(v >= fb)) ? 0.f : dkl[i];
+  dq[i] = g;
+  dp[i] = -g;
+}
+
+// a17: ELBO tail (models/base/model.py:171-193).  Single block; out = {batch-loss, batch-kl, batch-nll}.
+__device__ float block_sum_256(float v, float* red) {
+  v = group_sum(v, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+  return t;
+}
+
+__global__ void k_elbo_fwd(const float* __restrict__ recon, const float* __restrict__ kl,
+                           float* __restrict__ out, int B, int n, float wr, float wk, int iwae) {
+  __shared__ float red[8];
+  float a_loss = 0.f, a_kl = 0.f, a_nll = 0.f;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    float mx = -INFINITY;
+    for (int j = 0; j < n; ++j) {
+      float r = recon[b * n + j], k = kl[b * n + j];
+      a_kl += k;
+      a_nll += r;
+      float l = wr * r + wk * k;
+      if (iwae) mx = fmaxf(mx, l);
+      else a_loss += l;
+    }
+    if (iwae) {
+      float den = 0.f, num = 0.f;
+      for (int j = 0; j < n; ++j) {
+        float l = wr * recon[b * n + j] + wk * kl[b * n + j];
+        float e = expf(l - mx);
+        den += e;
+        num += e * l;
+      }
+      a_loss += num / den;
+    }
+  }
+  float t_loss = block_sum_256(a_loss, red);
+  float t_kl = block_sum_256(a_kl, red);
+  float t_nll = block_sum_256(a_nll, red);
+  if (threadIdx.x == 0) {
+    out[0] = t_loss / (iwae ? (float)B : (float)B * n);
+    out[1] = t_kl / ((float)B * n);
+    out[2] = t_nll / ((float)B * n);
+  }
+}
+
+// gout = {d batch-loss, d batch-kl, d batch-nll}
+__global__ void k_elbo_bwd(const float* __restrict__ recon, const float* __restrict__ kl,
+                           const float* __restrict__ gout, float* __restrict__ drecon,
+                           float* __restrict__ dkl, int B, int n, float wr, float wk, int iwae) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float gl = gout[0], gk = gout[1] / ((float)B * n), gn = gout[2] / ((float)B * n);
+  if (!iwae) {
+    float c = gl / ((float)B * n);
+    for (int j = 0; j < n; ++j) {
+      drecon[b * n + j] = wr * c + gn;
+      dkl[b * n + j] = wk * c + gk;
+    }
+    return;
+  }
+  float mx = -INFINITY;
+  for (int j = 0; j < n; ++j) mx = fmaxf(mx, wr * recon[b * n + j] + wk * kl[b * n + j]);
+  float den = 0.f, num = 0.f;
+  for (int j = 0; j < n; ++j) {
+    float l = wr * recon[b * n + j] + wk * kl[b * n + j];
+    float e = expf(l - mx);
+    den += e;
+    num += e * l;
+  }
+  float mean = num / den;
+  for (int j = 0; j < n; ++j) {
+    float l = wr * recon[b * n + j] + wk * kl[b * n + j];
+    float w = expf(l - mx) / den;
+    float c = gl / (float)B * w * (1.f + l - mean);
+    drecon[b * n + j] = wr * c + gn;
+    dkl[b * n + j] = wk * c + gk;
+  }
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+#define S_(x) ((hipStream_t)(x))
+
+extern "C" int mivae_tokens_mask(const int64_t* tokens, int64_t* mask, int64_t n, void* stream) {
+  MIVAE_REQUIRE(n >= 0, "tokens_mask: n < 0");
+  if (n == 0) return MIVAE_OK;
+  MIVAE_REQUIRE(tokens && mask, "tokens_mask: null pointer");
+  unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
+  if (grid > 4096) grid = 4096;
+  k_tokens_mask<<<grid, kBlock, 0, S_(stream)>>>(tokens, mask, n);
+  MIVAE_CHECK_LAUNCH("tokens_mask");
+  return MIVAE_OK;
+}
+
+extern "C" int mivae_gather_last(const void* out, const int64_t* mask, void* ctx, int64_t* last_idx,
+                                 int64_t B, int64_t S, int64_t E, int dtype, void* stream) {
+  MIVAE_REQUIRE(B >= 0 && S > 0 && E > 0, "gather_last: bad shape B=%ld S=%ld E=%ld", (long)B, (long)S, (long)E);
+  if (B == 0) return MIVAE_OK;
+  MIVAE_REQUIRE(out && mask && ctx, "gather_last: null pointer");
+  MIVAE_REQUIRE(dtype == MIVAE_F32 || dtype == MIVAE_BF16, "gather_last: bad dtype %d", dtype);
+  if (dtype == MIVAE_F32)
+    k_gather_last<float><<<(unsigned)B, kBlock, 0, S_(stream)>>>((const float*)out, mask, (float*)ctx, last_idx, (int)S, (int)E);
+  else
+    k_gather_last<unsigned short><<<(unsigned)B, kBlock, 0, S_(stream)>>>((const unsigned short*)out, mask, (unsigned short*)ctx, last_idx, (int)S, (int)E);
+  MIVAE_CHECK_LAUNCH("gather_last");
+  return MIVAE_OK;
+}
+
+static int check_latent(const char* name, int64_t Bn, int64_t S, int64_t D, int dtype) {
+  MIVAE_REQUIRE(Bn >= 0 && S > 0 && D > 0, "%s: bad shape Bn=%ld S=%ld D=%ld", name, (long)Bn, (long)S, (long)D);
+  MIVAE_REQUIRE(dtype == MIVAE_F32 || dtype == MIVAE_BF16, "%s: bad dtype %d", name, dtype);
+  MIVAE_REQUIRE(Bn * S < (1ll << 40) && D < (1 << 24) && S < (1ll << 31), "%s: shape too large", name);
+  return MIVAE_OK;
+}
+
+
+namespace {
+// ---- typed launchers (void* -> T*) ---------------------------------------------------------------
+template <typename T, int VEC>
+void l_reparam_fwd(const void* mu, const void* sigma, const void* eps, const int64_t* mask, void* z,
+                   float* tok, int64_t rows, int n, int S, int D, RowCfg c, hipStream_t st) {
+  k_reparam_fwd<T, VEC><<<c.grid, kBlock, 0, st>>>((const T*)mu, (const T*)sigma, (const T*)eps, mask,
+                                                  (T*)z, tok, rows, n, S, D, c.L);
+}
+template <typename T, int VEC>
+void l_reparam_bwd(const void* dz, const float* dlogq, const void* sigma, const void* eps,
+                   const int64_t* mask, void* dmu, void* dsigma, int64_t prows, int n, int S, int D,
+                   RowCfg c, hipStream_t st) {
+  k_reparam_bwd<T, VEC><<<c.grid, kBlock, 0, st>>>((const T*)dz, dlogq, (const T*)sigma, (const T*)eps,
+                                                  mask, (T*)dmu, (T*)dsigma, prows, n, S, D, c.L);
+}
+template <typename T, int VEC>
+void l_gauss_fwd(const void* z, const int64_t* mask, float* tok, int64_t rows, int mask_div, int S,
+                 int D, float mu, float inv2var, float cst, RowCfg c, hipStream_t st) {
+  k_gauss_logprob_fwd<T, VEC><<<c.grid, kBlock, 0, st>>>((const T*)z, mask, tok, rows, mask_div, S, D,
+                                                        c.L, mu, inv2var, cst);
+}
+template <typename T, int VEC>
+void l_gauss_bwd(const void* z, const int64_t* mask, const float* dlogp, void* dz, int64_t rows,
+                 int mask_div, int S, int D, float mu, float invvar, RowCfg c, hipStream_t st) {
+  k_gauss_logprob_bwd<T, VEC><<<c.grid, kBlock, 0, st>>>((const T*)z, mask, dlogp, (T*)dz, rows,
+                                                        mask_div, S, D, c.L, mu, invvar);
+}
+template <typename T, int VEC>
+void l_affine_fwd(const void* z, const void* s, const void* t, const int64_t* mask, void* out,
+                  float* tok, int64_t rows, int mask_div, int S, int h, int inverse, RowCfg c,
+                  hipStream_t st) {
+  k_nice_affine_fwd<T, VEC><<<c.grid, kBlock, 0, st>>>((const T*)z, (const T*)s, (const T*)t, mask,
+                                                      (T*)out, tok, rows, mask_div, S, h, c.L, inverse);
+}
+template <typename T, int VEC>
+void l_affine_bwd(const void* dout, const float* dld, const void* z, const void* s, const void* t,
+                  const int64_t* mask, void* dz, void* ds, void* dt, int64_t rows, int mask_div,
+                  int S, int h, int inverse, RowCfg c, hipStream_t st) {
+  k_nice_affine_bwd<T, VEC><<<c.grid, kBlock, 0, st>>>((const T*)dout, dld, (const T*)z, (const T*)s,
+                                                      (const T*)t, mask, (T*)dz, (T*)ds, (T*)dt, rows,
+                                                      mask_div, S, h, c.L, inverse);
+}
+template <typename T, int VEC>
+void l_actnorm_fwd(const void* z, const float* ls, const float* bias, const int64_t* mask, void* out,
+                   int64_t rows, int mask_div, int S, int D, int inverse, RowCfg c, hipStream_t st) {
+  k_actnorm_fwd<T, VEC><<<c.grid, kBlock, 0, st>>>((const T*)z, ls, bias, mask, (T*)out, rows,
+                                                  mask_div, S, D, c.L, inverse);
+}
+template <int MODE>
+struct ColPartial {
+  template <typename T, int VEC>
+  static void run(const void* x, const void* dout, const float* aux, const int64_t* mask, void* dz,
+                  float* partial, int64_t rows, int rows_per_block, int nblk, int mask_div, int S,
+                  int D, int L, hipStream_t st) {
+    constexpr int NV = MODE == 2 ? 2 : 1;
+    size_t smem = (size_t)(kBlock / L) * NV * L * VEC * sizeof(float);
+    k_col_partial<T, VEC, MODE><<<nblk, kBlock, smem, st>>>((const T*)x, (const T*)dout, aux, mask,
+                                                           (T*)dz, partial, rows, rows_per_block,
+                                                           mask_div, S, D, L);
+  }
+};
+#define DISPATCH_COL(dtype, vec, MODE, ...)                                             \
+  do {                                                                                  \
+    if ((dtype) == MIVAE_F32) {                                                         \
+      if ((vec) == 4) ColPartial<MODE>::run<float, 4>(__VA_ARGS__);                     \
+      else ColPartial<MODE>::run<float, 1>(__VA_ARGS__);                                \
+    } else {                                                                            \
+      if ((vec) == 8) ColPartial<MODE>::run<unsigned short, 8>(__VA_ARGS__);            \
+      else ColPartial<MODE>::run<unsigned short, 1>(__VA_ARGS__);                       \
+    }                                                                                   \
+  } while (0)
+
+// column-reduction geometry shared by the size query and the launches
+struct ColCfg { int vec; int L; int nblk; int rows_per_block; };
+static ColCfg col_cfg(int64_t rows, int64_t D, int dtype, bool aligned) {
+  ColCfg c;
+  int vmax = dtype == MIVAE_BF16 ? 8 : 4;
+  c.vec = (aligned && D % vmax == 0) ? vmax : 1;
+  c.L = lanes_per_row(D, c.vec);
+  int64_t nblk = (rows + 255) / 256;      // >= 256 rows per block
+  if (nblk > 1024) nblk = 1024;
+  if (nblk < 1) nblk = 1;
+  c.rows_per_block = (int)((rows + nblk - 1) / nblk);
+  if (c.rows_per_block < 1) c.rows_per_block = 1;
+  c.nblk = (int)((rows + c.rows_per_block - 1) / c.rows_per_block);
+  if (c.nblk < 1) c.nblk = 1;
+  return c;
+}
+}  // namespace
+
+extern "C" int mivae_reparam_logq_fwd(const void* mu, const void* sigma, const void* eps,
+                                      const int64_t* mask, void* z, float* tok_logq, int64_t B,
+                                      int64_t n, int64_t S, int64_t D, int dtype, void* stream) {
+  int rc = check_latent("reparam_logq_fwd", B * n, S, D, dtype);
+  if (rc) return rc;
+  MIVAE_REQUIRE(n >= 1, "reparam_logq_fwd: samples must be >= 1");
+  if (B == 0) return MIVAE_OK;
+  MIVAE_REQUIRE(mu && sigma && z && tok_logq, "reparam_logq_fwd: null pointer");
+  int64_t rows = B * n * S;
+  bool al = aligned16(mu) && aligned16(sigma) && aligned16(z) && (!eps || aligned16(eps));
+  RowCfg c = row_cfg(rows, D, dtype, al);
+  DISPATCH(dtype, c.vec, l_reparam_fwd, mu, sigma, eps, mask, z, tok_logq, rows, (int)n, (int)S,
+           (int)D, c, S_(stream));
+  MIVAE_CHECK_LAUNCH("reparam_logq_fwd");
+  return MIVAE_OK;
+}
+
+extern "C" int mivae_reparam_logq_bwd(const void* dz, const float* dlogq, const void* sigma,
+                                      const void* eps, const int64_t* mask, void* dmu, void* dsigma,
+                                      int64_t B, int64_t n, int64_t S, int64_t D, int dtype,
+                                      void* stream) {
+  int rc = check_latent("reparam_logq_bwd", B * n, S, D, dtype);
+  if (rc) return rc;
+  MIVAE_REQUIRE(n >= 1, "reparam_logq_bwd: samples must be >= 1");
+  if (B == 0) return MIVAE_OK;
+  MIVAE_REQUIRE(sigma && dmu && dsigma, "reparam_logq_bwd: null pointer");
+  int64_t prows = B * S;
+  bool al = aligned16(sigma) && aligned16(dmu) && aligned16(dsigma) && (!dz || aligned16(dz)) &&
+            (!eps || aligned16(eps));
+  RowCfg c = row_cfg(prows, D, dtype, al);
+  DISPATCH(dtype, c.vec, l_reparam_bwd, dz, dlogq, sigma, eps, mask, dmu, dsigma, prows, (int)n,
+           (int)S, (int)D, c, S_(stream));
+  MIVAE_CHECK_LAUNCH("reparam_logq_bwd");
+  return MIVAE_OK;
+}
+
+extern "C" int mivae_gauss_logprob_fwd(const void* z, const int64_t* mask, float* tok, int64_t Bn,
+                                       int64_t mask_div, int64_t S, int64_t D, float mu, float std,
+                                       int dtype, void* stream) {
+  int rc = check_latent("gauss_logprob_fwd", Bn, S, D, dtype);
+  if (rc) return rc;
+  MIVAE_REQUIRE(std > 0.f && mask_div >= 1, "gauss_logprob_fwd: std must be > 0, mask_div >= 1");
+  if (Bn == 0) return MIVAE_OK;
+  MIVAE_REQUIRE(z && tok, "gauss_logprob_fwd: null pointer");
+  int64_t rows = Bn * S;
+  RowCfg c = row_cfg(rows, D, dtype, aligned16(z));
+  float inv2var = 1.0f / (2.0f * std * std);
+  float cst = logf(std) + 0.5f * kLog2Pi;
+  DISPATCH(dtype, c.vec, l_gauss_fwd, z, mask, tok, rows, (int)mask_div, (int)S, (int)D, mu, inv2var,
+           cst, c, S_(stream));
+  MIVAE_CHECK_LAUNCH("gauss_logprob_fwd");
+  return MIVAE_OK;
+}
+
+extern "C" int mivae_gauss_logprob_bwd(const void* z, const int64_t* mask, const float* dlogp,
+                                       void* dz, int64_t Bn, int64_t mask_div, int64_t S, int64_t D,
+                                       float mu, float std, int dtype, void* stream) {
+  int rc = check_latent("gauss_logprob_bwd", Bn, S, D, dtype);
+  if (rc) return rc;
+  MIVAE_REQUIRE(std > 0.f && mask_div >= 1, "gauss_logprob_bwd: std must be > 0, mask_div >= 1");
+  if (Bn == 0) return MIVAE_OK;
+  MIVAE_REQUIRE(z && dlogp && dz, "gauss_logprob_bwd: null pointer");
+  int64_t rows = Bn * S;
+  RowCfg c = row_cfg(rows, D, dtype, aligned16(z) && aligned16(dz));
+  DISPATCH(dtype, c.vec, l_gauss_bwd, z, mask, dlogp, dz, rows, (int)mask_div, (int)S, (int)D, mu,
+           1.0f / (std * std), c, S_(stream));
+  MIVAE_CHECK_LAUNCH("gauss_logprob_bwd");
+  return MIVAE_OK;
+}
+
+extern "C" int mivae_segment_sum(const float* tok, const float* add, float* out, int64_t nseg,
+                                 int64_t S, void* stream) {
+  MIVAE_REQUIRE(nseg >= 0 && S > 0 && S < (1ll << 31), "segment_sum: bad shape");
+  if (nseg == 0) return MIVAE_OK;
+  MIVAE_REQUIRE(tok && out, "segment_sum: null pointer");
+  unsigned grid = (unsigned)((nseg + 3) / 4);
+  k_segment_sum<<<grid, kBlock, 0, S_(stream)>>>(tok, add, out, nseg, (int)S);
+  MIVAE_CHECK_LAUNCH("segment_sum");
+  return MIVAE_OK;
+}
+
+extern "C" int mivae_mask_count(const int64_t* mask, int64_t* count, int64_t Bn, int64_t mask_div,
+                                int64_t S, void* stream) {
+  MIVAE_REQUIRE(Bn >= 0 && S > 0 && mask_div >= 1, "mask_count: bad shape");
+  if (Bn == 0) return MIVAE_OK;
+  MIVAE_REQUIRE(mask && count, "mask_count: null pointer");
+  unsigned grid = (unsigned)((Bn + 3) / 4);
+  k_mask_count<<<grid, kBlock, 0, S_(stream)>>>(mask, count, Bn, (int)mask_div, (int)S);
+  MIVAE_CHECK_LAUNCH("mask_count");
+  return MIVAE_OK;
+}
+
+extern "C" int mivae_nice_affine_fwd(const void* z, const void* s, const void* t,
+                                     const int64_t* mask, void* out, float* tok_ld, int64_t Bn,
+                                     int64_t mask_div, int64_t S, int64_t D, int dtype, int inverse,
+                                     void* stream) {
+  int rc = check_latent("nice_affine_fwd", Bn, S, D, dtype);
+  if (rc) return rc;
+  MIVAE_REQUIRE(D % 2 == 0 && mask_div >= 1, "nice_affine_fwd: D must be even");
+  if (Bn == 0) return MIVAE_OK;
+  MIVAE_REQUIRE(z && s && t && out && tok_ld, "nice_affine_fwd: null pointer");
+  int64_t rows = Bn * S, h = D / 2;
+  bool al = aligned16(z) && aligned16(s) && aligned16(t) && aligned16(out);
+  RowCfg c = row_cfg(rows, h, dtype, al);
+  DISPATCH(dtype, c.vec, l_affine_fwd, z, s, t, mask, out, tok_ld, rows, (int)mask_div, (int)S,
+           (int)h, inverse, c, S_(stream));
+  MIVAE_CHECK_LAUNCH("nice_affine_fwd");
+  return MIVAE_OK;
+}
+
+extern "C" int mivae_nice_affine_bwd(const void* dout, const float* dld, const void* z,
+                                     const void* s, const void* t, const int64_t* mask, void* dz,
+                                     void* ds, void* dt, int64_t Bn, int64_t mask_div, int64_t S,
+                                     int64_t D, int dtype, int inverse, void* stream) {
+  int rc = check_latent("nice_affine_bwd", Bn, S, D, dtype);
+  if (rc) return rc;
+  MIVAE_REQUIRE(D % 2 == 0 && mask_div >= 1, "nice_affine_bwd: D must be even");
+  if (Bn == 0) return MIVAE_OK;
+  MIVAE_REQUIRE(dout && z && s && t && dz && ds && dt, "nice_affine_bwd: null pointer");
+  int64_t rows = Bn * S, h = D / 2;
+  bool al = aligned16(dout) && aligned16(z) && aligned16(s) && aligned16(t) && aligned16(dz) &&
+            aligned16(ds) && aligned16(dt);
+  RowCfg c = row_cfg(rows, h, dtype, al);
+  DISPATCH(dtype, c.vec, l_affine_bwd, dout, dld, z, s, t, mask, dz, ds, dt, rows, (int)mask_div,
+           (int)S, (int)h, inverse, c, S_(stream));
+  MIVAE_CHECK_LAUNCH("nice_affine_bwd");
+  return MIVAE_OK;
+}
+
+extern "C" int mivae_actnorm_fwd(const void* z, const float* log_scale, const float* bias,
+                                 const int64_t* mask, void* out, float* logdet, int64_t Bn,
+                                 int64_t mask_div, int64_t S, int64_t D, int64_t n_logdet,
+                                 int count_weighted, int dtype, int inverse, void* stream) {
+  int rc = check_latent("actnorm_fwd", Bn, S, D, dtype);
+  if (rc) return rc;
+  MIVAE_REQUIRE(mask_div >= 1, "actnorm_fwd: mask_div >= 1");
+  MIVAE_REQUIRE(log_scale && bias, "actnorm_fwd: null parameter pointer");
+  if (Bn > 0) {
+    MIVAE_REQUIRE(z && out, "actnorm_fwd: null pointer");
+    int64_t rows = Bn * S;
+    RowCfg c = row_cfg(rows, D, dtype, aligned16(z) && aligned16(out));
+    DISPATCH(dtype, c.vec, l_actnorm_fwd, z, log_scale, bias, mask, out, rows, (int)mask_div, (int)S,
+             (int)D, inverse, c, S_(stream));
+    MIVAE_CHECK_LAUNCH("actnorm_fwd");
+  }
+  if (logdet && n_logdet > 0) {
+    // n_logdet = Bn and count_weighted = 1 for 3-D input with a mask, else 1 / 0 (actnorm.py:35-38)
+    MIVAE_REQUIRE(!count_weighted || mask, "actnorm_fwd: count_weighted needs a mask");
+    unsigned grid = (unsigned)((n_logdet + 3) / 4);
+    k_actnorm_logdet<<<grid, kBlock, 0, S_(stream)>>>(log_scale, count_weighted ? mask : nullptr,
+                                                    logdet, n_logdet, (int)mask_div, (int)S, (int)D,
+                                                    inverse ? -1.f : 1.f);
+    MIVAE_CHECK_LAUNCH("actnorm_logdet");
+  }
+  return MIVAE_OK;
+}
+
+extern "C" int64_t mivae_col_workspace_floats(int64_t rows, int64_t D, int dtype) {
+  ColCfg c = col_cfg(rows, D, dtype, true);
+  return (int64_t)c.nblk * 2 * D;
+}
+
+// ActNorm backward (forward direction): dz = dout*m*exp(ls); dlog_scale[d] = sum g*z*exp(ls);
+// dbias[d] = sum g.  `dparams` receives [dlog_scale (D) | dbias (D)]; the log-det term
+// (sum_b dld[b]*count[b]) is added by the caller on the D-vector (it is the same for every d).
+extern "C" int mivae_actnorm_bwd(const void* dout, const void* z, const float* log_scale,
+                                 const int64_t* mask, void* dz, float* dparams, float* workspace,
+                                 int64_t Bn, int64_t mask_div, int64_t S, int64_t D, int dtype,
+                                 void* stream) {
+  int rc = check_latent("actnorm_bwd", Bn, S, D, dtype);
+  if (rc) return rc;
+  MIVAE_REQUIRE(Bn > 0, "actnorm_bwd: empty batch");
+  MIVAE_REQUIRE(dout && z && log_scale && dz && dparams && workspace, "actnorm_bwd: null pointer");
+  int64_t rows = Bn * S;
+  ColCfg c = col_cfg(rows, D, dtype, aligned16(dout) && aligned16(z) && aligned16(dz));
+  DISPATCH_COL(dtype, c.vec, 2, z, dout, log_scale, mask, dz, workspace, rows, c.rows_per_block,
+               c.nblk, (int)mask_div, (int)S, (int)D, c.L, S_(stream));
+  MIVAE_CHECK_LAUNCH("actnorm_bwd");
+  unsigned grid = (unsigned)((2 * D + kBlock - 1) / kBlock);
+  k_col_finish<<<grid, kBlock, 0, S_(stream)>>>(workspace, dparams, c.nblk, 2, (int)D, 1.f, 0);
+  MIVAE_CHECK_LAUNCH("actnorm_bwd_finish");
+  return MIVAE_OK;
+}
+
+// Column mean and unbiased std over all rows (padding included), two passes (actnorm.py:23-24).
+extern "C" int mivae_actnorm_stats(const void* z, float* mean, float* std, float* workspace,
+                                   int64_t rows, int64_t D, int dtype, void* stream) {
+  MIVAE_REQUIRE(rows >= 2 && D > 0, "actnorm_stats: need >= 2 rows (unbiased std)");
+  MIVAE_REQUIRE(dtype == MIVAE_F32 || dtype == MIVAE_BF16, "actnorm_stats: bad dtype");
+  MIVAE_REQUIRE(z && mean && std && workspace, "actnorm_stats: null pointer");
+  ColCfg c = col_cfg(rows, D, dtype, aligned16(z));
+  unsigned grid = (unsigned)((D + kBlock - 1) / kBlock);
+  DISPATCH_COL(dtype, c.vec, 0, z, nullptr, nullptr, nullptr, nullptr, workspace, rows,
+               c.rows_per_block, c.nblk, 1, 1, (int)D, c.L, S_(stream));
+  MIVAE_CHECK_LAUNCH("actnorm_stats_mean");
+  k_col_finish<<<grid, kBlock, 0, S_(stream)>>>(workspace, mean, c.nblk, 1, (int)D, 1.f / (float)rows, 0);
+  DISPATCH_COL(dtype, c.vec, 1, z, nullptr, mean, nullptr, nullptr, workspace, rows,
+               c.rows_per_block, c.nblk, 1, 1, (int)D, c.L, S_(stream));
+  MIVAE_CHECK_LAUNCH("actnorm_stats_var");
+  k_col_finish<<<grid, kBlock, 0, S_(stream)>>>(workspace, std, c.nblk, 1, (int)D,
+                                              1.f / (float)(rows - 1), 1);
+  MIVAE_CHECK_LAUNCH("actnorm_stats_finish");
+  return MIVAE_OK;
+}
+
+extern "C" int mivae_kl_fwd(const float* logq, const float* logp, float* kl, int64_t n, int use_fb,
+                            float free_bits, void* stream) {
+  MIVAE_REQUIRE(n >= 0, "kl_fwd: n < 0");
+  if (n == 0) return MIVAE_OK;
+  MIVAE_REQUIRE(logq && logp && kl, "kl_fwd: null pointer");
+  k_kl_fwd<<<(unsigned)((n + kBlock - 1) / kBlock), kBlock, 0, S_(stream)>>>(logq, logp, kl, n, use_fb, free_bits);
+  MIVAE_CHECK_LAUNCH("kl_fwd");
+  return MIVAE_OK;
+}
+
+extern "C" int mivae_kl_bwd(const float* logq, const float* logp, const float* dkl, float* dq,
+                            float* dp, int64_t n, int use_fb, float free_bits, void* stream) {
+  MIVAE_REQUIRE(n >= 0, "kl_bwd: n < 0");
+  if (n == 0) return MIVAE_OK;
+  MIVAE_REQUIRE(logq && logp && dkl && dq && dp, "kl_bwd: null pointer");
+  k_kl_bwd<<<(unsigned)((n + kBlock - 1) / kBlock), kBlock, 0, S_(stream)>>>(logq, logp, dkl, dq, dp, n, use_fb, free_bits);
+  MIVAE_CHECK_LAUNCH("kl_bwd");
+  return MIVAE_OK;
+}
+
+extern "C" int mivae_elbo_fwd(const float* recon, const float* kl, float* out3, int64_t B, int64_t n,
+                              float recon_weight, float kl_weight, int iwae, void* stream) {
+  MIVAE_REQUIRE(B > 0 && n > 0 && B * n < (1ll << 30), "elbo_fwd: bad shape B=%ld n=%ld", (long)B, (long)n);
+  MIVAE_REQUIRE(recon && kl && out3, "elbo_fwd: null pointer");
+  k_elbo_fwd<<<1, kBlock, 0, S_(stream)>>>(recon, kl, out3, (int)B, (int)n, recon_weight, kl_weight, iwae);
+  MIVAE_CHECK_LAUNCH("elbo_fwd");
+  return MIVAE_OK;
+}
+
+extern "C" int mivae_elbo_bwd(const float* recon, const float* kl, const float* gout3, float* drecon,
+                              float* dkl, int64_t B, int64_t n, float recon_weight, float kl_weight,
+                              int iwae, void* stream) {
+  MIVAE_REQUIRE(B > 0 && n > 0 && B * n < (1ll << 30), "elbo_bwd: bad shape");
+  MIVAE_REQUIRE(recon && kl && gout3 && drecon && dkl, "elbo_bwd: null pointer");
+  k_elbo_bwd<<<(unsigned)((B + kBlock - 1) / kBlock), kBlock, 0, S_(stream)>>>(recon, kl, gout3, drecon, dkl, (int)B, (int)n, recon_weight, kl_weight, iwae);
+  MIVAE_CHECK_LAUNCH("elbo_bwd");
+  return MIVAE_OK;
+}

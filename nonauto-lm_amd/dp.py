@@ -1,0 +1,153 @@
+"""Batch-parallel training over the GPUs of one node: one process per GPU, RCCL (torch.distributed
+backend "nccl" on ROCm) over xGMI.
+
+Replaces the reference's DistributedDataParallel wrap (training/trainers/trainer.py:51-60,
+find_unused_parameters=True), its per-batch / per-epoch scalar all-reduces (training/ddp.py:18-47)
+and the 2-per-metric scalar all-reduces (training/metrics.py:27-28) with:
+
+ * GradReducer -- gradients live as views into a few large flat buckets laid out in reverse
+   registration order (= the order backward produces them: decoder -> flow stack -> posterior ->
+   encoder).  A post-accumulate hook counts arrivals; when a bucket is complete its all-reduce is
+   issued asynchronously from the autograd thread, so RCCL's stream runs under the rest of backward.
+   Buckets default to 32 MiB: xGMI is point-to-point (7 links x ~153 GB/s), a ring is bound by one
+   link, so few large messages beat many 25 MB DDP buckets for the <= 70 MB of gradients here.
+   Parameters that received no gradient simply contribute zeros (no graph walk needed).
+ * PackedScalars -- every per-step scalar that must be global (done-early flag, metric sums, count)
+   travels in ONE small all-reduce.
+
+The path has no other exchange step: every op is per-sentence.
+"""
+from typing import Dict, Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def world_size(group=None) -> int:
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> None:
+    """Same initial weights on every rank (the reference relies on identical seeds, train_worker.py:48)."""
+    if world_size(group) == 1:
+        return
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.data, src, group=group)
+
+
+class GradReducer:
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 32 << 20, group=None):
+        self.group = group
+        self.world = world_size(group)
+        self.params = [p for p in params if p.requires_grad]
+        self.buckets: List[torch.Tensor] = []
+        self._bucket_of: Dict[int, int] = {}
+        self._bucket_size: List[int] = []
+        order = list(reversed(self.params))
+        cur: List[torch.nn.Parameter] = []
+        cur_bytes = 0
+        groups: List[List[torch.nn.Parameter]] = []
+        for p in order:
+            nbytes = p.numel() * p.element_size()
+            if cur and (cur_bytes + nbytes > bucket_bytes or p.dtype != cur[0].dtype or p.device != cur[0].device):
+                groups.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            groups.append(cur)
+        for bi, ps in enumerate(groups):
+            # 64-element alignment keeps every view 256-byte aligned for fp32
+            offs, total = [], 0
+            for p in ps:
+                offs.append(total)
+                total += (p.numel() + 63) // 64 * 64
+            flat = torch.zeros(total, dtype=ps[0].dtype, device=ps[0].device)
+            for p, o in zip(ps, offs):
+                p.grad = flat[o:o + p.numel()].view_as(p)
+                self._bucket_of[id(p)] = bi
+                p.register_post_accumulate_grad_hook(self._on_grad)
+            self.buckets.append(flat)
+            self._bucket_size.append(len(ps))
+        self._arrived = [0] * len(self.buckets)
+        self._handles: List[Optional[object]] = [None] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
+
+    # -- hooks ------------------------------------------------------------------------------------
+    def _on_grad(self, p: torch.nn.Parameter) -> None:
+        bi = self._bucket_of[id(p)]
+        flat = self.buckets[bi]
+        if p.grad.data_ptr() < flat.data_ptr() or p.grad.data_ptr() >= flat.data_ptr() + flat.numel() * flat.element_size():
+            # someone replaced .grad (zero_grad(set_to_none=True)): copy back into the bucket view
+            raise RuntimeError("GradReducer: parameter .grad was re-allocated; call reducer.zero_grad() "
+                               "instead of optimizer.zero_grad(set_to_none=True)")
+        self._arrived[bi] += 1
+        if self._arrived[bi] == self._bucket_size[bi]:
+            self._launch(bi)
+
+    def _launch(self, bi: int) -> None:
+        if self._launched[bi]:
+            return
+        self._launched[bi] = True
+        if self.world > 1:
+            self._handles[bi] = dist.all_reduce(self.buckets[bi], op=dist.ReduceOp.SUM, group=self.group,
+                                                async_op=True)
+
+    # -- step API ---------------------------------------------------------------------------------
+    def finish(self) -> None:
+        """Call after loss.backward(): flushes incomplete buckets, waits, averages."""
+        for bi in range(len(self.buckets)):
+            self._launch(bi)
+        for bi, h in enumerate(self._handles):
+            if h is not None:
+                h.wait()
+            if self.world > 1:
+                self.buckets[bi].div_(self.world)
+        self._arrived = [0] * len(self.buckets)
+        self._handles = [None] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
+
+    def zero_grad(self) -> None:
+        for flat in self.buckets:
+            flat.zero_()
+
+    def grad_norm(self) -> torch.Tensor:
+        """Global L2 norm over all buckets (identical on every rank after finish())."""
+        return torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(b.float()) for b in self.buckets]))
+
+    def clip_(self, max_norm: Optional[float], max_value: Optional[float]) -> torch.Tensor:
+        """clip_grad_norm_(max_norm) then clip_grad_value_(max_value) on the flat buckets
+        (training/trainers/trainer.py:286-289) -- two passes over a few tensors instead of a
+        multi-tensor walk over every parameter."""
+        norm = self.grad_norm()
+        if max_norm is not None:
+            coef = (max_norm / (norm + 1e-6)).clamp(max=1.0)
+            for b in self.buckets:
+                b.mul_(coef.to(b.dtype))
+        if max_value is not None:
+            for b in self.buckets:
+                b.clamp_(-max_value, max_value)
+        return norm
+
+
+class PackedScalars:
+    """One all-reduce for every per-step global scalar (replaces ddp.py:25-26 + metrics.py:27-28)."""
+
+    def __init__(self, names: List[str], device, group=None):
+        self.names = list(names)
+        self.group = group
+        self.buf = torch.zeros(len(self.names) + 1, dtype=torch.float32, device=device)
+
+    def reduce(self, values: Dict[str, torch.Tensor], count: float = 1.0, async_op: bool = False):
+        vals = [values[n].detach().float().reshape(()) if isinstance(values[n], torch.Tensor)
+                else torch.tensor(float(values[n]), device=self.buf.device) for n in self.names]
+        self.buf.copy_(torch.stack(vals + [torch.tensor(float(count), device=self.buf.device)]))
+        if world_size(self.group) > 1:
+            return dist.all_reduce(self.buf, group=self.group, async_op=async_op)
+        return None
+
+    def means(self) -> Dict[str, float]:
+        host = self.buf.tolist()                 # the only device->host sync
+        cnt = max(host[-1], 1e-30)
+        return {n: v / cnt for n, v in zip(self.names, host[:-1])}

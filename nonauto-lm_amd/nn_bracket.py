@@ -1,0 +1,309 @@
+"""Stock-PyTorch pieces that bracket the latent hot path (OUT OF SCOPE rows):
+Activation registry, FeedForward, transformer encoder / non-autoregressive decoder, embedder and the
+label-smoothing NLL.  They run on PyTorch-ROCm library ops (rocBLAS / MIOpen); no HIP kernels here.
+Parameter names follow the reference so its checkpoints load (state-dict keys).
+"""
+import math
+from typing import Callable, Dict, List, NamedTuple, Union
+
+import torch
+import torch.nn.functional as F
+
+from .registrable import FromParams, Registrable
+
+
+# ----------------------------------------------------------------------------------- activations
+def _gelu(x):
+    return x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))   # erf GELU, nn/activation.py:16
+
+
+ACTIVATION_FNS: Dict[str, Callable] = {
+    "linear": lambda x: x, "gelu": _gelu, "swish": lambda x: x * torch.sigmoid(x), "relu": F.relu,
+    "relu6": F.relu6, "elu": F.elu, "leaky_relu": F.leaky_relu, "hardtanh": F.hardtanh,
+    "sigmoid": torch.sigmoid, "tanh": torch.tanh, "log_sigmoid": F.logsigmoid, "softplus": F.softplus,
+    "softshrink": F.softshrink, "softsign": F.softsign, "tanhshrink": F.tanhshrink,
+}
+
+
+class Activation(torch.nn.Module):
+    """Named activation (nn/activation.py:26-56)."""
+
+    def __init__(self, name: str) -> None:
+        super().__init__()
+        if name not in ACTIVATION_FNS:
+            raise Exception("Inavalid activation name.")
+        self._name = name
+
+    def forward(self, x):
+        return ACTIVATION_FNS[self._name](x)
+
+    def __repr__(self):
+        return f"Activation({self._name})"
+
+    @classmethod
+    def by_name(cls, name: str) -> "Activation":
+        return cls(name)
+
+
+class FeedForward(torch.nn.Module, FromParams):
+    """Linear/activation/dropout stack + output Linear (nn/feedforward.py:54-98)."""
+
+    def __init__(self, input_size: int, num_layers: int, hidden_sizes: Union[int, List[int]],
+                 activations, dropout: Union[float, List[float]] = 0.0, output_size: int = None):
+        super().__init__()
+        hidden_sizes = hidden_sizes if isinstance(hidden_sizes, list) else [hidden_sizes] * num_layers
+        activations = activations if isinstance(activations, list) else [activations] * num_layers
+        dropout = dropout if isinstance(dropout, list) else [dropout] * num_layers
+        for name, seq in (("hidden_dims", hidden_sizes), ("activations", activations), ("dropout", dropout)):
+            if len(seq) != num_layers:
+                raise ValueError(f"len({name}) ({len(seq)}) != num_layers ({num_layers})")
+        self._input_size = input_size
+        self._output_size = output_size or hidden_sizes[-1]
+        dims = [input_size] + hidden_sizes
+        self._linear_layers = torch.nn.ModuleList(
+            [torch.nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:])])
+        self._activations = torch.nn.ModuleList(activations)
+        self._dropout = torch.nn.ModuleList([torch.nn.Dropout(p) for p in dropout])
+        self._output = torch.nn.Linear(hidden_sizes[-1], self._output_size)
+
+    def forward(self, x):
+        for lin, act, drop in zip(self._linear_layers, self._activations, self._dropout):
+            x = drop(act(lin(x)))
+        return self._output(x)
+
+    def get_input_size(self):
+        return self._input_size
+
+    def get_output_size(self):
+        return self._output_size
+
+
+# ----------------------------------------------------------------------------------- transformer
+def _maybe_dropout(p):
+    return torch.nn.Dropout(p) if p and p > 0 else torch.nn.Identity()
+
+
+class MultiHeadAttention(torch.nn.Module):
+    """nn/transformer.py:7-117: separate q/k/v projections, masked_fill(-1e13) on padded keys,
+    optional causal (tril) mask.  Scores are materialised like the reference (S <= 512 here)."""
+
+    def __init__(self, num_heads, hidden_size, bias=True, dropout=0.1, output_size=None,
+                 attention_fill_value=-1e13, mask_tril=False):
+        super().__init__()
+        assert hidden_size % num_heads == 0
+        self._attn_size = hidden_size // num_heads
+        self._num_heads = num_heads
+        self._projections = torch.nn.ModuleDict({
+            "query": torch.nn.Linear(hidden_size, hidden_size, bias=bias),
+            "key": torch.nn.Linear(hidden_size, hidden_size, bias=bias),
+            "value": torch.nn.Linear(hidden_size, hidden_size, bias=bias)})
+        self._output = torch.nn.Linear(hidden_size, output_size or hidden_size)
+        self._fill = attention_fill_value
+        self._mask_tril = mask_tril
+        self._dropout = _maybe_dropout(dropout)
+
+    def _split(self, x):
+        b, s, _ = x.shape
+        return x.view(b, s, self._num_heads, self._attn_size).transpose(1, 2)
+
+    def forward(self, query, key, value, mask=None):
+        q = self._split(self._projections["query"](query))
+        k = self._split(self._projections["key"](key))
+        v = self._split(self._projections["value"](value))
+        S = q.size(2)
+        scores = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(self._attn_size)
+        if mask is None:
+            keep = torch.ones(q.size(0), 1, 1, S, dtype=torch.bool, device=q.device)
+        else:
+            keep = mask.ne(0)[:, None, None, :]
+        if self._mask_tril:
+            keep = keep & torch.ones(S, S, dtype=torch.bool, device=q.device).tril()[None, None]
+        scores = scores.masked_fill(~keep, self._fill)
+        probs = self._dropout(torch.softmax(scores, dim=-1))
+        out = torch.matmul(probs, v).transpose(1, 2).reshape(q.size(0), S, -1)
+        return self._output(out)
+
+
+class PositionwiseFeedForward(torch.nn.Module):
+    def __init__(self, input_size, hidden_size, dropout=0.0):
+        super().__init__()
+        self._w_1 = torch.nn.Linear(input_size, hidden_size)
+        self._w_2 = torch.nn.Linear(hidden_size, input_size)
+        self._dropout = _maybe_dropout(dropout)
+
+    def forward(self, x):
+        return self._w_2(self._dropout(torch.relu(self._w_1(x))))
+
+
+class SublayerConnection(torch.nn.Module):
+    """Pre-norm residual (nn/transformer.py:147-162)."""
+
+    def __init__(self, input_size, dropout=0.1):
+        super().__init__()
+        self._norm = torch.nn.LayerNorm(input_size)
+        self._dropout = _maybe_dropout(dropout)
+
+    def forward(self, x, sublayer):
+        return x + self._dropout(sublayer(self._norm(x)))
+
+
+class PositionalEncoding(torch.nn.Module):
+    """Sinusoid table kept as a frozen Parameter named `_pos_enc` (nn/transformer.py:181-202)."""
+
+    def __init__(self, hidden_size, dropout=0.0, max_len=5000):
+        super().__init__()
+        pe = torch.zeros(max_len, hidden_size)
+        pos = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+        div = torch.exp(torch.arange(0, hidden_size, 2, dtype=torch.float) * -(math.log(10000.0) / hidden_size))
+        pe[:, 0::2] = torch.sin(pos * div)
+        pe[:, 1::2] = torch.cos(pos * div)
+        self._pos_enc = torch.nn.Parameter(pe.unsqueeze(0), requires_grad=False)
+        self._dropout = _maybe_dropout(dropout)
+
+    def forward(self, tokens):
+        return self._dropout(tokens + self._pos_enc[:, :tokens.size(1)].to(tokens.dtype))
+
+
+class _TransformerLayer(torch.nn.Module):
+    def __init__(self, input_size, hidden_size, num_heads, dropout=0.0, causal=False):
+        super().__init__()
+        self._attn = MultiHeadAttention(num_heads, input_size, dropout=dropout, mask_tril=causal)
+        self._pos_ffn = PositionwiseFeedForward(input_size, hidden_size, dropout=dropout)
+        self._sublayers = torch.nn.ModuleDict({
+            "attn": SublayerConnection(input_size, dropout=dropout),
+            "pos_ffn": SublayerConnection(input_size, dropout=dropout)})
+
+    def forward(self, x, mask):
+        x = self._sublayers["attn"](x, lambda y: self._attn(y, y, y, mask))
+        return self._sublayers["pos_ffn"](x, self._pos_ffn)
+
+
+class TransformerEncoderLayer(_TransformerLayer):
+    def __init__(self, input_size, hidden_size, num_heads, dropout=0.0):
+        super().__init__(input_size, hidden_size, num_heads, dropout, causal=False)
+
+
+class TransformerDecoderLayer(_TransformerLayer):
+    """Self-attention with a causal x padding mask (nn/transformer.py:275)."""
+
+    def __init__(self, input_size, hidden_size, num_heads, dropout=0.0):
+        super().__init__(input_size, hidden_size, num_heads, dropout, causal=True)
+
+
+class EncoderOutput(NamedTuple):
+    output: torch.Tensor
+    ctx: torch.Tensor
+    mask: torch.Tensor
+
+
+class Embedder(torch.nn.Module, FromParams):
+    def __init__(self, num_embeddings, embedding_dim, padding_idx=0, **kwargs):
+        super().__init__()
+        self._embedding = torch.nn.Embedding(num_embeddings, embedding_dim, padding_idx=padding_idx, **kwargs)
+
+    def forward(self, tokens):
+        return self._embedding(tokens)
+
+    @classmethod
+    def from_params(cls, vocab, **kwargs):
+        return cls(num_embeddings=vocab.get_vocab_size(), **kwargs)
+
+
+class Encoder(torch.nn.Module, Registrable):
+    """encoders/encoder.py:16-54; the last-token gather (a2) goes through the HIP kernel."""
+
+    def __init__(self, input_size):
+        super().__init__()
+        self._input_size = input_size
+
+    def forward(self, tokens, mask):
+        from . import ops
+        output = self.encoder(self._preprocess_embedding(tokens), mask)
+        ctx, _ = ops.gather_last(output, mask)
+        return EncoderOutput(output, ctx, mask)
+
+    def _preprocess_embedding(self, x):
+        return x
+
+    def get_input_size(self):
+        return self._input_size
+
+
+@Encoder.register("transformer")
+class TransformerEncoder(Encoder):
+    def __init__(self, input_size, hidden_size, num_layers, num_heads, dropout=0.0):
+        super().__init__(input_size)
+        self._pos_enc = PositionalEncoding(input_size)
+        self._layers = torch.nn.ModuleList(
+            [TransformerEncoderLayer(input_size, hidden_size, num_heads, dropout) for _ in range(num_layers)])
+        self._dropout = _maybe_dropout(dropout)
+
+    def get_output_size(self):
+        return self._input_size
+
+    def _preprocess_embedding(self, x):
+        return self._dropout(x)
+
+    def encoder(self, x, mask):
+        m = mask.unsqueeze(-1).to(x.dtype)
+        x = self._pos_enc(x) * m
+        for layer in self._layers:
+            x = layer(x, mask)
+        return x * m
+
+
+class Decoder(torch.nn.Module, Registrable):
+    def __init__(self, skip_z=False):
+        super().__init__()
+        self._skip_z = skip_z
+
+    def forward(self, z, mask):
+        out = self.decoder(z, mask)
+        return torch.cat([out, z], dim=-1) if self._skip_z else out
+
+
+@Decoder.register("nonauto-transformer")
+class TransformerDecoder(Decoder):
+    def __init__(self, input_size, hidden_size, num_layers, num_heads, dropout=0.0, skip_z=False):
+        super().__init__(skip_z)
+        self._input_size = input_size
+        self._pos_enc = PositionalEncoding(input_size)
+        self._layers = torch.nn.ModuleList(
+            [TransformerDecoderLayer(input_size, hidden_size, num_heads, dropout) for _ in range(num_layers)])
+        self._dropout = _maybe_dropout(dropout)
+
+    def get_input_size(self):
+        return self._input_size
+
+    def get_output_size(self):
+        return self._input_size * (2 if self._skip_z else 1)
+
+    def decoder(self, z, mask):
+        z = self._pos_enc(self._dropout(z)) * mask.unsqueeze(-1).to(z.dtype)
+        for layer in self._layers:
+            z = layer(z, mask)
+        return z
+
+
+class LabelSmoothingNLL(torch.nn.Module):
+    """Per-sequence token-mean NLL with optional label smoothing (models/base/losses.py:106-169)."""
+
+    def __init__(self, smoothing=0.0, size_average=True):
+        super().__init__()
+        self._smoothing = smoothing
+        self._size_average = size_average
+
+    def forward(self, logits, target, weights):
+        V = logits.size(-1)
+        logp = torch.log_softmax(logits.reshape(-1, V).float(), dim=-1)
+        tgt = target.reshape(-1, 1).long()
+        nll = -logp.gather(1, tgt)
+        if self._smoothing is not None and self._smoothing > 0.0 and self.training:
+            # sum_v q_v * (-logp_v) with q = (1 - s) onehot + s / V
+            nll = (1.0 - self._smoothing) * nll - (self._smoothing / V) * logp.sum(-1, keepdim=True)
+        nll = nll.view(*target.shape) * weights
+        wsum = weights.reshape(weights.size(0), -1).sum(1)
+        per_seq = nll.reshape(nll.size(0), -1).sum(1) / wsum.clamp(min=1e-13)
+        if self._size_average:
+            return per_seq.sum() / wsum.gt(0).float().sum().clamp(min=1e-13)
+        return per_seq

@@ -1,0 +1,466 @@
+"""torch.autograd wrappers around the libmivae C ABI (include/mivae.h).
+
+PyTorch is plumbing here: it owns device memory, the current HIP stream and autograd bookkeeping.
+Every numeric result on this path comes from a hand-written HIP kernel; inputs must live on the GPU.
+"""
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+ACT_IDS = {"linear": 0, "gelu": 1, "swish": 2, "relu": 3, "tanh": 4, "sigmoid": 5}
+FUSED_MAX_D = 256
+
+# Optional per-launch timing of named kernels with HIP events recorded on the launch stream (used by
+# bench.py for the roofline figure; no host sync is added here).
+_PROFILE = None
+
+
+def profile_kernels(enable: bool):
+    """Start (True) / stop (False) collecting (start, end) event pairs; returns the collected dict."""
+    global _PROFILE
+    prev = _PROFILE
+    _PROFILE = {} if enable else None
+    return prev
+
+
+class _timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if _PROFILE is not None:
+            self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.ev[0].record(torch.cuda.current_stream())
+
+    def __exit__(self, *exc):
+        if _PROFILE is not None:
+            self.ev[1].record(torch.cuda.current_stream())
+            _PROFILE.setdefault(self.name, []).append(self.ev)
+        return False
+
+
+def _mask_i64(mask: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """Masks are int64 0/1 in the reference (nn/utils.py:12-14); the sampling path passes the same
+    0/1 values as floats (priors/prior.py:116-122)."""
+    if mask is None:
+        return None
+    if mask.dtype != torch.int64:
+        mask = mask.to(torch.int64)
+    return mask.contiguous()
+
+
+def _shape3(z: torch.Tensor) -> Tuple[int, int, int]:
+    if z.dim() == 3:
+        return z.size(0), z.size(1), z.size(2)
+    if z.dim() == 2:
+        return z.size(0), 1, z.size(1)
+    raise ValueError(f"latent must be (B, S, D) or (B, D), got {tuple(z.shape)}")
+
+
+# ----------------------------------------------------------------------------------- integer helpers
+def tokens_mask(tokens: torch.Tensor) -> torch.Tensor:
+    """a1: x.ne(0).long()  (vae_lm/nn/utils.py:12-14)."""
+    L.require_gpu(tokens)
+    tokens = tokens.contiguous()
+    if tokens.dtype != torch.int64:
+        tokens = tokens.to(torch.int64)
+    out = torch.empty_like(tokens)
+    L.call("mivae_tokens_mask", L.ptr(tokens), L.ptr(out), tokens.numel(), L.stream())
+    return out
+
+
+class _GatherLast(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, output, mask):
+        B, S, E = output.shape
+        output = output.contiguous()
+        ctxv = torch.empty(B, E, dtype=output.dtype, device=output.device)
+        idx = torch.empty(B, dtype=torch.int64, device=output.device)
+        L.call("mivae_gather_last", L.ptr(output), L.ptr(mask), L.ptr(ctxv), L.ptr(idx), B, S, E,
+               L.dtype_code(output.dtype), L.stream())
+        ctx.save_for_backward(idx)
+        ctx.shape = (B, S, E)
+        ctx.mark_non_differentiable(idx)
+        return ctxv, idx
+
+    @staticmethod
+    def backward(ctx, g, _gidx):
+        (idx,) = ctx.saved_tensors
+        B, S, E = ctx.shape
+        grad = g.new_zeros(B, S, E)
+        pos = torch.where(idx < 0, idx + S, idx)
+        grad[torch.arange(B, device=g.device), pos] = g   # scatter of B rows: plumbing, not hot path
+        return grad, None
+
+
+def gather_last(output: torch.Tensor, mask: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """a2: ctx = output[b, mask.sum(1) - 1]  (encoders/encoder.py:35-37).  Returns (ctx, last_idx)."""
+    L.require_gpu(output, mask)
+    return _GatherLast.apply(output, _mask_i64(mask))
+
+
+def segment_sum(tok: torch.Tensor, nseg: int, S: int, add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    out = torch.empty(nseg, dtype=torch.float32, device=tok.device)
+    L.call("mivae_segment_sum", L.ptr(tok), L.ptr(add), L.ptr(out), nseg, S, L.stream())
+    return out
+
+
+def mask_count(mask: torch.Tensor, nseg: int, mask_div: int = 1) -> torch.Tensor:
+    mask = _mask_i64(mask)
+    out = torch.empty(nseg, dtype=torch.int64, device=mask.device)
+    L.call("mivae_mask_count", L.ptr(mask), L.ptr(out), nseg, mask_div, mask.size(-1), L.stream())
+    return out
+
+
+# ----------------------------------------------------------------------------------- posterior
+class _ReparamLogQ(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mu, sigma, eps, mask, n):
+        B, S, D = _shape3(mu)
+        # under autocast the sigma head (softplus) comes out fp32 while mu is bf16: z's dtype follows mu
+        mu_c, sg_c = mu.contiguous(), sigma.contiguous().to(mu.dtype)
+        eps_c = None if eps is None else eps.contiguous().to(mu.dtype)
+        ctx.sigma_dtype = sigma.dtype
+        z = torch.empty((B * n, *mu.shape[1:]), dtype=mu.dtype, device=mu.device)
+        tok = torch.empty(B * n * S, dtype=torch.float32, device=mu.device)
+        L.call("mivae_reparam_logq_fwd", L.ptr(mu_c), L.ptr(sg_c), L.ptr(eps_c), L.ptr(mask), L.ptr(z),
+               L.ptr(tok), B, n, S, D, L.dtype_code(mu.dtype), L.stream())
+        logq = segment_sum(tok, B * n, S)
+        ctx.save_for_backward(sg_c, eps_c, mask)
+        ctx.dims = (B, n, S, D)
+        return z, logq
+
+    @staticmethod
+    def backward(ctx, dz, dlogq):
+        sg, eps, mask = ctx.saved_tensors
+        B, n, S, D = ctx.dims
+        dz = None if dz is None else dz.contiguous()
+        dlogq = None if dlogq is None else dlogq.contiguous().float()
+        dmu = torch.empty_like(sg)
+        dsg = torch.empty_like(sg)
+        L.call("mivae_reparam_logq_bwd", L.ptr(dz), L.ptr(dlogq), L.ptr(sg), L.ptr(eps), L.ptr(mask),
+               L.ptr(dmu), L.ptr(dsg), B, n, S, D, L.dtype_code(sg.dtype), L.stream())
+        return dmu, dsg.to(ctx.sigma_dtype), None, None, None
+
+
+def reparam_logq(mu, sigma, eps, mask, samples: int):
+    """a4 + a5: z = (mu + eps * sigma) * mask (rearranged to (B n) ...), log q(z) per sample.
+
+    posterior.py:119-133 and :157-172 (nonauto); auto :111-119, :141-156 (mask None, 2-D)."""
+    L.require_gpu(mu, sigma, eps, mask)
+    return _ReparamLogQ.apply(mu, sigma, eps, _mask_i64(mask), int(samples))
+
+
+# ----------------------------------------------------------------------------------- base log-prob
+class _GaussLogProb(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, mask, mask_div, mu, std):
+        Bn, S, D = _shape3(z)
+        z = z.contiguous()
+        tok = torch.empty(Bn * S, dtype=torch.float32, device=z.device)
+        L.call("mivae_gauss_logprob_fwd", L.ptr(z), L.ptr(mask), L.ptr(tok), Bn, mask_div, S, D,
+               float(mu), float(std), L.dtype_code(z.dtype), L.stream())
+        ctx.save_for_backward(z, mask)
+        ctx.meta = (Bn, S, D, mask_div, float(mu), float(std))
+        return segment_sum(tok, Bn, S)
+
+    @staticmethod
+    def backward(ctx, dlogp):
+        z, mask = ctx.saved_tensors
+        Bn, S, D, mask_div, mu, std = ctx.meta
+        dz = torch.empty_like(z)
+        L.call("mivae_gauss_logprob_bwd", L.ptr(z), L.ptr(mask), L.ptr(dlogp.contiguous().float()),
+               L.ptr(dz), Bn, mask_div, S, D, mu, std, L.dtype_code(z.dtype), L.stream())
+        return dz, None, None, None, None
+
+
+def gauss_logprob(z, mask, mu: float, std: float, mask_div: int = 1):
+    """a15: sum over all but batch of Normal(mu, std).log_prob(z) * mask  (priors/prior.py:148-158)."""
+    L.require_gpu(z, mask)
+    return _GaussLogProb.apply(z, _mask_i64(mask), mask_div, mu, std)
+
+
+# ----------------------------------------------------------------------------------- NICE affine tail
+class _NiceAffine(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, s, t, mask, inverse):
+        Bn, S, D = _shape3(z)
+        z, s, t = z.contiguous(), s.contiguous().to(z.dtype), t.contiguous().to(z.dtype)
+        out = torch.empty_like(z)
+        tok = torch.empty(Bn * S, dtype=torch.float32, device=z.device)
+        L.call("mivae_nice_affine_fwd", L.ptr(z), L.ptr(s), L.ptr(t), L.ptr(mask), L.ptr(out), L.ptr(tok),
+               Bn, 1, S, D, L.dtype_code(z.dtype), int(inverse), L.stream())
+        ctx.save_for_backward(z, s, t, mask)
+        ctx.meta = (Bn, S, D, int(inverse))
+        return out, tok
+
+    @staticmethod
+    def backward(ctx, dout, dtok):
+        z, s, t, mask = ctx.saved_tensors
+        Bn, S, D, inverse = ctx.meta
+        dz, ds, dt = torch.empty_like(z), torch.empty_like(s), torch.empty_like(t)
+        if dout is None:
+            dout = torch.zeros_like(z)
+        # the kernel takes d(log_det) per *segment*; per-token cotangents are handled with S = 1
+        dld = None if dtok is None else dtok.contiguous().float()
+        L.call("mivae_nice_affine_bwd", L.ptr(dout.contiguous()), L.ptr(dld), L.ptr(z), L.ptr(s), L.ptr(t),
+               L.ptr(mask), L.ptr(dz), L.ptr(ds), L.ptr(dt), Bn * S, 1, 1, D, L.dtype_code(z.dtype),
+               inverse, L.stream())
+        return dz, ds, dt, None, None
+
+
+def nice_affine(z, s, t, mask, inverse: bool = False):
+    """a8/a9 tail: y1 = exp(s) x1 + t (or inverse), cat, mask multiply, masked log-det.
+
+    couplings.py:151-162 / :172-183.  Returns (z', log_det) with the reference's log_det shape:
+    (B,) for masked 3-D input and for 2-D input, (B, S) for 3-D input without a mask."""
+    L.require_gpu(z, s, t, mask)
+    mask = _mask_i64(mask)
+    Bn, S, D = _shape3(z)
+    out, tok = _NiceAffine.apply(z, s, t, mask, inverse)
+    if z.dim() == 2:
+        return out, tok
+    if mask is None:
+        return out, tok.view(Bn, S)
+    return out, _SegmentSum.apply(tok, Bn, S)
+
+
+class _SegmentSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tok, nseg, S):
+        ctx.meta = (nseg, S)
+        return segment_sum(tok.contiguous(), nseg, S)
+
+    @staticmethod
+    def backward(ctx, g):
+        nseg, S = ctx.meta
+        return g.reshape(nseg, 1).expand(nseg, S).reshape(-1), None, None
+
+
+# ----------------------------------------------------------------------------------- ActNorm
+class _ActNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, log_scale, bias, mask, inverse, count_weighted):
+        Bn, S, D = _shape3(z)
+        z = z.contiguous()
+        ls, b = log_scale.contiguous().float(), bias.contiguous().float()
+        out = torch.empty_like(z)
+        nld = Bn if count_weighted else 1
+        ld = torch.empty(nld, dtype=torch.float32, device=z.device)
+        L.call("mivae_actnorm_fwd", L.ptr(z), L.ptr(ls), L.ptr(b), L.ptr(mask), L.ptr(out), L.ptr(ld),
+               Bn, 1, S, D, nld, int(count_weighted), L.dtype_code(z.dtype), int(inverse), L.stream())
+        ctx.save_for_backward(z, ls, mask)
+        ctx.meta = (Bn, S, D, int(inverse), bool(count_weighted))
+        return out, ld
+
+    @staticmethod
+    def backward(ctx, dout, dld):
+        z, ls, mask = ctx.saved_tensors
+        Bn, S, D, inverse, cw = ctx.meta
+        if inverse:
+            raise RuntimeError("ActNorm: autograd through the inverse (sampling) direction is not "
+                               "supported; the reference only uses it under no_grad")
+        if dout is None:
+            dout = torch.zeros_like(z)
+        dz = torch.empty_like(z)
+        dparams = torch.empty(2, D, dtype=torch.float32, device=z.device)
+        nws = L.query("mivae_col_workspace_floats", Bn * S, D, L.dtype_code(z.dtype))
+        ws = torch.empty(nws, dtype=torch.float32, device=z.device)
+        L.call("mivae_actnorm_bwd", L.ptr(dout.contiguous()), L.ptr(z), L.ptr(ls), L.ptr(mask), L.ptr(dz),
+               L.ptr(dparams), L.ptr(ws), Bn, 1, S, D, L.dtype_code(z.dtype), L.stream())
+        dls, db = dparams[0], dparams[1]
+        if dld is not None:
+            # log_det = sum(log_scale) * count  ->  every d gets sum_b dld[b] * count[b]
+            if cw:
+                cnt = mask_count(mask, Bn).float()
+                dls = dls + (dld.float() * cnt).sum()
+            else:
+                dls = dls + dld.float().sum()
+        return dz, dls, db, None, None, None
+
+
+def actnorm(z, log_scale, bias, mask, inverse: bool = False):
+    """a12/a13: ActNorm.forward (actnorm.py:31-39) / .backward (:45-54) after initialisation."""
+    L.require_gpu(z, log_scale, bias, mask)
+    mask = _mask_i64(mask)
+    cw = z.dim() > 2 and mask is not None
+    return _ActNorm.apply(z, log_scale, bias, mask, inverse, cw)
+
+
+def actnorm_stats(z) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Column mean and unbiased std over z.view(-1, D) (actnorm.py:23-24), two passes, fp32."""
+    L.require_gpu(z)
+    D = z.size(-1)
+    z2 = z.contiguous().view(-1, D)
+    rows = z2.size(0)
+    mean = torch.empty(D, dtype=torch.float32, device=z.device)
+    std = torch.empty(D, dtype=torch.float32, device=z.device)
+    ws = torch.empty(L.query("mivae_col_workspace_floats", rows, D, L.dtype_code(z.dtype)),
+                     dtype=torch.float32, device=z.device)
+    L.call("mivae_actnorm_stats", L.ptr(z2), L.ptr(mean), L.ptr(std), L.ptr(ws), rows, D,
+           L.dtype_code(z.dtype), L.stream())
+    return mean, std
+
+
+# ----------------------------------------------------------------------------------- KL / ELBO
+class _KL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logq, logp, free_bits):
+        q, p = logq.contiguous().float(), logp.contiguous().float()
+        kl = torch.empty_like(q)
+        use = free_bits is not None
+        L.call("mivae_kl_fwd", L.ptr(q), L.ptr(p), L.ptr(kl), q.numel(), int(use),
+               float(free_bits) if use else 0.0, L.stream())
+        ctx.save_for_backward(q, p)
+        ctx.fb = free_bits
+        return kl
+
+    @staticmethod
+    def backward(ctx, dkl):
+        q, p = ctx.saved_tensors
+        dq, dp = torch.empty_like(q), torch.empty_like(p)
+        use = ctx.fb is not None
+        L.call("mivae_kl_bwd", L.ptr(q), L.ptr(p), L.ptr(dkl.contiguous().float()), L.ptr(dq), L.ptr(dp),
+               q.numel(), int(use), float(ctx.fb) if use else 0.0, L.stream())
+        return dq, dp, None
+
+
+def kl_default(logq, logp, free_bits: Optional[float] = None):
+    """a16: DefaultKLLoss (nn/kl_loss.py:38-49): clamp(log q - log p, min=free_bits_alpha)."""
+    L.require_gpu(logq, logp)
+    return _KL.apply(logq, logp, free_bits)
+
+
+class _Elbo(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, recon, kl, B, n, wr, wk, iwae):
+        r, k = recon.contiguous().float(), kl.contiguous().float()
+        out = torch.empty(3, dtype=torch.float32, device=r.device)
+        L.call("mivae_elbo_fwd", L.ptr(r), L.ptr(k), L.ptr(out), B, n, float(wr), float(wk), int(iwae),
+               L.stream())
+        ctx.save_for_backward(r, k)
+        ctx.meta = (B, n, float(wr), float(wk), int(iwae))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        r, k = ctx.saved_tensors
+        B, n, wr, wk, iwae = ctx.meta
+        dr, dk = torch.empty_like(r), torch.empty_like(k)
+        L.call("mivae_elbo_bwd", L.ptr(r), L.ptr(k), L.ptr(g.contiguous().float()), L.ptr(dr), L.ptr(dk),
+               B, n, wr, wk, iwae, L.stream())
+        return dr, dk, None, None, None, None, None
+
+
+def elbo_tail(recon, kl, batch: int, samples: int, recon_weight: float, kl_weight: float, iwae: bool):
+    """a17: (batch-loss, batch-kl, batch-nll) of VAELmModel.forward (models/base/model.py:171-193)."""
+    L.require_gpu(recon, kl)
+    out = _Elbo.apply(recon.reshape(-1), kl.reshape(-1), batch, samples, recon_weight, kl_weight, iwae)
+    return out[0], out[1], out[2]
+
+
+# ----------------------------------------------------------------------------------- fused NICE stack
+_PTR_CACHE = {}
+
+
+def _ptr_table(params: Sequence[torch.Tensor], device) -> torch.Tensor:
+    key = (device, tuple(p.data_ptr() for p in params))
+    tab = _PTR_CACHE.get(key)
+    if tab is None:
+        if len(_PTR_CACHE) > 64:
+            _PTR_CACHE.clear()
+        tab = torch.tensor(key[1], dtype=torch.int64).to(device)
+        _PTR_CACHE[key] = tab
+    return tab
+
+
+def nice_pack(params: Sequence[torch.Tensor], K: int, h: int, H: int, dtype) -> torch.Tensor:
+    """Repack K x {W1s,b1s,W2s,b2s,W1t,b1t,W2t,b2t} (fp32 nn.Linear layout) into MFMA fragment order."""
+    dev = params[0].device
+    for p in params:
+        if p.dtype != torch.float32 or not p.is_contiguous():
+            raise TypeError("NICE parameters must be contiguous float32 tensors")
+    code = L.dtype_code(dtype)
+    nbytes = L.query("mivae_nice_pack_bytes", h, H, code)
+    packed = torch.empty(K * nbytes, dtype=torch.uint8, device=dev)
+    L.call("mivae_nice_pack", L.ptr(_ptr_table(params, dev)), L.ptr(packed), K, h, H, code, L.stream())
+    return packed
+
+
+class _NiceStack(torch.autograd.Function):
+    """K fused NICE-FF steps (+ optional base log-prob).  params: K x 8 tensors, see nice_pack."""
+
+    @staticmethod
+    def forward(ctx, z, mask, H, act, inverse, base, mu, std, *params):
+        Bn, S, D = _shape3(z)
+        h = D // 2
+        K = len(params) // 8
+        z = z.contiguous()
+        code = L.dtype_code(z.dtype)
+        packed = nice_pack(params, K, h, H, z.dtype)
+        need_grad = (not inverse) and any(ctx.needs_input_grad)
+        N = Bn * S
+        z_out = torch.empty_like(z)
+        hist = torch.empty(K, N, h, dtype=z.dtype, device=z.device) if need_grad else None
+        tok = torch.empty(N, dtype=torch.float32, device=z.device)
+        with _timed("nice_stack_inv" if inverse else "nice_stack_fwd"):
+            L.call("mivae_nice_stack_fwd", L.ptr(z), L.ptr(z_out), L.ptr(hist), L.ptr(mask), L.ptr(packed),
+                   L.ptr(tok), Bn, 1, S, D, H, K, act, int(inverse), int(base), float(mu), float(std), code,
+                   L.stream())
+        ctx.meta = (Bn, S, D, H, K, act, int(base), float(mu), float(std), code)
+        ctx.shapes = [tuple(p.shape) for p in params]
+        if need_grad:
+            ctx.save_for_backward(z, z_out, hist, mask, packed)
+        return z_out, tok
+
+    @staticmethod
+    def backward(ctx, dz_out, dtok):
+        z, z_out, hist, mask, packed = ctx.saved_tensors
+        Bn, S, D, H, K, act, base, mu, std, code = ctx.meta
+        h, N = D // 2, Bn * S
+        hp, Hp = (h + 31) // 32 * 32, (H + 31) // 32 * 32
+        npad = L.query("mivae_nice_stack_npad", N)
+        dt = z.dtype
+        Gt = torch.empty(K, 2, Hp, npad, dtype=dt, device=z.device)
+        Ht = torch.empty(K, 2, Hp, npad, dtype=dt, device=z.device)
+        dSt = torch.empty(K, 2, hp, npad, dtype=dt, device=z.device)
+        dz_in = torch.empty_like(z)
+        # The kernel takes the per-token cotangent through `dlogp` with S = 1 segments: the
+        # per-sentence broadcast has already been applied by _SegmentSum.backward.
+        dlog = None if dtok is None else dtok.contiguous().float()
+        dzo = None if dz_out is None else dz_out.contiguous()
+        with _timed("nice_stack_bwd"):
+            L.call("mivae_nice_stack_bwd", L.ptr(z), L.ptr(z_out), L.ptr(hist), L.ptr(mask), L.ptr(packed),
+                   L.ptr(dzo), L.ptr(dlog), L.ptr(dz_in), L.ptr(Gt), L.ptr(Ht), L.ptr(dSt), N, 1, 1, D, H, K,
+                   act, base, mu, std, code, L.stream())
+        # Weight gradients: K-contiguous NT GEMMs over the token axis on the emitted
+        # [feature][token] tensors (plain library GEMMs; see DESIGN.md "dW").
+        x0 = z.reshape(N, D)[:, :h]
+        dW1 = torch.matmul(Gt[..., :N], x0).float()                       # (K, 2, Hp, h)
+        db1 = Gt.sum(-1, dtype=torch.float32)                             # (K, 2, Hp)
+        dW2 = torch.matmul(dSt, Ht.transpose(-1, -2)).float()             # (K, 2, hp, Hp)
+        db2 = dSt.sum(-1, dtype=torch.float32)                            # (K, 2, hp)
+        grads = []
+        for k in range(K):
+            for net in range(2):
+                grads += [dW1[k, net, :H, :h], db1[k, net, :H], dW2[k, net, :h, :H], db2[k, net, :h]]
+        return (dz_in, None, None, None, None, None, None, None, *grads)
+
+
+def nice_stack(z, mask, params: Sequence[torch.Tensor], H: int, activation: str, inverse: bool = False,
+               base: bool = False, mu: float = 0.0, std: float = 1.0):
+    """Fused K-step NICE-FF stack (a6-a10): returns (z_K, val) where val is the masked log-det summed
+    over steps (+ the base log-prob when `base`), reduced like the reference: (B,) for masked 3-D and
+    2-D inputs, (B, S) for unmasked 3-D inputs."""
+    L.require_gpu(z, mask, *params)
+    mask = _mask_i64(mask)
+    Bn, S, D = _shape3(z)
+    z_out, tok = _NiceStack.apply(z, mask, int(H), ACT_IDS[activation], bool(inverse), bool(base),
+                                  float(mu), float(std), *params)
+    if z.dim() == 2:
+        return z_out, tok
+    if mask is None and not base:
+        return z_out, tok.view(Bn, S)
+    return z_out, _SegmentSum.apply(tok, Bn, S)
