@@ -1,0 +1,148 @@
+"""World-size-2 `gloo` tests (CPU) of the batch-parallel machinery in nonauto_lm_amd/dp.py:
+bucketed gradient all-reduce from grad hooks == single-process gradient of the full batch,
+unused parameters contribute zeros, clipping matches torch's utilities, packed scalar reduction."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _Net(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.body = torch.nn.Sequential(torch.nn.Linear(12, 40), torch.nn.Tanh(), torch.nn.Linear(40, 40),
+                                        torch.nn.Tanh(), torch.nn.Linear(40, 3))
+        self.unused = torch.nn.Linear(5, 5)   # never touched by forward (find_unused_parameters case)
+
+    def forward(self, x):
+        return self.body(x)
+
+
+def _make_model():
+    torch.manual_seed(13)
+    return _Net()
+
+
+def _data():
+    g = torch.Generator().manual_seed(7)
+    return torch.randn(16, 12, generator=g), torch.randn(16, 3, generator=g)
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nonauto_lm_amd import dp
+    torch.set_num_threads(1)
+    model = _make_model()
+    if rank == 1:                              # perturb, then check broadcast restores rank 0's weights
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)
+    dp.broadcast_parameters(model)
+    reducer = dp.GradReducer(model.parameters(), bucket_bytes=4096)      # several buckets
+    x, y = _data()
+    shard = slice(rank * 8, (rank + 1) * 8)
+    out = {}
+    for it in range(2):                         # two steps: state resets between steps
+        loss = ((model(x[shard]) - y[shard]) ** 2).mean()
+        loss.backward()
+        reducer.finish()
+        out[f"grads{it}"] = [p.grad.clone() for p in model.parameters()]
+        norm = reducer.clip_(0.05, 0.01)
+        out[f"norm{it}"] = norm.clone()
+        out[f"clipped{it}"] = [p.grad.clone() for p in model.parameters()]
+        reducer.zero_grad()
+    sc = dp.PackedScalars(["a", "b"], "cpu")
+    sc.reduce({"a": torch.tensor(float(rank + 1)), "b": 10.0 * (rank + 1)}, count=1.0)
+    out["means"] = sc.means()
+    out["nbuckets"] = len(reducer.buckets)
+    # plain numpy payloads: torch tensors would travel as shared-memory handles that die with the child
+    def plain(v):
+        if isinstance(v, torch.Tensor):
+            return v.numpy().copy()
+        if isinstance(v, list):
+            return [plain(x) for x in v]
+        return v
+    q.put((rank, {k: plain(v) for k, v in out.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_grad_reducer_world2_matches_full_batch():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    def unplain(v):
+        import numpy as np
+        if isinstance(v, np.ndarray):
+            return torch.from_numpy(v)
+        if isinstance(v, list):
+            return [unplain(x) for x in v]
+        return v
+    res = {}
+    for _ in range(2):
+        rank, out = q.get(timeout=100)
+        res[rank] = {k: unplain(v) for k, v in out.items()}
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    # single-process reference on the full batch
+    model = _make_model()
+    x, y = _data()
+    # mean over the full batch == average of the two shard means (equal shard sizes)
+    ((model(x) - y) ** 2).mean().backward()
+    ref = [p.grad.clone() if p.grad is not None else torch.zeros_like(p) for p in model.parameters()]
+    for rank in (0, 1):
+        r = res[rank]
+        assert r["nbuckets"] >= 2
+        for it in range(2):
+            for a, b in zip(r[f"grads{it}"], ref):
+                assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+        # clipping == torch utilities applied to the reference gradient
+        for p, g in zip(model.parameters(), ref):
+            p.grad = g.clone()
+        n = torch.nn.utils.clip_grad_norm_(model.parameters(), 0.05)
+        torch.nn.utils.clip_grad_value_(model.parameters(), 0.01)
+        assert torch.allclose(r["norm0"], n, rtol=1e-5)
+        for a, p in zip(r["clipped0"], model.parameters()):
+            assert torch.allclose(a, p.grad, rtol=1e-4, atol=1e-8)
+        assert r["means"] == {"a": 1.5, "b": 15.0}
+    for a, b in zip(res[0]["grads1"], res[1]["grads1"]):
+        assert torch.equal(a, b)                # ranks stay bit-identical
+
+
+def test_grad_reducer_single_process_is_identity():
+    sys.path.insert(0, ROOT)
+    from nonauto_lm_amd import dp
+    model = _make_model()
+    x, y = _data()
+    reducer = dp.GradReducer(model.parameters(), bucket_bytes=1 << 20)
+    ((model(x) - y) ** 2).mean().backward()
+    reducer.finish()
+    got = [p.grad.clone() for p in model.parameters()]
+    model2 = _make_model()
+    ((model2(x) - y) ** 2).mean().backward()
+    for a, p in zip(got, model2.parameters()):
+        assert torch.equal(a, p.grad if p.grad is not None else torch.zeros_like(p))
+    reducer.zero_grad()
+    assert all(float(p.grad.abs().max()) == 0.0 for p in model.parameters())
