@@ -94,7 +94,8 @@ int mivae_nice_affine_bwd(const void* dout, const float* dld, const void* z, con
                           int64_t mask_div, int64_t S, int64_t D, int dtype, int inverse, void* stream);
 
 /* ---- fused NICE feed-forward stack (the dominant kernel) --------------------------------------- */
-/* Bytes of packed weights for ONE step (two nets), MFMA fragment order. */
+/* Bytes of packed weights for ONE step (two nets): forward task regions, backward task regions and
+ * biases in MFMA fragment order; a K-step image is K times this (sections are laid out by K). */
 int64_t mivae_nice_pack_bytes(int64_t h, int64_t H, int dtype);
 /* ptr_table: device int64[K][8] of fp32 parameter addresses {W1s,b1s,W2s,b2s,W1t,b1t,W2t,b2t} in
  * torch.nn.Linear layout (W1 (H,h), W2 (h,H)) -- the tensors behind the state-dict keys
@@ -111,16 +112,26 @@ int mivae_nice_stack_fwd(const void* z_in, void* z_out, void* x1_hist, const int
                          const void* packed, float* tok_val, int64_t Bn, int64_t mask_div, int64_t S,
                          int64_t D, int64_t H, int64_t K, int act, int inverse, int base, float mu,
                          float std, int dtype, void* stream);
-/* token count padded to the wave tile (leading dimension of Gt / Ht / dSt) */
+/* token count padded to the slab granule (leading dimension of Gt / Ht / dSt / x0t) */
 int64_t mivae_nice_stack_npad(int64_t N);
 /* Backward of the forward direction.  dz_out (N,D) / dlogp (Bn) may be NULL.  Emits dz_in and the
- * token-contiguous operands of the weight-gradient GEMMs: Gt, Ht (K,2,Hp,Npad) = d pre-activation and
- * hidden activations, dSt (K,2,hp,Npad) = ds / dt; Hp, hp = H, h rounded up to 32. */
+ * token-contiguous operands of the weight-gradient products: Gt, Ht (K,2,Hp,Npad) = d pre-activation
+ * and hidden activations, dSt (K,2,hp,Npad) = ds / dt, x0t (hp,Npad) = (x0 * mask)^T; Hp, hp = H, h
+ * rounded up to 32.  (Autograd of couplings.py:141-162 + nn/feedforward.py:93-98 w.r.t. z.) */
 int mivae_nice_stack_bwd(const void* z_in, const void* z_out, const void* x1_hist, const int64_t* mask,
                          const void* packed, const void* dz_out, const float* dlogp, void* dz_in,
-                         void* Gt, void* Ht, void* dSt, int64_t Bn, int64_t mask_div, int64_t S,
-                         int64_t D, int64_t H, int64_t K, int act, int base, float mu, float std,
-                         int dtype, void* stream);
+                         void* Gt, void* Ht, void* dSt, void* x0t, int64_t Bn, int64_t mask_div,
+                         int64_t S, int64_t D, int64_t H, int64_t K, int act, int base, float mu,
+                         float std, int dtype, void* stream);
+/* floats of workspace mivae_nice_dw needs for N tokens */
+int64_t mivae_nice_dw_workspace_floats(int64_t N, int64_t h, int64_t H, int64_t K);
+/* Weight gradients of the K x 2 feed-forward nets from the backward's side outputs, in nn.Linear
+ * layout: dW1 (K,2,H,h), db1 (K,2,H), dW2 (K,2,h,H), db2 (K,2,h), fp32.  Split over token slabs and
+ * reduced in fixed order (deterministic).  (Autograd of nn/feedforward.py:93-98 w.r.t. the
+ * `_linear_layers.0.{weight,bias}` / `_output.{weight,bias}` parameters of both nets.) */
+int mivae_nice_dw(const void* Gt, const void* Ht, const void* dSt, const void* x0t, float* workspace,
+                  float* dW1, float* db1, float* dW2, float* db2, int64_t N, int64_t h, int64_t H,
+                  int64_t K, int dtype, void* stream);
 
 /* ---- ActNorm ------------------------------------------------------------------------------------- */
 /* out = (z exp(log_scale) + bias) * mask  (inverse: ((z - bias) * mask) / (exp(log_scale) + 1e-13));

@@ -42,13 +42,16 @@ SIGNATURES = {
     "mivae_nice_pack": [P, P, I64, I64, I64, I32, P],
     "mivae_nice_stack_fwd": [P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I32, I32, I32, F32, F32, I32, P],
     "mivae_nice_stack_npad": [I64],
-    "mivae_nice_stack_bwd": [P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I32, I32, F32, F32, I32, P],
+    "mivae_nice_stack_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I32, I32, F32, F32, I32, P],
+    "mivae_nice_dw_workspace_floats": [I64, I64, I64, I64],
+    "mivae_nice_dw": [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I32, P],
 }
 _RET = {
     "mivae_last_error": ctypes.c_char_p,
     "mivae_col_workspace_floats": I64,
     "mivae_nice_pack_bytes": I64,
     "mivae_nice_stack_npad": I64,
+    "mivae_nice_dw_workspace_floats": I64,
 }
 
 _lib = None

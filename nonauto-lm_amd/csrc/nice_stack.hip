@@ -1,0 +1,1139 @@
+// Fused NICE (affine-coupling) flow stack for gfx950: K coupling steps with feed-forward s/t nets
+// (one hidden layer) in ONE launch -- forward / inverse / backward -- plus the split-K weight-gradient
+// kernel that consumes the backward's token-contiguous side outputs.
+//
+// Reference semantics: NICECoupling.forward/.backward (vae_lm/models/base/flows/couplings.py:141-183)
+// with FeedForwardCoupling nets (couplings.py:50-51, nn/feedforward.py:93-98), iterated by
+// FlowPrior.forward_pass / backward_pass (nonauto_lm/priors/flow_prior.py:37-70), optionally followed
+// by the base log-prob (priors/prior.py:148-158).
+//
+// Design (MI355X-first):
+//  * a workgroup is W waves (1..8); each wave64 owns 32 consecutive tokens for ALL K steps: z is read
+//    once and written once.  The reference never swaps halves (couplings.py:185-188), so
+//    x0 = z[..., :D/2] is the B operand of every first-layer product of every step: it is loaded once
+//    and stays in registers; only x1 evolves.
+//  * everything is computed transposed (features x tokens) on v_mfma_f32_32x32x16_bf16 (bf16 mode) or
+//    v_mfma_f32_32x32x2_f32 (exact fp32 mode):  a^T = W1 . x0^T -> act -> s^T = W2 . hid^T.  The first
+//    product's 32x32 accumulator (token on the lane, hidden unit in the registers) is converted in
+//    registers into the B operand of the second product: activations never touch LDS.
+//  * weights are the streamed operand.  They are pre-packed once per call (k_nice_pack) into "task"
+//    regions -- one per (step, net, 32-wide hidden chunk) -- in exact MFMA-fragment order, and streamed
+//    global -> LDS with global_load_lds (16 B/lane, lane-linear 1 KiB pieces) into a double buffer:
+//    the region of task i+1 is in flight while the W waves of the block read task i's fragments with
+//    conflict-free ds_read_b128.  One barrier per task; biases come in through the scalar cache so
+//    that no ordinary vector load sits between the LDS-DMA issue and its wait.
+//  * masked log-det: per-lane partial over the registers, one __shfl_xor across the two half-waves,
+//    fp32 throughout; per-token value out, per-sentence sum is mivae_segment_sum (fixed order).
+//  * backward recomputes s from x0, walks the affine chain in reverse with the saved per-step x1,
+//    produces dz in the same launch and emits token-contiguous ([feature][token]) ds/dt, hidden, d(pre-
+//    activation) and x0 tensors; k_dw_partial/k_dw_reduce turn those into dW1/db1/dW2/db2 with
+//    K-contiguous NT MFMA products, split over token slabs and reduced in fixed order (no atomics).
+#include "common.hpp"
+
+using namespace mivae;
+
+namespace {
+
+enum Act { ACT_LINEAR = 0, ACT_GELU = 1, ACT_SWISH = 2, ACT_RELU = 3, ACT_TANH = 4, ACT_SIGMOID = 5 };
+
+// ---- fast transcendental helpers (v_exp_f32 based) -------------------------------------------------
+// exp(x) = 2^(x log2 e) on the hardware exp2 unit: relative error ~1e-7 (1 + |x|) -- well inside the
+// 1e-5 parity budget for |s| < ~30, far cheaper than the ocml range-reduced expf.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+
+// erf(x) = sign(x) (1 - 2^{a q(a)}), a = min(|x|, 4), q = degree-7 weighted least-squares fit of
+// log2(erfc(a)) / a on [0, 4] (fit and error scan: DESIGN.md "erf").  Max abs error 1.1e-7 in fp32
+// arithmetic (erf-GELU abs error <= 1.0e-7); 11 VALU ops + 1 v_exp_f32, branch free.
+// Reference semantics: x * 0.5 * (1 + erf(x / sqrt 2)), vae_lm/nn/activation.py:9-16.
+__device__ __forceinline__ float fast_erf(float x) {
+  const float a = fminf(fabsf(x), 4.0f);
+  float q = -4.471107996e-05f;
+  q = fmaf(q, a, 4.402441469e-04f);
+  q = fmaf(q, a, -1.472712344e-03f);
+  q = fmaf(q, a, -8.012262794e-04f);
+  q = fmaf(q, a, 2.827611896e-02f);
+  q = fmaf(q, a, -1.484914114e-01f);
+  q = fmaf(q, a, -9.184144181e-01f);
+  q = fmaf(q, a, -1.627908727e+00f);
+  const float r = 1.0f - __builtin_amdgcn_exp2f(q * a);
+  return copysignf(r, x);
+}
+
+// activation applied to a whole accumulator tile; `act` is wave-uniform (kernel argument)
+__device__ __forceinline__ void act_tile(int act, f32x16& a) {
+  switch (act) {
+    case ACT_GELU:
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a[r] = a[r] * 0.5f * (1.0f + fast_erf(a[r] * kInvSqrt2));
+      break;
+    case ACT_SWISH:
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a[r] = a[r] / (1.0f + fast_exp(-a[r]));
+      break;
+    case ACT_RELU:
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a[r] = a[r] > 0.f ? a[r] : 0.f;
+      break;
+    case ACT_TANH:
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a[r] = tanhf(a[r]);
+      break;
+    case ACT_SIGMOID:
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a[r] = 1.0f / (1.0f + fast_exp(-a[r]));
+      break;
+    default:
+      break;
+  }
+}
+// value (in place) and derivative
+__device__ __forceinline__ void act_tile_fd(int act, f32x16& a, f32x16& d) {
+  switch (act) {
+    case ACT_GELU:
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float x = a[r];
+        const float cdf = 0.5f * (1.0f + fast_erf(x * kInvSqrt2));
+        a[r] = x * cdf;
+        d[r] = cdf + x * kInvSqrt2Pi * fast_exp(-0.5f * x * x);
+      }
+      break;
+    case ACT_SWISH:
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float x = a[r];
+        const float sg = 1.0f / (1.0f + fast_exp(-x));
+        a[r] = x * sg;
+        d[r] = sg + x * sg * (1.0f - sg);
+      }
+      break;
+    case ACT_RELU:
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float x = a[r];
+        a[r] = x > 0.f ? x : 0.f;
+        d[r] = x > 0.f ? 1.f : 0.f;
+      }
+      break;
+    case ACT_TANH:
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float y = tanhf(a[r]);
+        a[r] = y;
+        d[r] = 1.0f - y * y;
+      }
+      break;
+    case ACT_SIGMOID:
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float y = 1.0f / (1.0f + fast_exp(-a[r]));
+        a[r] = y;
+        d[r] = y * (1.0f - y);
+      }
+      break;
+    default:
+#pragma unroll
+      for (int r = 0; r < 16; ++r) d[r] = 1.f;
+      break;
+  }
+}
+
+// ---- MFMA policies ---------------------------------------------------------------------------------
+// C/D layout of both (guide section 3): col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+__host__ __device__ __forceinline__ int acc_row(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
+
+struct MmaBF16 {
+  typedef bf16x8 AF;  // A fragment: row = lane & 31, k = 8 * (lane >> 5) + j
+  typedef bf16x8 BF;  // B fragment: col = lane & 31, k = 8 * (lane >> 5) + j
+  typedef unsigned short E;
+  static constexpr int KS = 16;   // k per MFMA
+  static constexpr int NS = 2;    // MFMAs per 32-deep k block
+  static constexpr int EPF = 8;   // elements per lane per fragment
+  static __device__ __forceinline__ f32x16 mma(AF a, BF b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+  // accumulator tile X (rows in registers) -> B fragment of k-step s of a product summing over X's rows.
+  // element j of lane half hh is row 16 s + 8 (j >> 2) + 4 hh + (j & 3) = acc_row(8 s + j, hh).
+  template <int s>
+  static __device__ __forceinline__ BF from_acc(const f32x16& x) {
+    BF f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (bf16_t)x[8 * s + j];
+    return f;
+  }
+  static __host__ __device__ __forceinline__ int nat_k(int ks, int hh, int j) { return 16 * ks + 8 * hh + j; }
+  static __host__ __device__ __forceinline__ int perm_k(int s, int hh, int j) { return acc_row(8 * s + j, hh); }
+  static __device__ __forceinline__ E enc(float v) { return f32_to_bf16(v); }
+};
+
+struct MmaF32 {
+  typedef float AF;  // A: row = lane & 31, k = lane >> 5
+  typedef float BF;  // B: col = lane & 31, k = lane >> 5
+  typedef float E;
+  static constexpr int KS = 2;
+  static constexpr int NS = 16;
+  static constexpr int EPF = 1;
+  static __device__ __forceinline__ f32x16 mma(AF a, BF b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+  }
+  template <int s>
+  static __device__ __forceinline__ BF from_acc(const f32x16& x) { return x[s]; }
+  static __host__ __device__ __forceinline__ int nat_k(int ks, int hh, int) { return 2 * ks + hh; }
+  static __host__ __device__ __forceinline__ int perm_k(int s, int hh, int) { return acc_row(s, hh); }
+  static __device__ __forceinline__ E enc(float v) { return v; }
+};
+
+// ---- per-lane I/O in fragment / accumulator layouts ------------------------------------------------
+// x0 as B fragments (natural k order): lane (tok = lane & 31, hh) holds x0[tok][nat_k(ks, hh, j)].
+template <typename T, bool VEC, int NKS>
+__device__ __forceinline__ void load_x0_f32(const T* __restrict__ zrow, bool valid, int h, int hh,
+                                            float (&x0f)[NKS]) {
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const int f = 2 * ks + hh;
+    float v = 0.f;
+    if (valid && f < h) {
+      float t1[1];
+      RowIO<T, 1>::load(zrow + f, t1);
+      v = t1[0];
+    }
+    x0f[ks] = v;
+  }
+}
+template <typename T, bool VEC, int NKS>
+__device__ __forceinline__ void load_x0_bf16(const T* __restrict__ zrow, bool valid, int h, int hh,
+                                             bf16x8 (&x0f)[NKS]) {
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const int f = 16 * ks + 8 * hh;
+    u16x8 raw = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (VEC) {
+      if (valid && f < h) raw = *reinterpret_cast<const u16x8*>(zrow + f);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (valid && f + j < h) raw[j] = ((const unsigned short*)zrow)[f + j];
+    }
+    x0f[ks] = __builtin_bit_cast(bf16x8, raw);
+  }
+}
+
+// accumulator layout tile set: regs[t][r] <-> row[32 t + acc_row(r, hh)], groups of 4 contiguous.
+template <typename T, bool VEC, int HT>
+__device__ __forceinline__ void load_acc(const T* __restrict__ row, bool valid, int h, int hh,
+                                         f32x16 (&x)[HT]) {
+#pragma unroll
+  for (int t = 0; t < HT; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int f = 32 * t + 8 * g + 4 * hh;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (VEC) {
+        if (valid && f < h) RowIO<T, 4>::load(row + f, v);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (valid && f + i < h) {
+            float t1[1];
+            RowIO<T, 1>::load(row + f + i, t1);
+            v[i] = t1[0];
+          }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) x[t][4 * g + i] = v[i];
+    }
+}
+template <typename T, bool VEC, int HT>
+__device__ __forceinline__ void store_acc(T* __restrict__ row, bool valid, int h, int hh,
+                                          const f32x16 (&x)[HT]) {
+#pragma unroll
+  for (int t = 0; t < HT; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int f = 32 * t + 8 * g + 4 * hh;
+      float v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = x[t][4 * g + i];
+      if (VEC) {
+        if (valid && f < h) RowIO<T, 4>::store(row + f, v);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (valid && f + i < h) {
+            float t1[1] = {v[i]};
+            RowIO<T, 1>::store(row + f + i, t1);
+          }
+      }
+    }
+}
+
+// transposed ([feature row][token]) store of one accumulator tile: row = row0 + acc_row(r, hh)
+template <typename T>
+__device__ __forceinline__ void store_tile_t(T* __restrict__ base, int64_t ld, int row0, int hh,
+                                             int64_t col, const f32x16& x) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float t1[1] = {x[r]};
+    RowIO<T, 1>::store(base + (int64_t)(row0 + acc_row(r, hh)) * ld + col, t1);
+  }
+}
+
+// ---- packed weight geometry ------------------------------------------------------------------------
+// Packed image = [FWD tasks][BWD tasks][biases]:
+//   FWD task (k, net, c): [W1n: NKS frags][W2p: HT*NS frags]                      (tbf bytes)
+//   BWD task (k, net, c): [W1n: NKS frags][W2Tp: HT*NS frags][W1Tp: HT*NS frags]  (tbb bytes)
+//   bias (k, net): [b1: Hp floats][b2: hp floats], natural order
+// a fragment = 64 lanes x EPF elements (1 KiB bf16 / 256 B fp32); every task is a multiple of 1 KiB.
+struct Geom {
+  int h, H, hp, Hp, HT, HC, K;
+  int fe, nks, ns, esize;
+  int64_t tbf, tbb;
+  int64_t off_bwd, off_bias, total;
+};
+static Geom make_geom(int h, int H, int K, bool bf16) {
+  Geom g;
+  g.h = h; g.H = H; g.K = K;
+  g.hp = (h + 31) / 32 * 32; g.Hp = (H + 31) / 32 * 32;
+  g.HT = g.hp / 32; g.HC = g.Hp / 32;
+  const int epf = bf16 ? 8 : 1, ks = bf16 ? 16 : 2;
+  g.esize = bf16 ? 2 : 4;
+  g.fe = 64 * epf; g.nks = g.hp / ks; g.ns = 32 / ks;
+  const int64_t fb = (int64_t)g.fe * g.esize;
+  g.tbf = (int64_t)(g.nks + g.HT * g.ns) * fb;
+  g.tbb = (int64_t)(g.nks + 2 * g.HT * g.ns) * fb;
+  g.off_bwd = (int64_t)K * 2 * g.HC * g.tbf;
+  g.off_bias = g.off_bwd + (int64_t)K * 2 * g.HC * g.tbb;
+  g.total = g.off_bias + (int64_t)K * 2 * (g.Hp + g.hp) * 4;
+  return g;
+}
+
+// Pack kernel: ptrs[k][8] = {W1s, b1s, W2s, b2s, W1t, b1t, W2t, b2t} (fp32, torch.nn.Linear layout:
+// W1 (H, h), W2 (h, H)).  grid = (ceil(per_net_items / 256), 2 nets, K).
+template <class P>
+__global__ void k_nice_pack(const int64_t* __restrict__ ptrs, char* __restrict__ packed, Geom g) {
+  const int net = blockIdx.y, k = blockIdx.z;
+  const float* W1 = reinterpret_cast<const float*>(ptrs[k * 8 + net * 4 + 0]);
+  const float* b1 = reinterpret_cast<const float*>(ptrs[k * 8 + net * 4 + 1]);
+  const float* W2 = reinterpret_cast<const float*>(ptrs[k * 8 + net * 4 + 2]);
+  const float* b2 = reinterpret_cast<const float*>(ptrs[k * 8 + net * 4 + 3]);
+  const int htns = g.HT * g.ns;
+  const int64_t tfe = (int64_t)(g.nks + htns) * g.fe, tbe = (int64_t)(g.nks + 2 * htns) * g.fe;
+  const int64_t nf = g.HC * tfe, nb = g.HC * tbe;
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nf + nb + g.Hp + g.hp) return;
+  if (idx >= nf + nb) {
+    const int64_t i = idx - nf - nb;
+    float* bp = reinterpret_cast<float*>(packed + g.off_bias) + (int64_t)(k * 2 + net) * (g.Hp + g.hp);
+    if (i < g.Hp) bp[i] = i < g.H ? b1[i] : 0.f;
+    else bp[i] = (i - g.Hp) < g.h ? b2[i - g.Hp] : 0.f;
+    return;
+  }
+  const bool bwd = idx >= nf;
+  if (bwd) idx -= nf;
+  const int64_t te = bwd ? tbe : tfe;
+  const int c = (int)(idx / te);
+  int64_t rem = idx % te;
+  typename P::E* dst = reinterpret_cast<typename P::E*>(
+      packed + (bwd ? g.off_bwd + ((int64_t)(k * 2 + net) * g.HC + c) * g.tbb
+                    : ((int64_t)(k * 2 + net) * g.HC + c) * g.tbf)) + rem;
+  int frag = (int)(rem / g.fe);
+  const int e = (int)(rem % g.fe);
+  const int lane = e / P::EPF, j = e % P::EPF;
+  const int r = lane & 31, hh = lane >> 5;
+  float v = 0.f;
+  if (frag < g.nks) {  // W1n: W1[32c + r][nat k]
+    const int row = 32 * c + r, col = P::nat_k(frag, hh, j);
+    if (row < g.H && col < g.h) v = W1[(int64_t)row * g.h + col];
+  } else {
+    frag -= g.nks;
+    const int which = frag / htns;  // fwd: 0 = W2p ; bwd: 0 = W2Tp, 1 = W1Tp
+    frag %= htns;
+    const int t = frag / g.ns, s = frag % g.ns;
+    const int pk = P::perm_k(s, hh, j);
+    if (!bwd) {               // W2p : W2[32t + r][32c + pk]
+      const int row = 32 * t + r, col = 32 * c + pk;
+      if (row < g.h && col < g.H) v = W2[(int64_t)row * g.H + col];
+    } else if (which == 0) {  // W2Tp : A[row = hidden 32c + r][k = out 32t + pk] = W2[32t + pk][32c + r]
+      const int row = 32 * t + pk, col = 32 * c + r;
+      if (row < g.h && col < g.H) v = W2[(int64_t)row * g.H + col];
+    } else {                  // W1Tp : A[row = in 32t + r][k = hidden 32c + pk] = W1[32c + pk][32t + r]
+      const int row = 32 * c + pk, col = 32 * t + r;
+      if (row < g.H && col < g.h) v = W1[(int64_t)row * g.h + col];
+    }
+  }
+  *dst = P::enc(v);
+}
+
+struct StackArgs {
+  const void* z_in;     // (N, D)
+  void* z_out;          // (N, D)
+  void* x1_hist;        // (K, N, h) or null            [fwd: written, bwd: read]
+  const int64_t* mask;  // (Bn / mask_div, S) or null
+  const char* packed;
+  float* tok_val;       // (N) per-token masked log-det (+ base log-prob)
+  int64_t N;
+  int S, mask_div, D, K;
+  int inverse, base, act;
+  float mu, inv2var, cst;  // base dist: -(z-mu)^2 * inv2var - cst
+  // backward only
+  const void* dz_out;   // (N, D) or null
+  const float* dlogp;   // (Bn) or null: d loss / d (per-sentence sum of tok_val)
+  void* dz_in;          // (N, D)
+  void* Gt;             // (K, 2, Hp, Npad) d pre-activation, token-contiguous
+  void* Ht;             // (K, 2, Hp, Npad) hidden activations
+  void* dSt;            // (K, 2, hp, Npad) ds / dt
+  void* x0t;            // (hp, Npad) x0 * mask
+  int64_t Npad;
+  Geom g;
+};
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_cvoid_t;
+typedef const __attribute__((address_space(4))) float cfloat_t;
+
+// Asynchronous global -> LDS copy of one task region (multiple of 1 KiB), split over the W waves.
+__device__ __forceinline__ void stage_region(const char* src, char* dst, int bytes, int wave, int W, int lane) {
+  const int pieces = bytes >> 10;
+  for (int p = wave; p < pieces; p += W)
+    __builtin_amdgcn_global_load_lds((glb_cvoid_t*)(src + ((int64_t)p << 10) + lane * 16),
+                                     (lds_void_t*)(dst + (p << 10)), 16, 0, 0);
+}
+
+// 32 consecutive biases (scalar-cache loads: the address is wave-uniform) -> accumulator layout
+__device__ __forceinline__ f32x16 bias_tile(cfloat_t* B, int hh) {
+  f32x16 a;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2);
+    const float lo = B[row], hi = B[row + 4];
+    a[r] = hh ? hi : lo;
+  }
+  return a;
+}
+
+template <int N>
+struct IntC { static constexpr int value = N; };
+
+// acc[t] += A[t][s] . Bfrag_s(x) for all t; A fragments at w[(t * NS + s) * 64] (LDS, per-lane pointer)
+template <class P, int HT, int s>
+struct AccumFromAcc {
+  static __device__ __forceinline__ void run(const typename P::AF* w, const f32x16& x, f32x16 (&acc)[HT]) {
+    typename P::BF b = P::template from_acc<s>(x);
+#pragma unroll
+    for (int t = 0; t < HT; ++t) acc[t] = P::mma(w[(t * P::NS + s) * 64], b, acc[t]);
+    if constexpr (s + 1 < P::NS) AccumFromAcc<P, HT, s + 1>::run(w, x, acc);
+  }
+};
+// out += sum_t A[t][s] . Bfrag_s(y[t])
+template <class P, int HT, int s>
+struct ReduceFromAcc {
+  static __device__ __forceinline__ void run(const typename P::AF* w, const f32x16 (&y)[HT], f32x16& out) {
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+      typename P::BF b = P::template from_acc<s>(y[t]);
+      out = P::mma(w[(t * P::NS + s) * 64], b, out);
+    }
+    if constexpr (s + 1 < P::NS) ReduceFromAcc<P, HT, s + 1>::run(w, y, out);
+  }
+};
+
+// first-layer pre-activation of one hidden chunk from the staged fragments: b1 + W1[c] . x0^T
+template <class P, int NKS>
+__device__ __forceinline__ f32x16 preact(const typename P::AF* w1, cfloat_t* b1c, int hh,
+                                         const typename P::BF (&x0f)[NKS]) {
+  f32x16 a = bias_tile(b1c, hh);
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) a = P::mma(w1[ks * 64], x0f[ks], a);
+  return a;
+}
+
+// one forward task: acc += W2[:, c] . act(b1[c] + W1[c] . x0^T)
+template <class P, int HT, int NKS>
+__device__ __forceinline__ void fwd_chunk(const char* buf, cfloat_t* b1c, int act, int lane, int hh,
+                                          const typename P::BF (&x0f)[NKS], f32x16 (&acc)[HT]) {
+  const typename P::AF* w1 = reinterpret_cast<const typename P::AF*>(buf) + lane;
+  f32x16 a = preact<P, NKS>(w1, b1c, hh, x0f);
+  act_tile(act, a);
+  AccumFromAcc<P, HT, 0>::run(w1 + NKS * 64, a, acc);
+}
+
+// walks (step, net-order, chunk) in consumption order without integer division
+struct TaskIt {
+  int kk, n, c;
+  __device__ __forceinline__ void next(int nn, int HC) {
+    if (++c == HC) { c = 0; if (++n == nn) { n = 0; ++kk; } }
+  }
+};
+
+template <typename T, bool VEC, int NKS, class P>
+__device__ __forceinline__ void load_x0(const T* zrow, bool ok, int h, int hh, typename P::BF (&x0f)[NKS]) {
+  if constexpr (P::KS == 2) load_x0_f32<T, VEC, NKS>(zrow, ok, h, hh, x0f);
+  else load_x0_bf16<T, VEC, NKS>(zrow, ok, h, hh, x0f);
+}
+
+template <class P, typename T, int HT, bool VEC>
+__global__ void __launch_bounds__(512) k_stack_fwd(StackArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int hp = HT * 32;
+  constexpr int NKS = hp / P::KS;
+  const int lane = threadIdx.x & 63;
+  const int r32 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int W = blockDim.x >> 6;
+  const Geom& g = a.g;
+  const int h = g.h;
+  const int64_t tok = ((int64_t)blockIdx.x * W + wave) * 32 + r32;
+  const bool valid = tok < a.N;
+  float m = 0.f;
+  if (valid) {
+    m = 1.f;
+    if (a.mask) {
+      const int64_t bn = tok / a.S;
+      m = (float)a.mask[(bn / a.mask_div) * a.S + (tok - bn * a.S)];
+    }
+  }
+  // a tile whose tokens are all padding (or out of range) produces zeros: skip its arithmetic
+  const bool live = __any(m != 0.f) != 0;
+  const T* zrow = reinterpret_cast<const T*>(a.z_in) + tok * a.D;
+  // masked tokens are computed on zeros: every output of such a token is multiplied by the mask
+  // anyway (couplings.py:159-161), and zeros keep exp() finite at padding positions.
+  typename P::BF x0f[NKS];
+  load_x0<T, VEC, NKS, P>(zrow, valid && m != 0.f, h, hh, x0f);
+  f32x16 x1[HT];
+  load_acc<T, VEC, HT>(zrow + h, valid && m != 0.f, h, hh, x1);
+  float ld = 0.f;
+
+  const int HC = g.HC;
+  const int ntasks = a.K * 2 * HC;
+  const int tbf = (int)g.tbf;
+  cfloat_t* bias = (cfloat_t*)(a.packed + g.off_bias);
+  // forward: s (0) then t (1); inverse: steps reversed, t then s
+  auto region = [&](const TaskIt& it) -> const char* {
+    const int k = a.inverse ? a.K - 1 - it.kk : it.kk;
+    const int net = a.inverse ? 1 - it.n : it.n;
+    return a.packed + ((int64_t)(k * 2 + net) * HC + it.c) * tbf;
+  };
+  TaskIt cur = {0, 0, 0}, nxt = {0, 0, 0};
+  stage_region(region(nxt), smem, tbf, wave, W, lane);
+  nxt.next(2, HC);
+  f32x16 acc[HT];
+  for (int i = 0; i < ntasks; ++i) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // task i landed for every wave; everyone is done reading the other buffer
+    if (i + 1 < ntasks) {
+      stage_region(region(nxt), smem + ((i + 1) & 1) * tbf, tbf, wave, W, lane);
+      nxt.next(2, HC);
+    }
+    if (live) {
+      const int k = a.inverse ? a.K - 1 - cur.kk : cur.kk;
+      const int net = a.inverse ? 1 - cur.n : cur.n;
+      cfloat_t* bb = bias + (int64_t)(k * 2 + net) * (g.Hp + g.hp);
+      if (cur.c == 0) {
+        if (cur.n == 0 && a.x1_hist)
+          store_acc<T, VEC, HT>(reinterpret_cast<T*>(a.x1_hist) + ((int64_t)k * a.N + tok) * h, valid, h, hh, x1);
+#pragma unroll
+        for (int t = 0; t < HT; ++t) acc[t] = bias_tile(bb + g.Hp + 32 * t, hh);
+      }
+      fwd_chunk<P, HT, NKS>(smem + (i & 1) * tbf, bb + 32 * cur.c, a.act, lane, hh, x0f, acc);
+      if (cur.c == HC - 1) {
+        // the two nets run back to back and are folded into x1 immediately
+        // (forward: x1 = exp(s) x1, then + t; inverse: x1 - t first, then * exp(-s))
+        if (!a.inverse) {
+          if (cur.n == 0) {
+#pragma unroll
+            for (int t = 0; t < HT; ++t)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) { x1[t][r] *= fast_exp(acc[t][r]); ld += acc[t][r]; }
+          } else {
+#pragma unroll
+            for (int t = 0; t < HT; ++t)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) x1[t][r] = (x1[t][r] + acc[t][r]) * m;
+          }
+        } else {
+          if (cur.n == 0) {
+#pragma unroll
+            for (int t = 0; t < HT; ++t)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) x1[t][r] -= acc[t][r];
+          } else {
+#pragma unroll
+            for (int t = 0; t < HT; ++t)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) { x1[t][r] = (x1[t][r] * fast_exp(-acc[t][r])) * m; ld -= acc[t][r]; }
+          }
+        }
+      }
+    }
+    cur.next(2, HC);
+  }
+
+  // outputs ------------------------------------------------------------------------------------------
+  T* orow = reinterpret_cast<T*>(a.z_out) + tok * a.D;
+  store_acc<T, VEC, HT>(orow + h, valid, h, hh, x1);
+  float base = 0.f;
+  // x0 half: out = x0 * m (x0f is already masked), in fragment layout
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    if constexpr (P::KS == 2) {
+      const int f = 2 * ks + hh;
+      const float v = x0f[ks];
+      if (valid && f < h) {
+        float t1[1] = {v};
+        RowIO<T, 1>::store(orow + f, t1);
+        const float d = v - a.mu;
+        base += -(d * d) * a.inv2var - a.cst;
+      }
+    } else {
+      const int f = 16 * ks + 8 * hh;
+      u16x8 raw = __builtin_bit_cast(u16x8, x0f[ks]);
+      if (VEC) {
+        if (valid && f < h) *reinterpret_cast<u16x8*>(orow + f) = raw;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (valid && f + j < h) {
+          if (!VEC) ((unsigned short*)orow)[f + j] = raw[j];
+          const float d = bf16_to_f32(raw[j]) - a.mu;
+          base += -(d * d) * a.inv2var - a.cst;
+        }
+    }
+  }
+  if (a.base) {
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int f = 32 * t + acc_row(r, hh);
+        if (f < h) {
+          float v = x1[t][r];
+          if (sizeof(T) == 2) v = bf16_to_f32(f32_to_bf16(v));  // what the stored z_K holds
+          const float d = v - a.mu;
+          base += -(d * d) * a.inv2var - a.cst;
+        }
+      }
+  } else {
+    base = 0.f;
+  }
+  float tv = (ld + base) * m;
+  tv += __shfl_xor(tv, 32, 64);
+  if (valid && hh == 0 && a.tok_val) a.tok_val[tok] = tv;
+}
+
+// ---- backward ----------------------------------------------------------------------------------------
+// one backward task of one net: given d(out) (accumulator tiles, rows = out features) recompute
+// hid / act', d hid = W2^T d(out), d pre = d hid * act', emit hid and d pre token-contiguous, and
+// accumulate dx0 += W1^T d pre.
+template <class P, typename T, int HT, int NKS>
+__device__ __forceinline__ void bwd_chunk(const char* buf, cfloat_t* b1c, int act, int lane, int hh,
+                                          const typename P::BF (&x0f)[NKS], const f32x16 (&dout)[HT],
+                                          f32x16 (&dx0)[HT], T* __restrict__ Gt, T* __restrict__ Ht,
+                                          int64_t ld, int row0, int64_t col) {
+  const typename P::AF* w1 = reinterpret_cast<const typename P::AF*>(buf) + lane;
+  f32x16 hid = preact<P, NKS>(w1, b1c, hh, x0f);
+  f32x16 dact;
+  act_tile_fd(act, hid, dact);
+  store_tile_t<T>(Ht, ld, row0, hh, col, hid);
+  f32x16 dh;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dh[r] = 0.f;
+  ReduceFromAcc<P, HT, 0>::run(w1 + NKS * 64, dout, dh);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dh[r] *= dact[r];
+  store_tile_t<T>(Gt, ld, row0, hh, col, dh);
+  AccumFromAcc<P, HT, 0>::run(w1 + (NKS + HT * P::NS) * 64, dh, dx0);
+}
+
+template <class P, typename T, int HT, bool VEC, int LB>
+__global__ void __launch_bounds__(LB) k_stack_bwd(StackArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int hp = HT * 32;
+  constexpr int NKS = hp / P::KS;
+  const int lane = threadIdx.x & 63;
+  const int r32 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int W = blockDim.x >> 6;
+  const Geom& g = a.g;
+  const int h = g.h;
+  const int64_t tok0 = ((int64_t)blockIdx.x * W + wave) * 32;
+  const int64_t tok = tok0 + r32;
+  const bool active = tok0 < a.Npad;   // wave-uniform; tiles in [N, Npad) still zero-fill emitted columns
+  const bool valid = tok < a.N;
+  float m = 0.f, dl = 0.f;
+  if (valid) {
+    const int64_t bn = tok / a.S;
+    m = 1.f;
+    if (a.mask) m = (float)a.mask[(bn / a.mask_div) * a.S + (tok - bn * a.S)];
+    if (a.dlogp) dl = a.dlogp[bn] * m;
+  }
+  const T* zrow = reinterpret_cast<const T*>(a.z_in) + tok * a.D;
+  // x0 * m as B fragments (masked tokens contribute exactly zero gradient)
+  typename P::BF x0f[NKS];
+  load_x0<T, VEC, NKS, P>(zrow, valid && m != 0.f, h, hh, x0f);
+  const int64_t ldn = a.Npad;
+  if (active) {  // x0^T for the dW1 products
+    T* xt = reinterpret_cast<T*>(a.x0t);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      if constexpr (P::KS == 2) {
+        float t1[1] = {x0f[ks]};
+        RowIO<T, 1>::store(xt + (int64_t)(2 * ks + hh) * ldn + tok, t1);
+      } else {
+        u16x8 raw = __builtin_bit_cast(u16x8, x0f[ks]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ((unsigned short*)xt)[(int64_t)(16 * ks + 8 * hh + j) * ldn + tok] = raw[j];
+      }
+    }
+  }
+
+  // upstream gradients in accumulator layout
+  f32x16 gx1[HT], dx0[HT];
+  if (a.dz_out) {
+    const T* grow = reinterpret_cast<const T*>(a.dz_out) + tok * a.D;
+    load_acc<T, VEC, HT>(grow, valid, h, hh, dx0);
+    load_acc<T, VEC, HT>(grow + h, valid, h, hh, gx1);
+  } else {
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dx0[t][r] = 0.f; gx1[t][r] = 0.f; }
+  }
+  if (a.base && a.dlogp) {  // d/dz_K of the base log-prob: dl * -(z_K - mu) / std^2
+    const T* orow = reinterpret_cast<const T*>(a.z_out) + tok * a.D;
+    f32x16 zk[HT];
+    const float c2 = 2.0f * a.inv2var;
+    load_acc<T, VEC, HT>(orow, valid, h, hh, zk);
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        dx0[t][r] += (32 * t + acc_row(r, hh) < h) ? -dl * (zk[t][r] - a.mu) * c2 : 0.f;
+    load_acc<T, VEC, HT>(orow + h, valid, h, hh, zk);
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        gx1[t][r] += (32 * t + acc_row(r, hh) < h) ? -dl * (zk[t][r] - a.mu) * c2 : 0.f;
+  }
+#pragma unroll
+  for (int t = 0; t < HT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dx0[t][r] *= m;
+
+  const int HC = g.HC;
+  const int ntasks = a.K * 3 * HC;
+  const int tbf = (int)g.tbf, tbb = (int)g.tbb;
+  cfloat_t* bias = (cfloat_t*)(a.packed + g.off_bias);
+  // LDS: [buf0 tbb][buf1 tbb][per-wave dt stash: HT tiles x 4 KiB]
+  float* stash = reinterpret_cast<float*>(smem + 2 * tbb) + (wave * HT * 64 + lane) * 16;
+  // per step (k descending): phase 0 = s-net forward tasks, phase 1 = s-net backward, phase 2 = t-net backward
+  auto region = [&](const TaskIt& it) -> const char* {
+    const int k = a.K - 1 - it.kk;
+    if (it.n == 0) return a.packed + ((int64_t)(k * 2) * HC + it.c) * tbf;
+    return a.packed + g.off_bwd + ((int64_t)(k * 2 + (it.n - 1)) * HC + it.c) * tbb;
+  };
+  TaskIt cur = {0, 0, 0}, nxt = {0, 0, 0};
+  stage_region(region(nxt), smem, tbf, wave, W, lane);
+  nxt.next(3, HC);
+  f32x16 dcur[HT];   // phase 0: s accumulators, then ds; phase 2: dt
+  for (int i = 0; i < ntasks; ++i) {
+    const int k = a.K - 1 - cur.kk;
+    f32x16 x1[HT];
+    const bool chain = active && cur.n == 0 && cur.c == HC - 1;
+    // ordinary vector loads go BEFORE the LDS-DMA issue so that their wait does not drain it
+    if (chain)
+      load_acc<T, VEC, HT>(reinterpret_cast<const T*>(a.x1_hist) + ((int64_t)k * a.N + tok) * h, valid, h, hh, x1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (i + 1 < ntasks) {
+      stage_region(region(nxt), smem + ((i + 1) & 1) * tbb, nxt.n == 0 ? tbf : tbb, wave, W, lane);
+      nxt.next(3, HC);
+    }
+    if (active) {
+      const char* buf = smem + (i & 1) * tbb;
+      T* dS = reinterpret_cast<T*>(a.dSt) + (int64_t)k * 2 * g.hp * ldn;
+      if (cur.n == 0) {
+        cfloat_t* bb = bias + (int64_t)(k * 2) * (g.Hp + g.hp);
+        if (cur.c == 0) {
+#pragma unroll
+          for (int t = 0; t < HT; ++t) dcur[t] = bias_tile(bb + g.Hp + 32 * t, hh);
+        }
+        fwd_chunk<P, HT, NKS>(buf, bb + 32 * cur.c, a.act, lane, hh, x0f, dcur);   // dcur = s
+        if (chain) {
+#pragma unroll
+          for (int t = 0; t < HT; ++t) {
+            f32x16 dt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const bool in = 32 * t + acc_row(r, hh) < h;
+              const float g1 = gx1[t][r] * m;
+              const float ge = g1 * fast_exp(dcur[t][r]);
+              dt[r] = g1;
+              dcur[t][r] = in ? ge * x1[t][r] + dl : 0.f;
+              gx1[t][r] = ge;
+            }
+            store_tile_t<T>(dS, ldn, 32 * t, hh, tok, dcur[t]);
+            store_tile_t<T>(dS + (int64_t)g.hp * ldn, ldn, 32 * t, hh, tok, dt);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              f32x4 v = {dt[4 * q], dt[4 * q + 1], dt[4 * q + 2], dt[4 * q + 3]};
+              *reinterpret_cast<f32x4*>(stash + t * 1024 + 4 * q) = v;
+            }
+          }
+        }
+      } else {
+        const int net = cur.n - 1;
+        cfloat_t* bb = bias + (int64_t)(k * 2 + net) * (g.Hp + g.hp);
+        if (net == 1 && cur.c == 0) {
+#pragma unroll
+          for (int t = 0; t < HT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              f32x4 v = *reinterpret_cast<const f32x4*>(stash + t * 1024 + 4 * q);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) dcur[t][4 * q + e] = v[e];
+            }
+        }
+        T* Gt = reinterpret_cast<T*>(a.Gt) + (int64_t)(k * 2 + net) * g.Hp * ldn;
+        T* Ht = reinterpret_cast<T*>(a.Ht) + (int64_t)(k * 2 + net) * g.Hp * ldn;
+        bwd_chunk<P, T, HT, NKS>(buf, bb + 32 * cur.c, a.act, lane, hh, x0f, dcur, dx0, Gt, Ht, ldn, 32 * cur.c, tok);
+      }
+    }
+    cur.next(3, HC);
+  }
+  T* drow = reinterpret_cast<T*>(a.dz_in) + tok * a.D;
+  store_acc<T, VEC, HT>(drow, valid, h, hh, dx0);
+  store_acc<T, VEC, HT>(drow + h, valid, h, hh, gx1);
+}
+
+// ---- weight gradients --------------------------------------------------------------------------------
+// dW1[k,n] = Gt[k,n] . x0t^T, db1 = rowsum(Gt); dW2[k,n]^T = Ht[k,n] . dSt[k,n]^T, db2 = rowsum(dSt).
+// All operands are [feature][token] (token-contiguous), so both MFMA fragments are plain 16-byte
+// per-lane loads along the contraction axis.  One wave per (k, net, type, 32-row tile of A, token
+// slab); partial tiles are dumped in register order and k_dw_reduce sums the slabs in fixed order.
+struct DwArgs {
+  const void *Gt, *Ht, *dSt, *x0t;
+  float* part;    // [items][HT][64][16]
+  float* partb1;  // [items][32]        (type 0 items only are meaningful)
+  float* partb2;  // [K*2][nslab][hp]
+  float *dW1, *db1, *dW2, *db2;
+  int64_t Npad;
+  int K, h, H, hp, Hp, HT, HC, nslab, slab_len;
+  int64_t nitems;
+};
+
+template <class P, typename T, int HT>
+__global__ void __launch_bounds__(256) k_dw_partial(DwArgs a) {
+  const int lane = threadIdx.x & 63, r32 = lane & 31, hh = lane >> 5;
+  int64_t item = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (item >= a.nitems) return;  // wave-uniform
+  int64_t id = item;
+  const int slab = (int)(id % a.nslab); id /= a.nslab;
+  const int mt = (int)(id % a.HC); id /= a.HC;
+  const int type = (int)(id & 1);
+  const int kn = (int)(id >> 1);
+  const int64_t ldn = a.Npad;
+  const T* A = reinterpret_cast<const T*>(type == 0 ? a.Gt : a.Ht) + ((int64_t)kn * a.Hp + 32 * mt + r32) * ldn;
+  const T* B = (type == 0 ? reinterpret_cast<const T*>(a.x0t)
+                          : reinterpret_cast<const T*>(a.dSt) + (int64_t)kn * a.hp * ldn) + (int64_t)r32 * ldn;
+  const int64_t t0 = (int64_t)slab * a.slab_len;
+  int64_t t1 = t0 + a.slab_len;
+  if (t1 > ldn) t1 = ldn;
+  f32x16 acc[HT], accb[HT];
+#pragma unroll
+  for (int t = 0; t < HT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[t][r] = 0.f; accb[t][r] = 0.f; }
+  const bool want_b2 = type == 1 && mt == 0;
+  if constexpr (P::KS == 16) {
+    const u16x8 ones_raw = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_raw);
+    for (int64_t k0 = t0; k0 < t1; k0 += 16) {
+      const bf16x8 af = *reinterpret_cast<const bf16x8*>(A + k0 + 8 * hh);
+      bf16x8 bf[HT];
+#pragma unroll
+      for (int t = 0; t < HT; ++t) bf[t] = *reinterpret_cast<const bf16x8*>(B + (int64_t)32 * t * ldn + k0 + 8 * hh);
+#pragma unroll
+      for (int t = 0; t < HT; ++t) acc[t] = P::mma(af, bf[t], acc[t]);
+      if (type == 0) accb[0] = P::mma(af, ones, accb[0]);
+      if (want_b2) {
+#pragma unroll
+        for (int t = 0; t < HT; ++t) accb[t] = P::mma(ones, bf[t], accb[t]);
+      }
+    }
+  } else {
+    for (int64_t k0 = t0; k0 < t1; k0 += 8) {
+      const f32x4 af = *reinterpret_cast<const f32x4*>(A + k0 + 4 * hh);
+      f32x4 bf[HT];
+#pragma unroll
+      for (int t = 0; t < HT; ++t) bf[t] = *reinterpret_cast<const f32x4*>(B + (int64_t)32 * t * ldn + k0 + 4 * hh);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int t = 0; t < HT; ++t) acc[t] = P::mma(af[j], bf[t][j], acc[t]);
+        if (type == 0) accb[0] = P::mma(af[j], 1.0f, accb[0]);
+        if (want_b2) {
+#pragma unroll
+          for (int t = 0; t < HT; ++t) accb[t] = P::mma(1.0f, bf[t][j], accb[t]);
+        }
+      }
+    }
+  }
+  float* out = a.part + ((item * HT) * 64 + lane) * 16;
+#pragma unroll
+  for (int t = 0; t < HT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v = {acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+      *reinterpret_cast<f32x4*>(out + (int64_t)t * 1024 + 4 * q) = v;
+    }
+  if (type == 0 && r32 == 0) {   // every column of accb[0] holds the row sums of the A tile
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a.partb1[item * 32 + acc_row(r, hh)] = accb[0][r];
+  }
+  if (want_b2 && hh == 0) {      // every row of accb[t] holds the row sums of B tile t (column = B row)
+#pragma unroll
+    for (int t = 0; t < HT; ++t) a.partb2[((int64_t)kn * a.nslab + slab) * a.hp + 32 * t + r32] = accb[t][0];
+  }
+}
+
+// element (row of A tile, col of B tile t) of a dumped accumulator
+__device__ __forceinline__ int64_t dump_index(int64_t item, int HT, int t, int rr, int cc) {
+  const int hh = (rr >> 2) & 1, r = (rr & 3) + 4 * (rr >> 3);
+  return ((item * HT + t) * 64 + cc + 32 * hh) * 16 + r;
+}
+
+__global__ void k_dw_reduce(DwArgs a) {
+  const int64_t n1 = (int64_t)a.K * 2 * a.H * a.h;   // dW1 elements == dW2 elements
+  const int64_t nb1 = (int64_t)a.K * 2 * a.H, nb2 = (int64_t)a.K * 2 * a.h;
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < n1) {            // dW1[kn][row < H][col < h]
+    const int col = (int)(idx % a.h); int64_t q = idx / a.h;
+    const int row = (int)(q % a.H); const int kn = (int)(q / a.H);
+    const int64_t item0 = (((int64_t)kn * 2 + 0) * a.HC + row / 32) * a.nslab;
+    float s = 0.f;
+    for (int sl = 0; sl < a.nslab; ++sl) s += a.part[dump_index(item0 + sl, a.HT, col / 32, row % 32, col % 32)];
+    a.dW1[idx] = s;
+  } else if (idx < 2 * n1) {  // dW2[kn][out < h][hid < H] = (Ht . dSt^T)[hid][out]
+    idx -= n1;
+    const int hid = (int)(idx % a.H); int64_t q = idx / a.H;
+    const int out = (int)(q % a.h); const int kn = (int)(q / a.h);
+    const int64_t item0 = (((int64_t)kn * 2 + 1) * a.HC + hid / 32) * a.nslab;
+    float s = 0.f;
+    for (int sl = 0; sl < a.nslab; ++sl) s += a.part[dump_index(item0 + sl, a.HT, out / 32, hid % 32, out % 32)];
+    a.dW2[idx] = s;
+  } else if (idx < 2 * n1 + nb1) {
+    idx -= 2 * n1;
+    const int row = (int)(idx % a.H); const int kn = (int)(idx / a.H);
+    const int64_t item0 = (((int64_t)kn * 2 + 0) * a.HC + row / 32) * a.nslab;
+    float s = 0.f;
+    for (int sl = 0; sl < a.nslab; ++sl) s += a.partb1[(item0 + sl) * 32 + row % 32];
+    a.db1[idx] = s;
+  } else if (idx < 2 * n1 + nb1 + nb2) {
+    idx -= 2 * n1 + nb1;
+    const int out = (int)(idx % a.h); const int kn = (int)(idx / a.h);
+    float s = 0.f;
+    for (int sl = 0; sl < a.nslab; ++sl) s += a.partb2[((int64_t)kn * a.nslab + sl) * a.hp + out];
+    a.db2[idx] = s;
+  }
+}
+
+// ---- host dispatch -----------------------------------------------------------------------------------
+template <class P, typename T, int HT>
+int launch_stack(bool bwd, bool vec, const StackArgs& a, unsigned grid, unsigned block, size_t lds, hipStream_t st) {
+  // dynamic LDS above 64 KiB has to be opted into per kernel
+  auto big = [&](const void* fn) {
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  };
+  if (bwd) {
+    constexpr int LB = HT <= 2 ? 512 : 256;
+    if (vec) { big((const void*)k_stack_bwd<P, T, HT, true, LB>); k_stack_bwd<P, T, HT, true, LB><<<grid, block, lds, st>>>(a); }
+    else { big((const void*)k_stack_bwd<P, T, HT, false, LB>); k_stack_bwd<P, T, HT, false, LB><<<grid, block, lds, st>>>(a); }
+  } else {
+    if (vec) { big((const void*)k_stack_fwd<P, T, HT, true>); k_stack_fwd<P, T, HT, true><<<grid, block, lds, st>>>(a); }
+    else { big((const void*)k_stack_fwd<P, T, HT, false>); k_stack_fwd<P, T, HT, false><<<grid, block, lds, st>>>(a); }
+  }
+  return 0;
+}
+template <class P, typename T>
+int launch_ht(int HT, bool bwd, bool vec, const StackArgs& a, unsigned grid, unsigned block, size_t lds, hipStream_t st) {
+  switch (HT) {
+    case 1: return launch_stack<P, T, 1>(bwd, vec, a, grid, block, lds, st);
+    case 2: return launch_stack<P, T, 2>(bwd, vec, a, grid, block, lds, st);
+    case 3: return launch_stack<P, T, 3>(bwd, vec, a, grid, block, lds, st);
+    case 4: return launch_stack<P, T, 4>(bwd, vec, a, grid, block, lds, st);
+  }
+  return -1;
+}
+
+constexpr size_t kLdsLimit = 160 * 1024;
+
+static int run_stack(const char* name, bool bwd, StackArgs a, int64_t Bn, int h, int H, int dtype,
+                     int act, hipStream_t st) {
+  MIVAE_REQUIRE(dtype == MIVAE_F32 || dtype == MIVAE_BF16, "%s: bad dtype %d", name, dtype);
+  MIVAE_REQUIRE(act >= 0 && act <= ACT_SIGMOID, "%s: unsupported activation id %d", name, act);
+  MIVAE_REQUIRE(a.K >= 1 && a.K <= 4096, "%s: K=%d out of range", name, a.K);
+  MIVAE_REQUIRE(h >= 1 && H >= 1 && a.D == 2 * h, "%s: D must be 2*h (D=%d h=%d)", name, a.D, h);
+  MIVAE_REQUIRE(a.S >= 1 && a.mask_div >= 1 && Bn >= 0, "%s: bad shape", name);
+  a.act = act;
+  a.g = make_geom(h, H, a.K, dtype == MIVAE_BF16);
+  if (a.g.HT > 4) {
+    mivae_set_error("%s: fused path supports D <= 256 (got D=%d); use the composed path", name, a.D);
+    return MIVAE_EUNSUPPORTED;
+  }
+  a.N = Bn * a.S;
+  if (a.N == 0) return MIVAE_OK;
+  MIVAE_REQUIRE(a.z_in && a.packed, "%s: null pointer", name);
+  MIVAE_REQUIRE(aligned16(a.packed), "%s: packed weights must be 16-byte aligned", name);
+  const int esz = dtype == MIVAE_BF16 ? 2 : 4;
+  // vector I/O needs 16-byte aligned rows and halves: D*esz % 16 == 0, h*esz % 16 == 0 (bf16: h % 8)
+  bool vec = aligned16(a.z_in) && (a.z_out == nullptr || aligned16(a.z_out)) &&
+             ((int64_t)h * esz) % 16 == 0 && (a.x1_hist == nullptr || aligned16(a.x1_hist));
+  if (bwd) vec = vec && aligned16(a.dz_in) && (a.dz_out == nullptr || aligned16(a.dz_out));
+  const int64_t ntok = bwd ? a.Npad : a.N;
+  const int64_t ntiles = (ntok + 31) / 32;
+  // waves per block: keep >= 256 blocks (one per CU) before growing the block; W waves share each
+  // staged weight region, so larger W cuts L2 -> LDS traffic per token.
+  int W = 1;
+  const int wmax = (bwd && a.g.HT > 2) ? 4 : 8;
+  while (W < wmax && ntiles / (2 * W) >= 256) W *= 2;
+  auto lds_need = [&](int w) -> size_t {
+    return bwd ? 2 * (size_t)a.g.tbb + (size_t)w * a.g.HT * 4096 : 2 * (size_t)a.g.tbf;
+  };
+  while (W > 1 && lds_need(W) > kLdsLimit) W /= 2;
+  MIVAE_REQUIRE(lds_need(W) <= kLdsLimit, "%s: task region too large for LDS (h=%d)", name, h);
+  const unsigned grid = (unsigned)((ntiles + W - 1) / W);
+  const size_t lds = lds_need(W);
+  int rc;
+  if (dtype == MIVAE_F32) rc = launch_ht<MmaF32, float>(a.g.HT, bwd, vec, a, grid, W * 64, lds, st);
+  else rc = launch_ht<MmaBF16, unsigned short>(a.g.HT, bwd, vec, a, grid, W * 64, lds, st);
+  MIVAE_REQUIRE(rc == 0, "%s: no kernel instance for HT=%d", name, a.g.HT);
+  MIVAE_CHECK_LAUNCH(name);
+  return MIVAE_OK;
+}
+
+// slab geometry of the weight-gradient kernel, shared by the workspace query and the launch
+static void dw_geom(int64_t Npad, const Geom& g, int& nslab, int& slab_len, int64_t& nitems) {
+  const int64_t items0 = (int64_t)g.K * 2 * 2 * g.HC;
+  int64_t want = (4096 + items0 - 1) / items0;
+  const int64_t maxs = (Npad + 63) / 64;
+  if (want > maxs) want = maxs;
+  if (want < 1) want = 1;
+  slab_len = (int)(((Npad + want - 1) / want + 63) / 64 * 64);
+  nslab = (int)((Npad + slab_len - 1) / slab_len);
+  nitems = items0 * nslab;
+}
+
+template <class P, typename T>
+int launch_dw(int HT, const DwArgs& a, hipStream_t st) {
+  const unsigned grid = (unsigned)((a.nitems + 3) / 4);
+  switch (HT) {
+    case 1: k_dw_partial<P, T, 1><<<grid, 256, 0, st>>>(a); return 0;
+    case 2: k_dw_partial<P, T, 2><<<grid, 256, 0, st>>>(a); return 0;
+    case 3: k_dw_partial<P, T, 3><<<grid, 256, 0, st>>>(a); return 0;
+    case 4: k_dw_partial<P, T, 4><<<grid, 256, 0, st>>>(a); return 0;
+  }
+  return -1;
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" int64_t mivae_nice_pack_bytes(int64_t h, int64_t H, int dtype) {
+  if (h < 1 || H < 1) return 0;
+  return make_geom((int)h, (int)H, 1, dtype == MIVAE_BF16).total;   // bytes per step; total = K * this
+}
+
+extern "C" int mivae_nice_pack(const int64_t* ptr_table, void* packed, int64_t K, int64_t h, int64_t H,
+                               int dtype, void* stream) {
+  MIVAE_REQUIRE(ptr_table && packed, "nice_pack: null pointer");
+  MIVAE_REQUIRE(K >= 1 && K <= 4096 && h >= 1 && H >= 1, "nice_pack: bad shape K=%ld h=%ld H=%ld", (long)K, (long)h, (long)H);
+  MIVAE_REQUIRE(dtype == MIVAE_F32 || dtype == MIVAE_BF16, "nice_pack: bad dtype %d", dtype);
+  Geom g = make_geom((int)h, (int)H, (int)K, dtype == MIVAE_BF16);
+  const int htns = g.HT * g.ns;
+  const int64_t total = (int64_t)g.HC * (2 * g.nks + 3 * htns) * g.fe + g.Hp + g.hp;
+  dim3 grid((unsigned)((total + 255) / 256), 2, (unsigned)K);
+  if (dtype == MIVAE_BF16) k_nice_pack<MmaBF16><<<grid, 256, 0, (hipStream_t)stream>>>(ptr_table, (char*)packed, g);
+  else k_nice_pack<MmaF32><<<grid, 256, 0, (hipStream_t)stream>>>(ptr_table, (char*)packed, g);
+  MIVAE_CHECK_LAUNCH("nice_pack");
+  return MIVAE_OK;
+}
+
+extern "C" int mivae_nice_stack_fwd(const void* z_in, void* z_out, void* x1_hist, const int64_t* mask,
+                                    const void* packed, float* tok_val, int64_t Bn, int64_t mask_div,
+                                    int64_t S, int64_t D, int64_t H, int64_t K, int act, int inverse,
+                                    int base, float mu, float std, int dtype, void* stream) {
+  MIVAE_REQUIRE(z_out, "nice_stack_fwd: null z_out");
+  MIVAE_REQUIRE(!base || std > 0.f, "nice_stack_fwd: std must be > 0");
+  MIVAE_REQUIRE(!(inverse && x1_hist), "nice_stack_fwd: no activation history in the inverse direction");
+  StackArgs a = {};
+  a.z_in = z_in; a.z_out = z_out; a.x1_hist = x1_hist; a.mask = mask;
+  a.packed = (const char*)packed; a.tok_val = tok_val;
+  a.S = (int)S; a.mask_div = (int)mask_div; a.D = (int)D; a.K = (int)K;
+  a.inverse = inverse; a.base = base;
+  a.mu = mu;
+  a.inv2var = base ? 1.0f / (2.0f * std * std) : 0.f;
+  a.cst = base ? logf(std) + 0.5f * kLog2Pi : 0.f;
+  return run_stack("nice_stack_fwd", false, a, Bn, (int)(D / 2), (int)H, dtype, act, (hipStream_t)stream);
+}
+
+extern "C" int64_t mivae_nice_stack_npad(int64_t N) { return (N + 63) / 64 * 64; }
+
+extern "C" int mivae_nice_stack_bwd(const void* z_in, const void* z_out, const void* x1_hist,
+                                    const int64_t* mask, const void* packed, const void* dz_out,
+                                    const float* dlogp, void* dz_in, void* Gt, void* Ht, void* dSt,
+                                    void* x0t, int64_t Bn, int64_t mask_div, int64_t S, int64_t D,
+                                    int64_t H, int64_t K, int act, int base, float mu, float std,
+                                    int dtype, void* stream) {
+  MIVAE_REQUIRE(x1_hist && dz_in && Gt && Ht && dSt && x0t, "nice_stack_bwd: null pointer");
+  MIVAE_REQUIRE(!base || (std > 0.f && z_out), "nice_stack_bwd: base log-prob needs z_out and std > 0");
+  StackArgs a = {};
+  a.z_in = z_in; a.z_out = const_cast<void*>(z_out); a.x1_hist = const_cast<void*>(x1_hist);
+  a.mask = mask; a.packed = (const char*)packed;
+  a.S = (int)S; a.mask_div = (int)mask_div; a.D = (int)D; a.K = (int)K;
+  a.inverse = 0; a.base = base;
+  a.mu = mu;
+  a.inv2var = base ? 1.0f / (2.0f * std * std) : 0.f;
+  a.cst = 0.f;
+  a.dz_out = dz_out; a.dlogp = dlogp; a.dz_in = dz_in; a.Gt = Gt; a.Ht = Ht; a.dSt = dSt; a.x0t = x0t;
+  a.Npad = mivae_nice_stack_npad(Bn * S);
+  return run_stack("nice_stack_bwd", true, a, Bn, (int)(D / 2), (int)H, dtype, act, (hipStream_t)stream);
+}
+
+extern "C" int64_t mivae_nice_dw_workspace_floats(int64_t N, int64_t h, int64_t H, int64_t K) {
+  if (N < 1 || h < 1 || H < 1 || K < 1) return 0;
+  Geom g = make_geom((int)h, (int)H, (int)K, true);
+  int nslab, slab_len;
+  int64_t nitems;
+  dw_geom(mivae_nice_stack_npad(N), g, nslab, slab_len, nitems);
+  return nitems * ((int64_t)g.HT * 1024 + 32) + (int64_t)K * 2 * nslab * g.hp;
+}
+
+extern "C" int mivae_nice_dw(const void* Gt, const void* Ht, const void* dSt, const void* x0t,
+                             float* workspace, float* dW1, float* db1, float* dW2, float* db2,
+                             int64_t N, int64_t h, int64_t H, int64_t K, int dtype, void* stream) {
+  MIVAE_REQUIRE(Gt && Ht && dSt && x0t && workspace && dW1 && db1 && dW2 && db2, "nice_dw: null pointer");
+  MIVAE_REQUIRE(N >= 1 && h >= 1 && H >= 1 && K >= 1 && K <= 4096, "nice_dw: bad shape");
+  MIVAE_REQUIRE(dtype == MIVAE_F32 || dtype == MIVAE_BF16, "nice_dw: bad dtype %d", dtype);
+  Geom g = make_geom((int)h, (int)H, (int)K, dtype == MIVAE_BF16);
+  MIVAE_REQUIRE(g.HT <= 4, "nice_dw: supports D <= 256");
+  MIVAE_REQUIRE(aligned16(Gt) && aligned16(Ht) && aligned16(dSt) && aligned16(x0t) && aligned16(workspace),
+                "nice_dw: operands must be 16-byte aligned");
+  DwArgs a = {};
+  a.Gt = Gt; a.Ht = Ht; a.dSt = dSt; a.x0t = x0t;
+  a.Npad = mivae_nice_stack_npad(N);
+  a.K = (int)K; a.h = (int)h; a.H = (int)H; a.hp = g.hp; a.Hp = g.Hp; a.HT = g.HT; a.HC = g.HC;
+  dw_geom(a.Npad, g, a.nslab, a.slab_len, a.nitems);
+  a.part = workspace;
+  a.partb1 = workspace + a.nitems * (int64_t)g.HT * 1024;
+  a.partb2 = a.partb1 + a.nitems * 32;
+  a.dW1 = dW1; a.db1 = db1; a.dW2 = dW2; a.db2 = db2;
+  int rc = dtype == MIVAE_BF16 ? launch_dw<MmaBF16, unsigned short>(g.HT, a, (hipStream_t)stream)
+                               : launch_dw<MmaF32, float>(g.HT, a, (hipStream_t)stream);
+  MIVAE_REQUIRE(rc == 0, "nice_dw: no kernel instance");
+  MIVAE_CHECK_LAUNCH("nice_dw_partial");
+  const int64_t nout = 2 * (int64_t)K * 2 * H * h + (int64_t)K * 2 * (H + h);
+  k_dw_reduce<<<(unsigned)((nout + 255) / 256), 256, 0, (hipStream_t)stream>>>(a);
+  MIVAE_CHECK_LAUNCH("nice_dw_reduce");
+  return MIVAE_OK;
+}

@@ -426,6 +426,7 @@ class _NiceStack(torch.autograd.Function):
         Gt = torch.empty(K, 2, Hp, npad, dtype=dt, device=z.device)
         Ht = torch.empty(K, 2, Hp, npad, dtype=dt, device=z.device)
         dSt = torch.empty(K, 2, hp, npad, dtype=dt, device=z.device)
+        x0t = torch.empty(hp, npad, dtype=dt, device=z.device)
         dz_in = torch.empty_like(z)
         # The kernel takes the per-token cotangent through `dlogp` with S = 1 segments: the
         # per-sentence broadcast has already been applied by _SegmentSum.backward.
@@ -433,19 +434,22 @@ class _NiceStack(torch.autograd.Function):
         dzo = None if dz_out is None else dz_out.contiguous()
         with _timed("nice_stack_bwd"):
             L.call("mivae_nice_stack_bwd", L.ptr(z), L.ptr(z_out), L.ptr(hist), L.ptr(mask), L.ptr(packed),
-                   L.ptr(dzo), L.ptr(dlog), L.ptr(dz_in), L.ptr(Gt), L.ptr(Ht), L.ptr(dSt), N, 1, 1, D, H, K,
-                   act, base, mu, std, code, L.stream())
-        # Weight gradients: K-contiguous NT GEMMs over the token axis on the emitted
-        # [feature][token] tensors (plain library GEMMs; see DESIGN.md "dW").
-        x0 = z.reshape(N, D)[:, :h]
-        dW1 = torch.matmul(Gt[..., :N], x0).float()                       # (K, 2, Hp, h)
-        db1 = Gt.sum(-1, dtype=torch.float32)                             # (K, 2, Hp)
-        dW2 = torch.matmul(dSt, Ht.transpose(-1, -2)).float()             # (K, 2, hp, Hp)
-        db2 = dSt.sum(-1, dtype=torch.float32)                            # (K, 2, hp)
+                   L.ptr(dzo), L.ptr(dlog), L.ptr(dz_in), L.ptr(Gt), L.ptr(Ht), L.ptr(dSt), L.ptr(x0t), N, 1, 1,
+                   D, H, K, act, base, mu, std, code, L.stream())
+        # Weight gradients: split-K NT MFMA products over the token axis on the emitted
+        # [feature][token] tensors, reduced in fixed order (k_dw_partial / k_dw_reduce).
+        ws = torch.empty(L.query("mivae_nice_dw_workspace_floats", N, h, H, K), dtype=torch.float32, device=z.device)
+        dW1 = torch.empty(K, 2, H, h, dtype=torch.float32, device=z.device)
+        db1 = torch.empty(K, 2, H, dtype=torch.float32, device=z.device)
+        dW2 = torch.empty(K, 2, h, H, dtype=torch.float32, device=z.device)
+        db2 = torch.empty(K, 2, h, dtype=torch.float32, device=z.device)
+        with _timed("nice_dw"):
+            L.call("mivae_nice_dw", L.ptr(Gt), L.ptr(Ht), L.ptr(dSt), L.ptr(x0t), L.ptr(ws), L.ptr(dW1), L.ptr(db1),
+                   L.ptr(dW2), L.ptr(db2), N, h, H, K, code, L.stream())
         grads = []
         for k in range(K):
             for net in range(2):
-                grads += [dW1[k, net, :H, :h], db1[k, net, :H], dW2[k, net, :h, :H], db2[k, net, :h]]
+                grads += [dW1[k, net], db1[k, net], dW2[k, net], db2[k, net]]
         return (dz_in, None, None, None, None, None, None, None, *grads)
 
 
