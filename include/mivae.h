@@ -94,14 +94,15 @@ int mivae_nice_affine_bwd(const void* dout, const float* dld, const void* z, con
                           int64_t mask_div, int64_t S, int64_t D, int dtype, int inverse, void* stream);
 
 /* ---- fused NICE feed-forward stack (the dominant kernel) --------------------------------------- */
-/* Bytes of packed weights for ONE step (two nets): forward task regions, backward task regions and
- * biases in MFMA fragment order; a K-step image is K times this (sections are laid out by K). */
+/* Bytes of packed weights for ONE step (two nets): the forward and backward task streams (weights in
+ * MFMA fragment order + biases, in the order the kernels consume them); a K-step image is K times
+ * this.  `inverse` != 0 packs the forward stream for the sampling direction (steps K-1..0, t then s). */
 int64_t mivae_nice_pack_bytes(int64_t h, int64_t H, int dtype);
 /* ptr_table: device int64[K][8] of fp32 parameter addresses {W1s,b1s,W2s,b2s,W1t,b1t,W2t,b2t} in
  * torch.nn.Linear layout (W1 (H,h), W2 (h,H)) -- the tensors behind the state-dict keys
  * `_flows.{k}._{s,t}_net._feedforward.{_linear_layers.0,_output}.{weight,bias}` (couplings.py:26-48). */
 int mivae_nice_pack(const int64_t* ptr_table, void* packed, int64_t K, int64_t h, int64_t H, int dtype,
-                    void* stream);
+                    int inverse, void* stream);
 /* K NICE steps with one-hidden-layer feed-forward nets in ONE launch.  Replaces the loop of
  * FlowPrior.forward_pass (nonauto flow_prior.py:45-52, auto :43-50) / .backward_pass (:65-69) over
  * NICECoupling(FeedForwardCoupling) steps, incl. FeedForward.forward (nn/feedforward.py:93-98).

@@ -29,6 +29,7 @@
 //    activation) and x0 tensors; k_dw_partial/k_dw_reduce turn those into dW1/db1/dW2/db2 with
 //    K-contiguous NT MFMA products, split over token slabs and reduced in fixed order (no atomics).
 #include "common.hpp"
+#include <stdlib.h>
 
 using namespace mivae;
 
@@ -41,100 +42,132 @@ enum Act { ACT_LINEAR = 0, ACT_GELU = 1, ACT_SWISH = 2, ACT_RELU = 3, ACT_TANH =
 // 1e-5 parity budget for |s| < ~30, far cheaper than the ocml range-reduced expf.
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 
-// erf(x) = sign(x) (1 - 2^{a q(a)}), a = min(|x|, 4), q = degree-7 weighted least-squares fit of
-// log2(erfc(a)) / a on [0, 4] (fit and error scan: DESIGN.md "erf").  Max abs error 1.1e-7 in fp32
-// arithmetic (erf-GELU abs error <= 1.0e-7); 11 VALU ops + 1 v_exp_f32, branch free.
-// Reference semantics: x * 0.5 * (1 + erf(x / sqrt 2)), vae_lm/nn/activation.py:9-16.
+// erf(x) = sign(x) (1 - 2^{a q(a)}), a = min(|x|, A), q = weighted least-squares fit of log2(erfc(a)) / a
+// on [0, A].  Branch free, one v_exp_f32.  Reference: x * 0.5 * (1 + erf(x / sqrt 2)), nn/activation.py:9-16.
+//   LOWP = false (fp32 latents): degree 7, A = 4: max abs error 1.1e-7 in fp32 arithmetic (GELU <= 1.0e-7)
+//   LOWP = true  (bf16 latents): degree 3, A = 3.2: max abs error 1.6e-5 (GELU <= 3e-5), two orders of
+//     magnitude under the bf16 rounding the hidden activations get before the second MFMA.
+template <bool LOWP>
 __device__ __forceinline__ float fast_erf(float x) {
-  const float a = fminf(fabsf(x), 4.0f);
-  float q = -4.471107996e-05f;
-  q = fmaf(q, a, 4.402441469e-04f);
-  q = fmaf(q, a, -1.472712344e-03f);
-  q = fmaf(q, a, -8.012262794e-04f);
-  q = fmaf(q, a, 2.827611896e-02f);
-  q = fmaf(q, a, -1.484914114e-01f);
-  q = fmaf(q, a, -9.184144181e-01f);
-  q = fmaf(q, a, -1.627908727e+00f);
+  float q, a;
+  if constexpr (LOWP) {
+    a = fminf(fabsf(x), 3.2f);
+    q = 0.019193846f;
+    q = fmaf(q, a, -0.136759108f);
+    q = fmaf(q, a, -0.923531482f);
+    q = fmaf(q, a, -1.6272781f);
+  } else {
+    a = fminf(fabsf(x), 4.0f);
+    q = -4.471107996e-05f;
+    q = fmaf(q, a, 4.402441469e-04f);
+    q = fmaf(q, a, -1.472712344e-03f);
+    q = fmaf(q, a, -8.012262794e-04f);
+    q = fmaf(q, a, 2.827611896e-02f);
+    q = fmaf(q, a, -1.484914114e-01f);
+    q = fmaf(q, a, -9.184144181e-01f);
+    q = fmaf(q, a, -1.627908727e+00f);
+  }
   const float r = 1.0f - __builtin_amdgcn_exp2f(q * a);
   return copysignf(r, x);
 }
 
-// activation applied to a whole accumulator tile; `act` is wave-uniform (kernel argument)
+// activation applied to a whole accumulator tile.  ACT = ACT_GELU is the specialised default of the
+// reference (couplings.py:32); ACT = -1 dispatches on the wave-uniform runtime id.
+template <int ACT, bool LOWP>
 __device__ __forceinline__ void act_tile(int act, f32x16& a) {
-  switch (act) {
-    case ACT_GELU:
+  if constexpr (ACT == ACT_GELU) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) a[r] = a[r] * 0.5f * (1.0f + fast_erf(a[r] * kInvSqrt2));
-      break;
-    case ACT_SWISH:
+    for (int r = 0; r < 16; ++r) {
+      const float hx = 0.5f * a[r];
+      a[r] = fmaf(hx, fast_erf<LOWP>(a[r] * kInvSqrt2), hx);
+    }
+  } else {
+    switch (act) {
+      case ACT_GELU:
 #pragma unroll
-      for (int r = 0; r < 16; ++r) a[r] = a[r] / (1.0f + fast_exp(-a[r]));
-      break;
-    case ACT_RELU:
+        for (int r = 0; r < 16; ++r) a[r] = a[r] * 0.5f * (1.0f + fast_erf<LOWP>(a[r] * kInvSqrt2));
+        break;
+      case ACT_SWISH:
 #pragma unroll
-      for (int r = 0; r < 16; ++r) a[r] = a[r] > 0.f ? a[r] : 0.f;
-      break;
-    case ACT_TANH:
+        for (int r = 0; r < 16; ++r) a[r] = a[r] / (1.0f + fast_exp(-a[r]));
+        break;
+      case ACT_RELU:
 #pragma unroll
-      for (int r = 0; r < 16; ++r) a[r] = tanhf(a[r]);
-      break;
-    case ACT_SIGMOID:
+        for (int r = 0; r < 16; ++r) a[r] = a[r] > 0.f ? a[r] : 0.f;
+        break;
+      case ACT_TANH:
 #pragma unroll
-      for (int r = 0; r < 16; ++r) a[r] = 1.0f / (1.0f + fast_exp(-a[r]));
-      break;
-    default:
-      break;
+        for (int r = 0; r < 16; ++r) a[r] = tanhf(a[r]);
+        break;
+      case ACT_SIGMOID:
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = 1.0f / (1.0f + fast_exp(-a[r]));
+        break;
+      default:
+        break;
+    }
   }
 }
 // value (in place) and derivative
+template <int ACT, bool LOWP>
 __device__ __forceinline__ void act_tile_fd(int act, f32x16& a, f32x16& d) {
-  switch (act) {
-    case ACT_GELU:
+  if constexpr (ACT == ACT_GELU) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float x = a[r];
-        const float cdf = 0.5f * (1.0f + fast_erf(x * kInvSqrt2));
-        a[r] = x * cdf;
-        d[r] = cdf + x * kInvSqrt2Pi * fast_exp(-0.5f * x * x);
-      }
-      break;
-    case ACT_SWISH:
+    for (int r = 0; r < 16; ++r) {
+      const float x = a[r];
+      const float cdf = fmaf(0.5f, fast_erf<LOWP>(x * kInvSqrt2), 0.5f);
+      a[r] = x * cdf;
+      d[r] = fmaf(x * kInvSqrt2Pi, __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f), cdf);
+    }
+  } else {
+    switch (act) {
+      case ACT_GELU:
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float x = a[r];
-        const float sg = 1.0f / (1.0f + fast_exp(-x));
-        a[r] = x * sg;
-        d[r] = sg + x * sg * (1.0f - sg);
-      }
-      break;
-    case ACT_RELU:
+        for (int r = 0; r < 16; ++r) {
+          const float x = a[r];
+          const float cdf = 0.5f * (1.0f + fast_erf<LOWP>(x * kInvSqrt2));
+          a[r] = x * cdf;
+          d[r] = cdf + x * kInvSqrt2Pi * fast_exp(-0.5f * x * x);
+        }
+        break;
+      case ACT_SWISH:
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float x = a[r];
-        a[r] = x > 0.f ? x : 0.f;
-        d[r] = x > 0.f ? 1.f : 0.f;
-      }
-      break;
-    case ACT_TANH:
+        for (int r = 0; r < 16; ++r) {
+          const float x = a[r];
+          const float sg = 1.0f / (1.0f + fast_exp(-x));
+          a[r] = x * sg;
+          d[r] = sg + x * sg * (1.0f - sg);
+        }
+        break;
+      case ACT_RELU:
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float y = tanhf(a[r]);
-        a[r] = y;
-        d[r] = 1.0f - y * y;
-      }
-      break;
-    case ACT_SIGMOID:
+        for (int r = 0; r < 16; ++r) {
+          const float x = a[r];
+          a[r] = x > 0.f ? x : 0.f;
+          d[r] = x > 0.f ? 1.f : 0.f;
+        }
+        break;
+      case ACT_TANH:
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float y = 1.0f / (1.0f + fast_exp(-a[r]));
-        a[r] = y;
-        d[r] = y * (1.0f - y);
-      }
-      break;
-    default:
+        for (int r = 0; r < 16; ++r) {
+          const float y = tanhf(a[r]);
+          a[r] = y;
+          d[r] = 1.0f - y * y;
+        }
+        break;
+      case ACT_SIGMOID:
 #pragma unroll
-      for (int r = 0; r < 16; ++r) d[r] = 1.f;
-      break;
+        for (int r = 0; r < 16; ++r) {
+          const float y = 1.0f / (1.0f + fast_exp(-a[r]));
+          a[r] = y;
+          d[r] = y * (1.0f - y);
+        }
+        break;
+      default:
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[r] = 1.f;
+        break;
+    }
   }
 }
 
@@ -278,18 +311,23 @@ __device__ __forceinline__ void store_tile_t(T* __restrict__ base, int64_t ld, i
   }
 }
 
-// ---- packed weight geometry ------------------------------------------------------------------------
-// Packed image = [FWD tasks][BWD tasks][biases]:
-//   FWD task (k, net, c): [W1n: NKS frags][W2p: HT*NS frags]                      (tbf bytes)
-//   BWD task (k, net, c): [W1n: NKS frags][W2Tp: HT*NS frags][W1Tp: HT*NS frags]  (tbb bytes)
-//   bias (k, net): [b1: Hp floats][b2: hp floats], natural order
+// ---- packed weight streams -------------------------------------------------------------------------
+// The packed image is two linear streams of equally sized "task" regions laid out in exactly the
+// order the kernels consume them, so staging is a pure sequential copy:
+//   F stream (forward, or inverse when packed with inverse = 1): task (kk, n, c), n = net order within
+//     the step, c = 32-wide hidden chunk:  [W1n: NKS frags][W2p: HT*NS frags][tail]          (tbf bytes)
+//   B stream (backward, steps K-1 .. 0): task (kk, phase, c); phase 0 = s-net forward recompute
+//     ([W1n][W2p][pad]), phase 1 / 2 = s / t net backward ([W1n][W2Tp][W1Tp]); + [tail]       (tbb bytes)
+//   tail (1 KiB): b1[32c .. 32c+31] (32 floats) | b2[0 .. hp) -- biases travel with the weights.
 // a fragment = 64 lanes x EPF elements (1 KiB bf16 / 256 B fp32); every task is a multiple of 1 KiB.
 struct Geom {
   int h, H, hp, Hp, HT, HC, K;
   int fe, nks, ns, esize;
-  int64_t tbf, tbb;
-  int64_t off_bwd, off_bias, total;
+  int64_t nfe_f, nfe_b;   // fragment elements per task
+  int64_t tbf, tbb;       // bytes per task
+  int64_t off_b, total;
 };
+constexpr int kTailBytes = 1024;
 static Geom make_geom(int h, int H, int K, bool bf16) {
   Geom g;
   g.h = h; g.H = H; g.K = K;
@@ -298,46 +336,61 @@ static Geom make_geom(int h, int H, int K, bool bf16) {
   const int epf = bf16 ? 8 : 1, ks = bf16 ? 16 : 2;
   g.esize = bf16 ? 2 : 4;
   g.fe = 64 * epf; g.nks = g.hp / ks; g.ns = 32 / ks;
-  const int64_t fb = (int64_t)g.fe * g.esize;
-  g.tbf = (int64_t)(g.nks + g.HT * g.ns) * fb;
-  g.tbb = (int64_t)(g.nks + 2 * g.HT * g.ns) * fb;
-  g.off_bwd = (int64_t)K * 2 * g.HC * g.tbf;
-  g.off_bias = g.off_bwd + (int64_t)K * 2 * g.HC * g.tbb;
-  g.total = g.off_bias + (int64_t)K * 2 * (g.Hp + g.hp) * 4;
+  g.nfe_f = (int64_t)(g.nks + g.HT * g.ns) * g.fe;
+  g.nfe_b = (int64_t)(g.nks + 2 * g.HT * g.ns) * g.fe;
+  g.tbf = g.nfe_f * g.esize + kTailBytes;
+  g.tbb = g.nfe_b * g.esize + kTailBytes;
+  g.off_b = (int64_t)K * 2 * g.HC * g.tbf;
+  g.total = g.off_b + (int64_t)K * 3 * g.HC * g.tbb;
   return g;
 }
 
 // Pack kernel: ptrs[k][8] = {W1s, b1s, W2s, b2s, W1t, b1t, W2t, b2t} (fp32, torch.nn.Linear layout:
-// W1 (H, h), W2 (h, H)).  grid = (ceil(per_net_items / 256), 2 nets, K).
+// W1 (H, h), W2 (h, H)).  grid = (ceil(slots per step / 256), 1, K consumption steps).
 template <class P>
-__global__ void k_nice_pack(const int64_t* __restrict__ ptrs, char* __restrict__ packed, Geom g) {
-  const int net = blockIdx.y, k = blockIdx.z;
+__global__ void k_nice_pack(const int64_t* __restrict__ ptrs, char* __restrict__ packed, Geom g, int inverse) {
+  const int kk = blockIdx.z;
+  const int htns = g.HT * g.ns;
+  const int64_t slots_f = g.nfe_f + 256, slots_b = g.nfe_b + 256;
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 2 * g.HC * slots_f + 3 * g.HC * slots_b) return;
+  int k, net, c, content;   // content 0 = forward fragments, 1 = backward fragments
+  int64_t slot, nfe;
+  char* base;
+  if (idx < 2 * g.HC * slots_f) {
+    const int tq = (int)(idx / slots_f);
+    slot = idx % slots_f;
+    const int n = tq / g.HC;
+    c = tq % g.HC;
+    k = inverse ? g.K - 1 - kk : kk;
+    net = inverse ? 1 - n : n;
+    content = 0; nfe = g.nfe_f;
+    base = packed + ((int64_t)(kk * 2 + n) * g.HC + c) * g.tbf;
+  } else {
+    idx -= 2 * g.HC * slots_f;
+    const int tq = (int)(idx / slots_b);
+    slot = idx % slots_b;
+    const int ph = tq / g.HC;
+    c = tq % g.HC;
+    k = g.K - 1 - kk;
+    net = ph == 2 ? 1 : 0;
+    content = ph == 0 ? 0 : 1; nfe = g.nfe_b;
+    base = packed + g.off_b + ((int64_t)(kk * 3 + ph) * g.HC + c) * g.tbb;
+  }
   const float* W1 = reinterpret_cast<const float*>(ptrs[k * 8 + net * 4 + 0]);
   const float* b1 = reinterpret_cast<const float*>(ptrs[k * 8 + net * 4 + 1]);
   const float* W2 = reinterpret_cast<const float*>(ptrs[k * 8 + net * 4 + 2]);
   const float* b2 = reinterpret_cast<const float*>(ptrs[k * 8 + net * 4 + 3]);
-  const int htns = g.HT * g.ns;
-  const int64_t tfe = (int64_t)(g.nks + htns) * g.fe, tbe = (int64_t)(g.nks + 2 * htns) * g.fe;
-  const int64_t nf = g.HC * tfe, nb = g.HC * tbe;
-  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= nf + nb + g.Hp + g.hp) return;
-  if (idx >= nf + nb) {
-    const int64_t i = idx - nf - nb;
-    float* bp = reinterpret_cast<float*>(packed + g.off_bias) + (int64_t)(k * 2 + net) * (g.Hp + g.hp);
-    if (i < g.Hp) bp[i] = i < g.H ? b1[i] : 0.f;
-    else bp[i] = (i - g.Hp) < g.h ? b2[i - g.Hp] : 0.f;
+  if (slot >= nfe) {   // tail
+    const int t = (int)(slot - nfe);
+    float v = 0.f;
+    if (t < 32) { if (32 * c + t < g.H) v = b1[32 * c + t]; }
+    else if (t - 32 < g.h) v = b2[t - 32];
+    reinterpret_cast<float*>(base + nfe * g.esize)[t] = v;
     return;
   }
-  const bool bwd = idx >= nf;
-  if (bwd) idx -= nf;
-  const int64_t te = bwd ? tbe : tfe;
-  const int c = (int)(idx / te);
-  int64_t rem = idx % te;
-  typename P::E* dst = reinterpret_cast<typename P::E*>(
-      packed + (bwd ? g.off_bwd + ((int64_t)(k * 2 + net) * g.HC + c) * g.tbb
-                    : ((int64_t)(k * 2 + net) * g.HC + c) * g.tbf)) + rem;
-  int frag = (int)(rem / g.fe);
-  const int e = (int)(rem % g.fe);
+  int frag = (int)(slot / g.fe);
+  const int e = (int)(slot % g.fe);
   const int lane = e / P::EPF, j = e % P::EPF;
   const int r = lane & 31, hh = lane >> 5;
   float v = 0.f;
@@ -346,13 +399,13 @@ __global__ void k_nice_pack(const int64_t* __restrict__ ptrs, char* __restrict__
     if (row < g.H && col < g.h) v = W1[(int64_t)row * g.h + col];
   } else {
     frag -= g.nks;
-    const int which = frag / htns;  // fwd: 0 = W2p ; bwd: 0 = W2Tp, 1 = W1Tp
+    const int which = frag / htns;  // forward: 0 = W2p (1 = padding); backward: 0 = W2Tp, 1 = W1Tp
     frag %= htns;
     const int t = frag / g.ns, s = frag % g.ns;
     const int pk = P::perm_k(s, hh, j);
-    if (!bwd) {               // W2p : W2[32t + r][32c + pk]
+    if (content == 0) {       // W2p : W2[32t + r][32c + pk]
       const int row = 32 * t + r, col = 32 * c + pk;
-      if (row < g.h && col < g.H) v = W2[(int64_t)row * g.H + col];
+      if (which == 0 && row < g.h && col < g.H) v = W2[(int64_t)row * g.H + col];
     } else if (which == 0) {  // W2Tp : A[row = hidden 32c + r][k = out 32t + pk] = W2[32t + pk][32c + r]
       const int row = 32 * t + pk, col = 32 * c + r;
       if (row < g.h && col < g.H) v = W2[(int64_t)row * g.H + col];
@@ -361,7 +414,7 @@ __global__ void k_nice_pack(const int64_t* __restrict__ ptrs, char* __restrict__
       if (row < g.H && col < g.h) v = W1[(int64_t)row * g.h + col];
     }
   }
-  *dst = P::enc(v);
+  reinterpret_cast<typename P::E*>(base)[slot] = P::enc(v);
 }
 
 struct StackArgs {
@@ -374,6 +427,8 @@ struct StackArgs {
   int64_t N;
   int S, mask_div, D, K;
   int inverse, base, act;
+  int G;                // tasks per staged block
+  int dbg;              // timing ablations (MIVAE_DBG env): 1 = no weight staging, 2 = no arithmetic
   float mu, inv2var, cst;  // base dist: -(z-mu)^2 * inv2var - cst
   // backward only
   const void* dz_out;   // (N, D) or null
@@ -389,9 +444,8 @@ struct StackArgs {
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_cvoid_t;
-typedef const __attribute__((address_space(4))) float cfloat_t;
 
-// Asynchronous global -> LDS copy of one task region (multiple of 1 KiB), split over the W waves.
+// Asynchronous global -> LDS copy of `bytes` (multiple of 1 KiB), split over the W waves.
 __device__ __forceinline__ void stage_region(const char* src, char* dst, int bytes, int wave, int W, int lane) {
   const int pieces = bytes >> 10;
   for (int p = wave; p < pieces; p += W)
@@ -399,71 +453,106 @@ __device__ __forceinline__ void stage_region(const char* src, char* dst, int byt
                                      (lds_void_t*)(dst + (p << 10)), 16, 0, 0);
 }
 
-// 32 consecutive biases (scalar-cache loads: the address is wave-uniform) -> accumulator layout
-__device__ __forceinline__ f32x16 bias_tile(cfloat_t* B, int hh) {
+// Double-buffered sequential stream of task regions: block b (G tasks) lives in LDS buffer b & 1; the
+// next block is in flight (LDS-DMA) while the current one is consumed.  One barrier per block.
+struct Stream {
+  const char* src;   // global stream base
+  char* lds;         // two buffers of G * tb bytes
+  int tb, G, ntasks, blk, g;
+  const char* cur;
+  int wave, W, lane, off;
+
+  __device__ __forceinline__ void init(const char* s, char* l, int tb_, int G_, int n, int wave_, int W_,
+                                       int lane_, int off_) {
+    src = s; lds = l; tb = tb_; G = G_; ntasks = n; blk = 0; g = G_; cur = l;
+    wave = wave_; W = W_; lane = lane_; off = off_;
+    if (!off) stage_region(src, lds, (n < G_ ? n : G_) * tb_, wave, W, lane);
+  }
+  // LDS address of the next task region (call once per task, by every wave of the block)
+  __device__ __forceinline__ const char* next() {
+    if (g == G) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();   // block `blk` has landed for every wave; the other buffer is free again
+      const int first = (blk + 1) * G;
+      if (first < ntasks && !off) {
+        const int cnt = ntasks - first < G ? ntasks - first : G;
+        stage_region(src + (int64_t)first * tb, lds + ((blk + 1) & 1) * G * tb, cnt * tb, wave, W, lane);
+      }
+      cur = lds + (blk & 1) * G * tb;
+      ++blk;
+      g = 0;
+    }
+    const char* p = cur + g * tb;
+    ++g;
+    return p;
+  }
+};
+
+// 32 consecutive biases from the staged tail -> accumulator layout (broadcast ds_read_b128)
+__device__ __forceinline__ f32x16 bias_tile(const float* B, int hh) {
   f32x16 a;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = (r & 3) + 8 * (r >> 2);
-    const float lo = B[row], hi = B[row + 4];
-    a[r] = hh ? hi : lo;
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(B + 8 * q + 4 * hh);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[4 * q + i] = v[i];
   }
   return a;
 }
 
-template <int N>
-struct IntC { static constexpr int value = N; };
+// LLVM SchedGroupMask bits for __builtin_amdgcn_sched_group_barrier
+#define SG_MFMA 0x008
+#define SG_DS_READ 0x100
 
-// acc[t] += A[t][s] . Bfrag_s(x) for all t; A fragments at w[(t * NS + s) * 64] (LDS, per-lane pointer)
+// Fragment sets are read from LDS into registers in one burst (the compiler otherwise sinks every
+// ds_read next to its MFMA and serialises LDS latency with the matrix pipe).
+template <class P, int N>
+__device__ __forceinline__ void load_frags(const typename P::AF* w, typename P::AF (&f)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) f[i] = w[i * 64];
+}
+
+// acc[t] += A[t][s] . Bfrag_s(x) for all t; A fragment (t, s) is f[t * NS + s]
 template <class P, int HT, int s>
 struct AccumFromAcc {
-  static __device__ __forceinline__ void run(const typename P::AF* w, const f32x16& x, f32x16 (&acc)[HT]) {
+  static __device__ __forceinline__ void run(const typename P::AF (&f)[HT * P::NS], const f32x16& x,
+                                             f32x16 (&acc)[HT]) {
     typename P::BF b = P::template from_acc<s>(x);
 #pragma unroll
-    for (int t = 0; t < HT; ++t) acc[t] = P::mma(w[(t * P::NS + s) * 64], b, acc[t]);
-    if constexpr (s + 1 < P::NS) AccumFromAcc<P, HT, s + 1>::run(w, x, acc);
+    for (int t = 0; t < HT; ++t) acc[t] = P::mma(f[t * P::NS + s], b, acc[t]);
+    if constexpr (s + 1 < P::NS) AccumFromAcc<P, HT, s + 1>::run(f, x, acc);
   }
 };
 // out += sum_t A[t][s] . Bfrag_s(y[t])
 template <class P, int HT, int s>
 struct ReduceFromAcc {
-  static __device__ __forceinline__ void run(const typename P::AF* w, const f32x16 (&y)[HT], f32x16& out) {
+  static __device__ __forceinline__ void run(const typename P::AF (&f)[HT * P::NS], const f32x16 (&y)[HT],
+                                             f32x16& out) {
 #pragma unroll
     for (int t = 0; t < HT; ++t) {
       typename P::BF b = P::template from_acc<s>(y[t]);
-      out = P::mma(w[(t * P::NS + s) * 64], b, out);
+      out = P::mma(f[t * P::NS + s], b, out);
     }
-    if constexpr (s + 1 < P::NS) ReduceFromAcc<P, HT, s + 1>::run(w, y, out);
+    if constexpr (s + 1 < P::NS) ReduceFromAcc<P, HT, s + 1>::run(f, y, out);
   }
 };
-
-// first-layer pre-activation of one hidden chunk from the staged fragments: b1 + W1[c] . x0^T
-template <class P, int NKS>
-__device__ __forceinline__ f32x16 preact(const typename P::AF* w1, cfloat_t* b1c, int hh,
-                                         const typename P::BF (&x0f)[NKS]) {
-  f32x16 a = bias_tile(b1c, hh);
-#pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) a = P::mma(w1[ks * 64], x0f[ks], a);
-  return a;
-}
 
 // one forward task: acc += W2[:, c] . act(b1[c] + W1[c] . x0^T)
-template <class P, int HT, int NKS>
-__device__ __forceinline__ void fwd_chunk(const char* buf, cfloat_t* b1c, int act, int lane, int hh,
+template <class P, int ACT, int HT, int NKS>
+__device__ __forceinline__ void fwd_chunk(const char* buf, const float* tail, int act, int lane, int hh,
                                           const typename P::BF (&x0f)[NKS], f32x16 (&acc)[HT]) {
   const typename P::AF* w1 = reinterpret_cast<const typename P::AF*>(buf) + lane;
-  f32x16 a = preact<P, NKS>(w1, b1c, hh, x0f);
-  act_tile(act, a);
-  AccumFromAcc<P, HT, 0>::run(w1 + NKS * 64, a, acc);
+  typename P::AF f1[NKS], f2[HT * P::NS];
+  load_frags<P, NKS>(w1, f1);
+  load_frags<P, HT * P::NS>(w1 + NKS * 64, f2);
+  f32x16 a = bias_tile(tail, hh);
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) a = P::mma(f1[ks], x0f[ks], a);
+  __builtin_amdgcn_sched_group_barrier(SG_DS_READ, NKS + HT * P::NS + 4, 0);
+  __builtin_amdgcn_sched_group_barrier(SG_MFMA, NKS, 0);
+  act_tile<ACT, P::KS == 16>(act, a);
+  AccumFromAcc<P, HT, 0>::run(f2, a, acc);
 }
-
-// walks (step, net-order, chunk) in consumption order without integer division
-struct TaskIt {
-  int kk, n, c;
-  __device__ __forceinline__ void next(int nn, int HC) {
-    if (++c == HC) { c = 0; if (++n == nn) { n = 0; ++kk; } }
-  }
-};
 
 template <typename T, bool VEC, int NKS, class P>
 __device__ __forceinline__ void load_x0(const T* zrow, bool ok, int h, int hh, typename P::BF (&x0f)[NKS]) {
@@ -471,8 +560,8 @@ __device__ __forceinline__ void load_x0(const T* zrow, bool ok, int h, int hh, t
   else load_x0_bf16<T, VEC, NKS>(zrow, ok, h, hh, x0f);
 }
 
-template <class P, typename T, int HT, bool VEC>
-__global__ void __launch_bounds__(512) k_stack_fwd(StackArgs a) {
+template <class P, typename T, int HT, bool VEC, int LB, int ACT>
+__global__ void __launch_bounds__(LB) k_stack_fwd(StackArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int hp = HT * 32;
   constexpr int NKS = hp / P::KS;
@@ -493,7 +582,7 @@ __global__ void __launch_bounds__(512) k_stack_fwd(StackArgs a) {
     }
   }
   // a tile whose tokens are all padding (or out of range) produces zeros: skip its arithmetic
-  const bool live = __any(m != 0.f) != 0;
+  const bool live = (__any(m != 0.f) != 0) && !(a.dbg & 2);
   const T* zrow = reinterpret_cast<const T*>(a.z_in) + tok * a.D;
   // masked tokens are computed on zeros: every output of such a token is multiplied by the mask
   // anyway (couplings.py:159-161), and zeros keep exp() finite at padding positions.
@@ -504,68 +593,58 @@ __global__ void __launch_bounds__(512) k_stack_fwd(StackArgs a) {
   float ld = 0.f;
 
   const int HC = g.HC;
-  const int ntasks = a.K * 2 * HC;
   const int tbf = (int)g.tbf;
-  cfloat_t* bias = (cfloat_t*)(a.packed + g.off_bias);
-  // forward: s (0) then t (1); inverse: steps reversed, t then s
-  auto region = [&](const TaskIt& it) -> const char* {
-    const int k = a.inverse ? a.K - 1 - it.kk : it.kk;
-    const int net = a.inverse ? 1 - it.n : it.n;
-    return a.packed + ((int64_t)(k * 2 + net) * HC + it.c) * tbf;
-  };
-  TaskIt cur = {0, 0, 0}, nxt = {0, 0, 0};
-  stage_region(region(nxt), smem, tbf, wave, W, lane);
-  nxt.next(2, HC);
+  Stream st;
+  st.init(a.packed, smem, tbf, a.G, a.K * 2 * HC, wave, W, lane, a.dbg & 1);
   f32x16 acc[HT];
-  for (int i = 0; i < ntasks; ++i) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();   // task i landed for every wave; everyone is done reading the other buffer
-    if (i + 1 < ntasks) {
-      stage_region(region(nxt), smem + ((i + 1) & 1) * tbf, tbf, wave, W, lane);
-      nxt.next(2, HC);
-    }
-    if (live) {
-      const int k = a.inverse ? a.K - 1 - cur.kk : cur.kk;
-      const int net = a.inverse ? 1 - cur.n : cur.n;
-      cfloat_t* bb = bias + (int64_t)(k * 2 + net) * (g.Hp + g.hp);
-      if (cur.c == 0) {
-        if (cur.n == 0 && a.x1_hist)
-          store_acc<T, VEC, HT>(reinterpret_cast<T*>(a.x1_hist) + ((int64_t)k * a.N + tok) * h, valid, h, hh, x1);
+  for (int kk = 0; kk < a.K; ++kk) {
+    const int k = a.inverse ? a.K - 1 - kk : kk;
+    if (live && a.x1_hist)
+      store_acc<T, VEC, HT>(reinterpret_cast<T*>(a.x1_hist) + ((int64_t)k * a.N + tok) * h, valid, h, hh, x1);
+    for (int n = 0; n < 2; ++n) {
 #pragma unroll
-        for (int t = 0; t < HT; ++t) acc[t] = bias_tile(bb + g.Hp + 32 * t, hh);
+      for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+      const char* buf = nullptr;
+      for (int c = 0; c < HC; ++c) {
+        buf = st.next();
+        if (live) fwd_chunk<P, ACT, HT, NKS>(buf, reinterpret_cast<const float*>(buf + tbf - kTailBytes), a.act, lane, hh, x0f, acc);
       }
-      fwd_chunk<P, HT, NKS>(smem + (i & 1) * tbf, bb + 32 * cur.c, a.act, lane, hh, x0f, acc);
-      if (cur.c == HC - 1) {
+      if (live) {
         // the two nets run back to back and are folded into x1 immediately
-        // (forward: x1 = exp(s) x1, then + t; inverse: x1 - t first, then * exp(-s))
-        if (!a.inverse) {
-          if (cur.n == 0) {
+        // (forward: x1 = exp(s) x1, then + t; inverse: x1 - t first, then * exp(-s)); b2 joins here
+        const float* b2 = reinterpret_cast<const float*>(buf + tbf - kTailBytes) + 32;
 #pragma unroll
-            for (int t = 0; t < HT; ++t)
+        for (int t = 0; t < HT; ++t) {
+          const f32x16 bt = bias_tile(b2 + 32 * t, hh);
 #pragma unroll
-              for (int r = 0; r < 16; ++r) { x1[t][r] *= fast_exp(acc[t][r]); ld += acc[t][r]; }
-          } else {
+          for (int r = 0; r < 16; ++r) acc[t][r] += bt[r];
+        }
+        const int mode = (a.inverse ? 2 : 0) + n;
+        if (mode == 0) {
 #pragma unroll
-            for (int t = 0; t < HT; ++t)
+          for (int t = 0; t < HT; ++t)
 #pragma unroll
-              for (int r = 0; r < 16; ++r) x1[t][r] = (x1[t][r] + acc[t][r]) * m;
-          }
+            for (int r = 0; r < 16; ++r) { x1[t][r] *= fast_exp(acc[t][r]); ld += acc[t][r]; }
+        } else if (mode == 1) {
+#pragma unroll
+          for (int t = 0; t < HT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x1[t][r] = (x1[t][r] + acc[t][r]) * m;
+        } else if (mode == 2) {
+#pragma unroll
+          for (int t = 0; t < HT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x1[t][r] -= acc[t][r];
         } else {
-          if (cur.n == 0) {
 #pragma unroll
-            for (int t = 0; t < HT; ++t)
+          for (int t = 0; t < HT; ++t)
 #pragma unroll
-              for (int r = 0; r < 16; ++r) x1[t][r] -= acc[t][r];
-          } else {
-#pragma unroll
-            for (int t = 0; t < HT; ++t)
-#pragma unroll
-              for (int r = 0; r < 16; ++r) { x1[t][r] = (x1[t][r] * fast_exp(-acc[t][r])) * m; ld -= acc[t][r]; }
-          }
+            for (int r = 0; r < 16; ++r) { x1[t][r] = (x1[t][r] * fast_exp(-acc[t][r])) * m; ld -= acc[t][r]; }
         }
       }
     }
-    cur.next(2, HC);
   }
 
   // outputs ------------------------------------------------------------------------------------------
@@ -624,27 +703,35 @@ __global__ void __launch_bounds__(512) k_stack_fwd(StackArgs a) {
 // one backward task of one net: given d(out) (accumulator tiles, rows = out features) recompute
 // hid / act', d hid = W2^T d(out), d pre = d hid * act', emit hid and d pre token-contiguous, and
 // accumulate dx0 += W1^T d pre.
-template <class P, typename T, int HT, int NKS>
-__device__ __forceinline__ void bwd_chunk(const char* buf, cfloat_t* b1c, int act, int lane, int hh,
+template <class P, int ACT, typename T, int HT, int NKS>
+__device__ __forceinline__ void bwd_chunk(const char* buf, const float* tail, int act, int lane, int hh,
                                           const typename P::BF (&x0f)[NKS], const f32x16 (&dout)[HT],
                                           f32x16 (&dx0)[HT], T* __restrict__ Gt, T* __restrict__ Ht,
                                           int64_t ld, int row0, int64_t col) {
   const typename P::AF* w1 = reinterpret_cast<const typename P::AF*>(buf) + lane;
-  f32x16 hid = preact<P, NKS>(w1, b1c, hh, x0f);
-  f32x16 dact;
-  act_tile_fd(act, hid, dact);
-  store_tile_t<T>(Ht, ld, row0, hh, col, hid);
+  typename P::AF f1[NKS], f2[HT * P::NS], f3[HT * P::NS];
+  load_frags<P, NKS>(w1, f1);
+  load_frags<P, HT * P::NS>(w1 + NKS * 64, f2);
+  load_frags<P, HT * P::NS>(w1 + (NKS + HT * P::NS) * 64, f3);
+  f32x16 hid = bias_tile(tail, hh);
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) hid = P::mma(f1[ks], x0f[ks], hid);
+  __builtin_amdgcn_sched_group_barrier(SG_DS_READ, NKS + 2 * HT * P::NS + 4, 0);
+  __builtin_amdgcn_sched_group_barrier(SG_MFMA, NKS, 0);
   f32x16 dh;
 #pragma unroll
   for (int r = 0; r < 16; ++r) dh[r] = 0.f;
-  ReduceFromAcc<P, HT, 0>::run(w1 + NKS * 64, dout, dh);
+  ReduceFromAcc<P, HT, 0>::run(f2, dout, dh);   // independent of the activation: overlaps its VALU work
+  f32x16 dact;
+  act_tile_fd<ACT, P::KS == 16>(act, hid, dact);
+  store_tile_t<T>(Ht, ld, row0, hh, col, hid);
 #pragma unroll
   for (int r = 0; r < 16; ++r) dh[r] *= dact[r];
   store_tile_t<T>(Gt, ld, row0, hh, col, dh);
-  AccumFromAcc<P, HT, 0>::run(w1 + (NKS + HT * P::NS) * 64, dh, dx0);
+  AccumFromAcc<P, HT, 0>::run(f3, dh, dx0);
 }
 
-template <class P, typename T, int HT, bool VEC, int LB>
+template <class P, typename T, int HT, bool VEC, int LB, int ACT>
 __global__ void __launch_bounds__(LB) k_stack_bwd(StackArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int hp = HT * 32;
@@ -721,85 +808,72 @@ __global__ void __launch_bounds__(LB) k_stack_bwd(StackArgs a) {
     for (int r = 0; r < 16; ++r) dx0[t][r] *= m;
 
   const int HC = g.HC;
-  const int ntasks = a.K * 3 * HC;
-  const int tbf = (int)g.tbf, tbb = (int)g.tbb;
-  cfloat_t* bias = (cfloat_t*)(a.packed + g.off_bias);
-  // LDS: [buf0 tbb][buf1 tbb][per-wave dt stash: HT tiles x 4 KiB]
-  float* stash = reinterpret_cast<float*>(smem + 2 * tbb) + (wave * HT * 64 + lane) * 16;
-  // per step (k descending): phase 0 = s-net forward tasks, phase 1 = s-net backward, phase 2 = t-net backward
-  auto region = [&](const TaskIt& it) -> const char* {
-    const int k = a.K - 1 - it.kk;
-    if (it.n == 0) return a.packed + ((int64_t)(k * 2) * HC + it.c) * tbf;
-    return a.packed + g.off_bwd + ((int64_t)(k * 2 + (it.n - 1)) * HC + it.c) * tbb;
-  };
-  TaskIt cur = {0, 0, 0}, nxt = {0, 0, 0};
-  stage_region(region(nxt), smem, tbf, wave, W, lane);
-  nxt.next(3, HC);
+  const int tbb = (int)g.tbb;
+  // LDS: [2 stream buffers of G * tbb][per-wave dt stash: HT tiles x 4 KiB]
+  Stream st;
+  st.init(a.packed + g.off_b, smem, tbb, a.G, a.K * 3 * HC, wave, W, lane, a.dbg & 1);
+  float* stash = reinterpret_cast<float*>(smem + 2 * a.G * tbb) + (wave * HT * 64 + lane) * 16;
   f32x16 dcur[HT];   // phase 0: s accumulators, then ds; phase 2: dt
-  for (int i = 0; i < ntasks; ++i) {
-    const int k = a.K - 1 - cur.kk;
-    f32x16 x1[HT];
-    const bool chain = active && cur.n == 0 && cur.c == HC - 1;
-    // ordinary vector loads go BEFORE the LDS-DMA issue so that their wait does not drain it
-    if (chain)
-      load_acc<T, VEC, HT>(reinterpret_cast<const T*>(a.x1_hist) + ((int64_t)k * a.N + tok) * h, valid, h, hh, x1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (i + 1 < ntasks) {
-      stage_region(region(nxt), smem + ((i + 1) & 1) * tbb, nxt.n == 0 ? tbf : tbb, wave, W, lane);
-      nxt.next(3, HC);
+  for (int k = a.K - 1; k >= 0; --k) {
+    // ---- phase 0: recompute s = s_net(x0)
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dcur[t][r] = 0.f;
+    const char* buf = nullptr;
+    for (int c = 0; c < HC; ++c) {
+      buf = st.next();
+      if (active) fwd_chunk<P, ACT, HT, NKS>(buf, reinterpret_cast<const float*>(buf + tbb - kTailBytes), a.act, lane, hh, x0f, dcur);
     }
+    T* dS = reinterpret_cast<T*>(a.dSt) + (int64_t)k * 2 * g.hp * ldn;
     if (active) {
-      const char* buf = smem + (i & 1) * tbb;
-      T* dS = reinterpret_cast<T*>(a.dSt) + (int64_t)k * 2 * g.hp * ldn;
-      if (cur.n == 0) {
-        cfloat_t* bb = bias + (int64_t)(k * 2) * (g.Hp + g.hp);
-        if (cur.c == 0) {
+      // ---- affine chain, reversed: x1 is the step's saved input half
+      const float* b2 = reinterpret_cast<const float*>(buf + tbb - kTailBytes) + 32;
+      f32x16 x1[HT];
+      load_acc<T, VEC, HT>(reinterpret_cast<const T*>(a.x1_hist) + ((int64_t)k * a.N + tok) * h, valid, h, hh, x1);
 #pragma unroll
-          for (int t = 0; t < HT; ++t) dcur[t] = bias_tile(bb + g.Hp + 32 * t, hh);
+      for (int t = 0; t < HT; ++t) {
+        const f32x16 bt = bias_tile(b2 + 32 * t, hh);
+        f32x16 dt;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool in = 32 * t + acc_row(r, hh) < h;
+          const float g1 = gx1[t][r] * m;
+          const float ge = g1 * fast_exp(dcur[t][r] + bt[r]);
+          dt[r] = g1;
+          dcur[t][r] = in ? ge * x1[t][r] + dl : 0.f;
+          gx1[t][r] = ge;
         }
-        fwd_chunk<P, HT, NKS>(buf, bb + 32 * cur.c, a.act, lane, hh, x0f, dcur);   // dcur = s
-        if (chain) {
+        store_tile_t<T>(dS, ldn, 32 * t, hh, tok, dcur[t]);
+        store_tile_t<T>(dS + (int64_t)g.hp * ldn, ldn, 32 * t, hh, tok, dt);
 #pragma unroll
-          for (int t = 0; t < HT; ++t) {
-            f32x16 dt;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const bool in = 32 * t + acc_row(r, hh) < h;
-              const float g1 = gx1[t][r] * m;
-              const float ge = g1 * fast_exp(dcur[t][r]);
-              dt[r] = g1;
-              dcur[t][r] = in ? ge * x1[t][r] + dl : 0.f;
-              gx1[t][r] = ge;
-            }
-            store_tile_t<T>(dS, ldn, 32 * t, hh, tok, dcur[t]);
-            store_tile_t<T>(dS + (int64_t)g.hp * ldn, ldn, 32 * t, hh, tok, dt);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              f32x4 v = {dt[4 * q], dt[4 * q + 1], dt[4 * q + 2], dt[4 * q + 3]};
-              *reinterpret_cast<f32x4*>(stash + t * 1024 + 4 * q) = v;
-            }
-          }
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v = {dt[4 * q], dt[4 * q + 1], dt[4 * q + 2], dt[4 * q + 3]};
+          *reinterpret_cast<f32x4*>(stash + t * 1024 + 4 * q) = v;
         }
-      } else {
-        const int net = cur.n - 1;
-        cfloat_t* bb = bias + (int64_t)(k * 2 + net) * (g.Hp + g.hp);
-        if (net == 1 && cur.c == 0) {
-#pragma unroll
-          for (int t = 0; t < HT; ++t)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              f32x4 v = *reinterpret_cast<const f32x4*>(stash + t * 1024 + 4 * q);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) dcur[t][4 * q + e] = v[e];
-            }
-        }
-        T* Gt = reinterpret_cast<T*>(a.Gt) + (int64_t)(k * 2 + net) * g.Hp * ldn;
-        T* Ht = reinterpret_cast<T*>(a.Ht) + (int64_t)(k * 2 + net) * g.Hp * ldn;
-        bwd_chunk<P, T, HT, NKS>(buf, bb + 32 * cur.c, a.act, lane, hh, x0f, dcur, dx0, Gt, Ht, ldn, 32 * cur.c, tok);
       }
     }
-    cur.next(3, HC);
+    // ---- phases 1, 2: s-net then t-net backward
+    for (int net = 0; net < 2; ++net) {
+      if (active && net == 1) {
+#pragma unroll
+        for (int t = 0; t < HT; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(stash + t * 1024 + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dcur[t][4 * q + e] = v[e];
+          }
+      }
+      T* Gt = reinterpret_cast<T*>(a.Gt) + (int64_t)(k * 2 + net) * g.Hp * ldn;
+      T* Ht = reinterpret_cast<T*>(a.Ht) + (int64_t)(k * 2 + net) * g.Hp * ldn;
+      for (int c = 0; c < HC; ++c) {
+        buf = st.next();
+        if (active)
+          bwd_chunk<P, ACT, T, HT, NKS>(buf, reinterpret_cast<const float*>(buf + tbb - kTailBytes), a.act, lane, hh,
+                                        x0f, dcur, dx0, Gt, Ht, ldn, 32 * c, tok);
+      }
+    }
   }
   T* drow = reinterpret_cast<T*>(a.dz_in) + tok * a.D;
   store_acc<T, VEC, HT>(drow, valid, h, hh, dx0);
@@ -939,34 +1013,36 @@ __global__ void k_dw_reduce(DwArgs a) {
 }
 
 // ---- host dispatch -----------------------------------------------------------------------------------
-template <class P, typename T, int HT>
+template <class P, typename T, int HT, int ACT>
 int launch_stack(bool bwd, bool vec, const StackArgs& a, unsigned grid, unsigned block, size_t lds, hipStream_t st) {
   // dynamic LDS above 64 KiB has to be opted into per kernel
   auto big = [&](const void* fn) {
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   };
   if (bwd) {
-    constexpr int LB = HT <= 2 ? 512 : 256;
-    if (vec) { big((const void*)k_stack_bwd<P, T, HT, true, LB>); k_stack_bwd<P, T, HT, true, LB><<<grid, block, lds, st>>>(a); }
-    else { big((const void*)k_stack_bwd<P, T, HT, false, LB>); k_stack_bwd<P, T, HT, false, LB><<<grid, block, lds, st>>>(a); }
+    constexpr int LB = HT <= 1 ? 512 : 256;
+    if (vec) { big((const void*)k_stack_bwd<P, T, HT, true, LB, ACT>); k_stack_bwd<P, T, HT, true, LB, ACT><<<grid, block, lds, st>>>(a); }
+    else { big((const void*)k_stack_bwd<P, T, HT, false, LB, ACT>); k_stack_bwd<P, T, HT, false, LB, ACT><<<grid, block, lds, st>>>(a); }
   } else {
-    if (vec) { big((const void*)k_stack_fwd<P, T, HT, true>); k_stack_fwd<P, T, HT, true><<<grid, block, lds, st>>>(a); }
-    else { big((const void*)k_stack_fwd<P, T, HT, false>); k_stack_fwd<P, T, HT, false><<<grid, block, lds, st>>>(a); }
+    constexpr int LB = HT <= 2 ? 512 : 256;
+    if (vec) { big((const void*)k_stack_fwd<P, T, HT, true, LB, ACT>); k_stack_fwd<P, T, HT, true, LB, ACT><<<grid, block, lds, st>>>(a); }
+    else { big((const void*)k_stack_fwd<P, T, HT, false, LB, ACT>); k_stack_fwd<P, T, HT, false, LB, ACT><<<grid, block, lds, st>>>(a); }
   }
   return 0;
 }
-template <class P, typename T>
+template <class P, typename T, int ACT>
 int launch_ht(int HT, bool bwd, bool vec, const StackArgs& a, unsigned grid, unsigned block, size_t lds, hipStream_t st) {
   switch (HT) {
-    case 1: return launch_stack<P, T, 1>(bwd, vec, a, grid, block, lds, st);
-    case 2: return launch_stack<P, T, 2>(bwd, vec, a, grid, block, lds, st);
-    case 3: return launch_stack<P, T, 3>(bwd, vec, a, grid, block, lds, st);
-    case 4: return launch_stack<P, T, 4>(bwd, vec, a, grid, block, lds, st);
+    case 1: return launch_stack<P, T, 1, ACT>(bwd, vec, a, grid, block, lds, st);
+    case 2: return launch_stack<P, T, 2, ACT>(bwd, vec, a, grid, block, lds, st);
+    case 3: return launch_stack<P, T, 3, ACT>(bwd, vec, a, grid, block, lds, st);
+    case 4: return launch_stack<P, T, 4, ACT>(bwd, vec, a, grid, block, lds, st);
   }
   return -1;
 }
 
 constexpr size_t kLdsLimit = 160 * 1024;
+constexpr int64_t kStageBufBytes = 40 * 1024;   // per LDS stream buffer (two of them)
 
 static int run_stack(const char* name, bool bwd, StackArgs a, int64_t Bn, int h, int H, int dtype,
                      int act, hipStream_t st) {
@@ -976,6 +1052,7 @@ static int run_stack(const char* name, bool bwd, StackArgs a, int64_t Bn, int h,
   MIVAE_REQUIRE(h >= 1 && H >= 1 && a.D == 2 * h, "%s: D must be 2*h (D=%d h=%d)", name, a.D, h);
   MIVAE_REQUIRE(a.S >= 1 && a.mask_div >= 1 && Bn >= 0, "%s: bad shape", name);
   a.act = act;
+  { const char* e = getenv("MIVAE_DBG"); a.dbg = e ? atoi(e) : 0; }
   a.g = make_geom(h, H, a.K, dtype == MIVAE_BF16);
   if (a.g.HT > 4) {
     mivae_set_error("%s: fused path supports D <= 256 (got D=%d); use the composed path", name, a.D);
@@ -992,21 +1069,33 @@ static int run_stack(const char* name, bool bwd, StackArgs a, int64_t Bn, int h,
   if (bwd) vec = vec && aligned16(a.dz_in) && (a.dz_out == nullptr || aligned16(a.dz_out));
   const int64_t ntok = bwd ? a.Npad : a.N;
   const int64_t ntiles = (ntok + 31) / 32;
+  const int64_t tb = bwd ? a.g.tbb : a.g.tbf;
+  const int64_t ntasks = (int64_t)a.K * (bwd ? 3 : 2) * a.g.HC;
+  // tasks per staged block: as many as fit one stream buffer (fewer barriers, deeper prefetch)
+  int64_t G = kStageBufBytes / tb;
+  if (G < 1) G = 1;
+  if (G > ntasks) G = ntasks;
+  a.G = (int)G;
   // waves per block: keep >= 256 blocks (one per CU) before growing the block; W waves share each
-  // staged weight region, so larger W cuts L2 -> LDS traffic per token.
+  // staged weight block, so larger W cuts L2 -> LDS traffic per token.
   int W = 1;
-  const int wmax = (bwd && a.g.HT > 2) ? 4 : 8;
+  const int wmax = (bwd ? a.g.HT > 1 : a.g.HT > 2) ? 4 : 8;   // must match the kernels' launch bounds
   while (W < wmax && ntiles / (2 * W) >= 256) W *= 2;
   auto lds_need = [&](int w) -> size_t {
-    return bwd ? 2 * (size_t)a.g.tbb + (size_t)w * a.g.HT * 4096 : 2 * (size_t)a.g.tbf;
+    return 2 * (size_t)(G * tb) + (bwd ? (size_t)w * a.g.HT * 4096 : 0);
   };
   while (W > 1 && lds_need(W) > kLdsLimit) W /= 2;
   MIVAE_REQUIRE(lds_need(W) <= kLdsLimit, "%s: task region too large for LDS (h=%d)", name, h);
   const unsigned grid = (unsigned)((ntiles + W - 1) / W);
   const size_t lds = lds_need(W);
   int rc;
-  if (dtype == MIVAE_F32) rc = launch_ht<MmaF32, float>(a.g.HT, bwd, vec, a, grid, W * 64, lds, st);
-  else rc = launch_ht<MmaBF16, unsigned short>(a.g.HT, bwd, vec, a, grid, W * 64, lds, st);
+  if (act == ACT_GELU) {
+    if (dtype == MIVAE_F32) rc = launch_ht<MmaF32, float, ACT_GELU>(a.g.HT, bwd, vec, a, grid, W * 64, lds, st);
+    else rc = launch_ht<MmaBF16, unsigned short, ACT_GELU>(a.g.HT, bwd, vec, a, grid, W * 64, lds, st);
+  } else {
+    if (dtype == MIVAE_F32) rc = launch_ht<MmaF32, float, -1>(a.g.HT, bwd, vec, a, grid, W * 64, lds, st);
+    else rc = launch_ht<MmaBF16, unsigned short, -1>(a.g.HT, bwd, vec, a, grid, W * 64, lds, st);
+  }
   MIVAE_REQUIRE(rc == 0, "%s: no kernel instance for HT=%d", name, a.g.HT);
   MIVAE_CHECK_LAUNCH(name);
   return MIVAE_OK;
@@ -1045,16 +1134,15 @@ extern "C" int64_t mivae_nice_pack_bytes(int64_t h, int64_t H, int dtype) {
 }
 
 extern "C" int mivae_nice_pack(const int64_t* ptr_table, void* packed, int64_t K, int64_t h, int64_t H,
-                               int dtype, void* stream) {
+                               int dtype, int inverse, void* stream) {
   MIVAE_REQUIRE(ptr_table && packed, "nice_pack: null pointer");
   MIVAE_REQUIRE(K >= 1 && K <= 4096 && h >= 1 && H >= 1, "nice_pack: bad shape K=%ld h=%ld H=%ld", (long)K, (long)h, (long)H);
   MIVAE_REQUIRE(dtype == MIVAE_F32 || dtype == MIVAE_BF16, "nice_pack: bad dtype %d", dtype);
   Geom g = make_geom((int)h, (int)H, (int)K, dtype == MIVAE_BF16);
-  const int htns = g.HT * g.ns;
-  const int64_t total = (int64_t)g.HC * (2 * g.nks + 3 * htns) * g.fe + g.Hp + g.hp;
-  dim3 grid((unsigned)((total + 255) / 256), 2, (unsigned)K);
-  if (dtype == MIVAE_BF16) k_nice_pack<MmaBF16><<<grid, 256, 0, (hipStream_t)stream>>>(ptr_table, (char*)packed, g);
-  else k_nice_pack<MmaF32><<<grid, 256, 0, (hipStream_t)stream>>>(ptr_table, (char*)packed, g);
+  const int64_t total = 2 * g.HC * (g.nfe_f + 256) + 3 * g.HC * (g.nfe_b + 256);
+  dim3 grid((unsigned)((total + 255) / 256), 1, (unsigned)K);
+  if (dtype == MIVAE_BF16) k_nice_pack<MmaBF16><<<grid, 256, 0, (hipStream_t)stream>>>(ptr_table, (char*)packed, g, inverse);
+  else k_nice_pack<MmaF32><<<grid, 256, 0, (hipStream_t)stream>>>(ptr_table, (char*)packed, g, inverse);
   MIVAE_CHECK_LAUNCH("nice_pack");
   return MIVAE_OK;
 }

@@ -376,7 +376,7 @@ def _ptr_table(params: Sequence[torch.Tensor], device) -> torch.Tensor:
     return tab
 
 
-def nice_pack(params: Sequence[torch.Tensor], K: int, h: int, H: int, dtype) -> torch.Tensor:
+def nice_pack(params: Sequence[torch.Tensor], K: int, h: int, H: int, dtype, inverse: bool = False) -> torch.Tensor:
     """Repack K x {W1s,b1s,W2s,b2s,W1t,b1t,W2t,b2t} (fp32 nn.Linear layout) into MFMA fragment order."""
     dev = params[0].device
     for p in params:
@@ -385,7 +385,7 @@ def nice_pack(params: Sequence[torch.Tensor], K: int, h: int, H: int, dtype) -> 
     code = L.dtype_code(dtype)
     nbytes = L.query("mivae_nice_pack_bytes", h, H, code)
     packed = torch.empty(K * nbytes, dtype=torch.uint8, device=dev)
-    L.call("mivae_nice_pack", L.ptr(_ptr_table(params, dev)), L.ptr(packed), K, h, H, code, L.stream())
+    L.call("mivae_nice_pack", L.ptr(_ptr_table(params, dev)), L.ptr(packed), K, h, H, code, int(inverse), L.stream())
     return packed
 
 
@@ -399,7 +399,7 @@ class _NiceStack(torch.autograd.Function):
         K = len(params) // 8
         z = z.contiguous()
         code = L.dtype_code(z.dtype)
-        packed = nice_pack(params, K, h, H, z.dtype)
+        packed = nice_pack(params, K, h, H, z.dtype, inverse)
         need_grad = (not inverse) and any(ctx.needs_input_grad)
         N = Bn * S
         z_out = torch.empty_like(z)

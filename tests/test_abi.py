@@ -58,7 +58,7 @@ def test_argument_validation_without_gpu(pkg):
     assert lib.mivae_reparam_logq_fwd(None, None, None, None, None, None, 2, 1, 3, 4, 7, None) == -1
     assert b"dtype" in lib.mivae_last_error()
     assert lib.mivae_nice_pack_bytes(32, 64, 1) > 0 and lib.mivae_nice_pack_bytes(0, 64, 1) == 0
-    assert lib.mivae_nice_stack_npad(33) == 64
+    assert lib.mivae_nice_stack_npad(33) == 64 and lib.mivae_nice_stack_npad(64) == 64
 
 
 def test_product_path_refuses_cpu_tensors(pkg):
