@@ -300,22 +300,27 @@ __device__ __forceinline__ void store_acc(T* __restrict__ row, bool valid, int h
     }
 }
 
-// transposed ([feature row][token]) store of one accumulator tile: row = row0 + acc_row(r, hh)
+// transposed ([feature row][token]) store of one accumulator tile: row = row0 + acc_row(r, hh).
+// `base`, `ld`, `row0` are wave-uniform, so every store is (scalar row pointer) + one 32-bit per-lane
+// offset `loff` = 4 * hh * ld + token (computed once per kernel): no per-store 64-bit VALU address
+// arithmetic and no hoisted address registers.
 template <typename T>
-__device__ __forceinline__ void store_tile_t(T* __restrict__ base, int64_t ld, int row0, int hh,
-                                             int64_t col, const f32x16& x) {
+__device__ __forceinline__ void store_tile_t(T* __restrict__ base, int64_t ld, int row0, unsigned loff,
+                                             const f32x16& x) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
+    T* rowp = base + (int64_t)(row0 + (r & 3) + 8 * (r >> 2)) * ld;
     float t1[1] = {x[r]};
-    RowIO<T, 1>::store(base + (int64_t)(row0 + acc_row(r, hh)) * ld + col, t1);
+    RowIO<T, 1>::store(rowp + loff, t1);
   }
 }
 
 // ---- packed weight streams -------------------------------------------------------------------------
 // The packed image is two linear streams of equally sized "task" regions laid out in exactly the
 // order the kernels consume them, so staging is a pure sequential copy:
-//   F stream (forward, or inverse when packed with inverse = 1): task (kk, n, c), n = net order within
-//     the step, c = 32-wide hidden chunk:  [W1n: NKS frags][W2p: HT*NS frags][tail]          (tbf bytes)
+//   F stream (forward; steps reversed when packed with inverse = 1): task (kk, c, net), c = 32-wide hidden
+//     chunk, net 0 = s, 1 = t (a pair per iteration: the s and t nets run on sibling waves):
+//     [W1n: NKS frags][W2p: HT*NS frags][tail]                                                  (tbf bytes)
 //   B stream (backward, steps K-1 .. 0): task (kk, phase, c); phase 0 = s-net forward recompute
 //     ([W1n][W2p][pad]), phase 1 / 2 = s / t net backward ([W1n][W2Tp][W1Tp]); + [tail]       (tbb bytes)
 //   tail (1 KiB): b1[32c .. 32c+31] (32 floats) | b2[0 .. hp) -- biases travel with the weights.
@@ -360,12 +365,11 @@ __global__ void k_nice_pack(const int64_t* __restrict__ ptrs, char* __restrict__
   if (idx < 2 * g.HC * slots_f) {
     const int tq = (int)(idx / slots_f);
     slot = idx % slots_f;
-    const int n = tq / g.HC;
-    c = tq % g.HC;
+    c = tq / 2;
+    net = tq % 2;
     k = inverse ? g.K - 1 - kk : kk;
-    net = inverse ? 1 - n : n;
     content = 0; nfe = g.nfe_f;
-    base = packed + ((int64_t)(kk * 2 + n) * g.HC + c) * g.tbf;
+    base = packed + ((int64_t)(kk * g.HC + c) * 2 + net) * g.tbf;
   } else {
     idx -= 2 * g.HC * slots_f;
     const int tq = (int)(idx / slots_b);
@@ -500,6 +504,29 @@ __device__ __forceinline__ f32x16 bias_tile(const float* B, int hh) {
   return a;
 }
 
+// accumulator tiles <-> per-wave private LDS area (64 B per lane per tile, lane-linear)
+template <int HT>
+__device__ __forceinline__ void stash_put(float* st, const f32x16 (&x)[HT]) {
+#pragma unroll
+  for (int t = 0; t < HT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v = {x[t][4 * q], x[t][4 * q + 1], x[t][4 * q + 2], x[t][4 * q + 3]};
+      *reinterpret_cast<f32x4*>(st + t * 1024 + q * 256) = v;
+    }
+}
+template <int HT>
+__device__ __forceinline__ void stash_get(const float* st, f32x16 (&x)[HT]) {
+#pragma unroll
+  for (int t = 0; t < HT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(st + t * 1024 + q * 256);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[t][4 * q + e] = v[e];
+    }
+}
+
 // LLVM SchedGroupMask bits for __builtin_amdgcn_sched_group_barrier
 #define SG_MFMA 0x008
 #define SG_DS_READ 0x100
@@ -543,15 +570,43 @@ __device__ __forceinline__ void fwd_chunk(const char* buf, const float* tail, in
                                           const typename P::BF (&x0f)[NKS], f32x16 (&acc)[HT]) {
   const typename P::AF* w1 = reinterpret_cast<const typename P::AF*>(buf) + lane;
   typename P::AF f1[NKS], f2[HT * P::NS];
+  f32x16 a = bias_tile(tail, hh);
   load_frags<P, NKS>(w1, f1);
   load_frags<P, HT * P::NS>(w1 + NKS * 64, f2);
-  f32x16 a = bias_tile(tail, hh);
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) a = P::mma(f1[ks], x0f[ks], a);
+  // issue order: every LDS read first (bias, W1 frags, W2 frags -- LDS returns in order, so the first
+  // MFMA only waits for its own operands), then the first-layer MFMA chain
   __builtin_amdgcn_sched_group_barrier(SG_DS_READ, NKS + HT * P::NS + 4, 0);
   __builtin_amdgcn_sched_group_barrier(SG_MFMA, NKS, 0);
   act_tile<ACT, P::KS == 16>(act, a);
   AccumFromAcc<P, HT, 0>::run(f2, a, acc);
+}
+
+// fold one net's output (acc + b2) into the parked x1 tiles; returns the lane's sum of s
+//   MODE 0: x1 *= exp(s)        MODE 1: x1 = (x1 + t) * m        (forward,  couplings.py:151-160)
+//   MODE 2: x1 -= t             MODE 3: x1 = x1 * exp(-s) * m    (inverse,  couplings.py:172-181)
+template <int MODE, int HT>
+__device__ __forceinline__ float fold_tiles(float* stash, const float* b2, int hh, float m, const f32x16 (&acc)[HT]) {
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < HT; ++t) {
+    const f32x16 bt = bias_tile(b2 + 32 * t, hh);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 x = *reinterpret_cast<const f32x4*>(stash + t * 1024 + q * 256);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = acc[t][4 * q + e] + bt[4 * q + e];
+        if constexpr (MODE == 0) { x[e] *= fast_exp(v); sum += v; }
+        else if constexpr (MODE == 1) x[e] = (x[e] + v) * m;
+        else if constexpr (MODE == 2) x[e] -= v;
+        else { x[e] = (x[e] * fast_exp(-v)) * m; sum += v; }
+      }
+      *reinterpret_cast<f32x4*>(stash + t * 1024 + q * 256) = x;
+    }
+  }
+  return sum;
 }
 
 template <typename T, bool VEC, int NKS, class P>
@@ -560,6 +615,10 @@ __device__ __forceinline__ void load_x0(const T* zrow, bool ok, int h, int hh, t
   else load_x0_bf16<T, VEC, NKS>(zrow, ok, h, hh, x0f);
 }
 
+// Forward / inverse kernel.  A block is Wt token tiles x 2 roles: for every 32-token tile, wave role 0
+// runs the s-net and wave role 1 the t-net of each step concurrently (they only depend on x0); x1 lives
+// in a per-tile LDS area that the two roles update in turn (exp(s) scaling, then + t; reversed for
+// the inverse), so the tile offers two independent instruction streams to its SIMD.
 template <class P, typename T, int HT, bool VEC, int LB, int ACT>
 __global__ void __launch_bounds__(LB) k_stack_fwd(StackArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -569,9 +628,10 @@ __global__ void __launch_bounds__(LB) k_stack_fwd(StackArgs a) {
   const int r32 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int W = blockDim.x >> 6;
+  const int tile = wave >> 1, role = wave & 1;
   const Geom& g = a.g;
   const int h = g.h;
-  const int64_t tok = ((int64_t)blockIdx.x * W + wave) * 32 + r32;
+  const int64_t tok = ((int64_t)blockIdx.x * (W >> 1) + tile) * 32 + r32;
   const bool valid = tok < a.N;
   float m = 0.f;
   if (valid) {
@@ -588,64 +648,64 @@ __global__ void __launch_bounds__(LB) k_stack_fwd(StackArgs a) {
   // anyway (couplings.py:159-161), and zeros keep exp() finite at padding positions.
   typename P::BF x0f[NKS];
   load_x0<T, VEC, NKS, P>(zrow, valid && m != 0.f, h, hh, x0f);
-  f32x16 x1[HT];
-  load_acc<T, VEC, HT>(zrow + h, valid && m != 0.f, h, hh, x1);
   float ld = 0.f;
 
   const int HC = g.HC;
   const int tbf = (int)g.tbf;
   Stream st;
-  st.init(a.packed, smem, tbf, a.G, a.K * 2 * HC, wave, W, lane, a.dbg & 1);
-  f32x16 acc[HT];
-  for (int kk = 0; kk < a.K; ++kk) {
-    const int k = a.inverse ? a.K - 1 - kk : kk;
-    if (live && a.x1_hist)
-      store_acc<T, VEC, HT>(reinterpret_cast<T*>(a.x1_hist) + ((int64_t)k * a.N + tok) * h, valid, h, hh, x1);
-    for (int n = 0; n < 2; ++n) {
+  st.init(a.packed, smem, 2 * tbf, a.G, a.K * HC, wave, W, lane, a.dbg & 1);
+  // x1 (the half the steps transform) is parked in a per-tile LDS area shared by the two roles
+  float* stash = reinterpret_cast<float*>(smem + 2 * a.G * 2 * tbf) + tile * HT * 1024 + lane * 4;
+  if (role == 0) {
+    f32x16 x1[HT];
+    load_acc<T, VEC, HT>(zrow + h, valid && m != 0.f, h, hh, x1);
+    stash_put<HT>(stash, x1);
+  }
+  __syncthreads();
+  if (!live) {
+    // dead tile: keep the block's barrier / staging cadence, no arithmetic
+    for (int kk = 0; kk < a.K; ++kk) {
+      for (int c = 0; c < HC; ++c) (void)st.next();
+      __syncthreads();
+      __syncthreads();
+    }
+  } else {
+    f32x16 acc[HT];
+    for (int kk = 0; kk < a.K; ++kk) {
+      const int k = a.inverse ? a.K - 1 - kk : kk;
+      if (a.x1_hist && role == 0) {
+        f32x16 x1[HT];
+        stash_get<HT>(stash, x1);
+        store_acc<T, VEC, HT>(reinterpret_cast<T*>(a.x1_hist) + ((int64_t)k * a.N + tok) * h, valid, h, hh, x1);
+      }
 #pragma unroll
       for (int t = 0; t < HT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
       const char* buf = nullptr;
+#pragma unroll 1
       for (int c = 0; c < HC; ++c) {
-        buf = st.next();
-        if (live) fwd_chunk<P, ACT, HT, NKS>(buf, reinterpret_cast<const float*>(buf + tbf - kTailBytes), a.act, lane, hh, x0f, acc);
+        buf = st.next() + role * tbf;
+        fwd_chunk<P, ACT, HT, NKS>(buf, reinterpret_cast<const float*>(buf + tbf - kTailBytes), a.act, lane, hh, x0f, acc);
       }
-      if (live) {
-        // the two nets run back to back and are folded into x1 immediately
-        // (forward: x1 = exp(s) x1, then + t; inverse: x1 - t first, then * exp(-s)); b2 joins here
-        const float* b2 = reinterpret_cast<const float*>(buf + tbf - kTailBytes) + 32;
-#pragma unroll
-        for (int t = 0; t < HT; ++t) {
-          const f32x16 bt = bias_tile(b2 + 32 * t, hh);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[t][r] += bt[r];
-        }
-        const int mode = (a.inverse ? 2 : 0) + n;
-        if (mode == 0) {
-#pragma unroll
-          for (int t = 0; t < HT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { x1[t][r] *= fast_exp(acc[t][r]); ld += acc[t][r]; }
-        } else if (mode == 1) {
-#pragma unroll
-          for (int t = 0; t < HT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) x1[t][r] = (x1[t][r] + acc[t][r]) * m;
-        } else if (mode == 2) {
-#pragma unroll
-          for (int t = 0; t < HT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) x1[t][r] -= acc[t][r];
-        } else {
-#pragma unroll
-          for (int t = 0; t < HT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { x1[t][r] = (x1[t][r] * fast_exp(-acc[t][r])) * m; ld -= acc[t][r]; }
-        }
+      // fold the nets' outputs (+ b2) into x1: forward x1 = (exp(s) x1 + t) m, inverse x1 = (x1 - t) exp(-s) m
+      const float* b2 = reinterpret_cast<const float*>(buf + tbf - kTailBytes) + 32;
+      if (!a.inverse) {
+        if (role == 0) ld += fold_tiles<0, HT>(stash, b2, hh, m, acc);
+        __syncthreads();
+        if (role == 1) fold_tiles<1, HT>(stash, b2, hh, m, acc);
+        __syncthreads();
+      } else {
+        if (role == 1) fold_tiles<2, HT>(stash, b2, hh, m, acc);
+        __syncthreads();
+        if (role == 0) ld -= fold_tiles<3, HT>(stash, b2, hh, m, acc);
+        __syncthreads();
       }
     }
   }
+  if (role != 0) return;   // role 0 owns the tile's outputs (no barriers below)
+  f32x16 x1[HT];
+  stash_get<HT>(stash, x1);
 
   // outputs ------------------------------------------------------------------------------------------
   T* orow = reinterpret_cast<T*>(a.z_out) + tok * a.D;
@@ -707,7 +767,7 @@ template <class P, int ACT, typename T, int HT, int NKS>
 __device__ __forceinline__ void bwd_chunk(const char* buf, const float* tail, int act, int lane, int hh,
                                           const typename P::BF (&x0f)[NKS], const f32x16 (&dout)[HT],
                                           f32x16 (&dx0)[HT], T* __restrict__ Gt, T* __restrict__ Ht,
-                                          int64_t ld, int row0, int64_t col) {
+                                          int64_t ld, int row0, unsigned loff) {
   const typename P::AF* w1 = reinterpret_cast<const typename P::AF*>(buf) + lane;
   typename P::AF f1[NKS], f2[HT * P::NS], f3[HT * P::NS];
   load_frags<P, NKS>(w1, f1);
@@ -724,10 +784,10 @@ __device__ __forceinline__ void bwd_chunk(const char* buf, const float* tail, in
   ReduceFromAcc<P, HT, 0>::run(f2, dout, dh);   // independent of the activation: overlaps its VALU work
   f32x16 dact;
   act_tile_fd<ACT, P::KS == 16>(act, hid, dact);
-  store_tile_t<T>(Ht, ld, row0, hh, col, hid);
+  store_tile_t<T>(Ht, ld, row0, loff, hid);
 #pragma unroll
   for (int r = 0; r < 16; ++r) dh[r] *= dact[r];
-  store_tile_t<T>(Gt, ld, row0, hh, col, dh);
+  store_tile_t<T>(Gt, ld, row0, loff, dh);
   AccumFromAcc<P, HT, 0>::run(f3, dh, dx0);
 }
 
@@ -758,6 +818,7 @@ __global__ void __launch_bounds__(LB) k_stack_bwd(StackArgs a) {
   typename P::BF x0f[NKS];
   load_x0<T, VEC, NKS, P>(zrow, valid && m != 0.f, h, hh, x0f);
   const int64_t ldn = a.Npad;
+  const unsigned loff = (unsigned)(4 * hh * ldn + tok);
   if (active) {  // x0^T for the dW1 products
     T* xt = reinterpret_cast<T*>(a.x0t);
 #pragma unroll
@@ -812,66 +873,64 @@ __global__ void __launch_bounds__(LB) k_stack_bwd(StackArgs a) {
   // LDS: [2 stream buffers of G * tbb][per-wave dt stash: HT tiles x 4 KiB]
   Stream st;
   st.init(a.packed + g.off_b, smem, tbb, a.G, a.K * 3 * HC, wave, W, lane, a.dbg & 1);
-  float* stash = reinterpret_cast<float*>(smem + 2 * a.G * tbb) + (wave * HT * 64 + lane) * 16;
-  f32x16 dcur[HT];   // phase 0: s accumulators, then ds; phase 2: dt
-  for (int k = a.K - 1; k >= 0; --k) {
-    // ---- phase 0: recompute s = s_net(x0)
+  float* stash = reinterpret_cast<float*>(smem + 2 * a.G * tbb) + wave * HT * 1024 + lane * 4;
+  if (!active) {
+    // tile past the padded token range: keep the block's barrier / staging cadence only
+    for (int i = a.K * 3 * HC; i > 0; --i) (void)st.next();
+  } else {
+    f32x16 dcur[HT];   // phase 0: s accumulators, then ds; phase 2: dt
+    for (int k = a.K - 1; k >= 0; --k) {
+      // ---- phase 0: recompute s = s_net(x0)
 #pragma unroll
-    for (int t = 0; t < HT; ++t)
+      for (int t = 0; t < HT; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dcur[t][r] = 0.f;
-    const char* buf = nullptr;
-    for (int c = 0; c < HC; ++c) {
-      buf = st.next();
-      if (active) fwd_chunk<P, ACT, HT, NKS>(buf, reinterpret_cast<const float*>(buf + tbb - kTailBytes), a.act, lane, hh, x0f, dcur);
-    }
-    T* dS = reinterpret_cast<T*>(a.dSt) + (int64_t)k * 2 * g.hp * ldn;
-    if (active) {
-      // ---- affine chain, reversed: x1 is the step's saved input half
-      const float* b2 = reinterpret_cast<const float*>(buf + tbb - kTailBytes) + 32;
-      f32x16 x1[HT];
-      load_acc<T, VEC, HT>(reinterpret_cast<const T*>(a.x1_hist) + ((int64_t)k * a.N + tok) * h, valid, h, hh, x1);
-#pragma unroll
-      for (int t = 0; t < HT; ++t) {
-        const f32x16 bt = bias_tile(b2 + 32 * t, hh);
-        f32x16 dt;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const bool in = 32 * t + acc_row(r, hh) < h;
-          const float g1 = gx1[t][r] * m;
-          const float ge = g1 * fast_exp(dcur[t][r] + bt[r]);
-          dt[r] = g1;
-          dcur[t][r] = in ? ge * x1[t][r] + dl : 0.f;
-          gx1[t][r] = ge;
-        }
-        store_tile_t<T>(dS, ldn, 32 * t, hh, tok, dcur[t]);
-        store_tile_t<T>(dS + (int64_t)g.hp * ldn, ldn, 32 * t, hh, tok, dt);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          f32x4 v = {dt[4 * q], dt[4 * q + 1], dt[4 * q + 2], dt[4 * q + 3]};
-          *reinterpret_cast<f32x4*>(stash + t * 1024 + 4 * q) = v;
-        }
-      }
-    }
-    // ---- phases 1, 2: s-net then t-net backward
-    for (int net = 0; net < 2; ++net) {
-      if (active && net == 1) {
-#pragma unroll
-        for (int t = 0; t < HT; ++t)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(stash + t * 1024 + 4 * q);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) dcur[t][4 * q + e] = v[e];
-          }
-      }
-      T* Gt = reinterpret_cast<T*>(a.Gt) + (int64_t)(k * 2 + net) * g.Hp * ldn;
-      T* Ht = reinterpret_cast<T*>(a.Ht) + (int64_t)(k * 2 + net) * g.Hp * ldn;
+        for (int r = 0; r < 16; ++r) dcur[t][r] = 0.f;
+      const char* buf = nullptr;
+#pragma unroll 1
       for (int c = 0; c < HC; ++c) {
         buf = st.next();
-        if (active)
+        fwd_chunk<P, ACT, HT, NKS>(buf, reinterpret_cast<const float*>(buf + tbb - kTailBytes), a.act, lane, hh, x0f, dcur);
+      }
+      T* dS = reinterpret_cast<T*>(a.dSt) + (int64_t)k * 2 * g.hp * ldn;
+      {
+        // ---- affine chain, reversed: x1 is the step's saved input half
+        const float* b2 = reinterpret_cast<const float*>(buf + tbb - kTailBytes) + 32;
+        f32x16 x1[HT];
+        load_acc<T, VEC, HT>(reinterpret_cast<const T*>(a.x1_hist) + ((int64_t)k * a.N + tok) * h, valid, h, hh, x1);
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+          const f32x16 bt = bias_tile(b2 + 32 * t, hh);
+          f32x16 dt;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const bool in = 32 * t + acc_row(r, hh) < h;
+            const float g1 = gx1[t][r] * m;
+            const float ge = g1 * fast_exp(dcur[t][r] + bt[r]);
+            dt[r] = g1;
+            dcur[t][r] = in ? ge * x1[t][r] + dl : 0.f;
+            gx1[t][r] = ge;
+          }
+          store_tile_t<T>(dS, ldn, 32 * t, loff, dcur[t]);
+          store_tile_t<T>(dS + (int64_t)g.hp * ldn, ldn, 32 * t, loff, dt);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x4 v = {dt[4 * q], dt[4 * q + 1], dt[4 * q + 2], dt[4 * q + 3]};
+            *reinterpret_cast<f32x4*>(stash + t * 1024 + q * 256) = v;
+          }
+        }
+      }
+      // ---- phases 1, 2: s-net then t-net backward
+#pragma unroll 1
+      for (int net = 0; net < 2; ++net) {
+        if (net == 1) stash_get<HT>(stash, dcur);
+        T* Gt = reinterpret_cast<T*>(a.Gt) + (int64_t)(k * 2 + net) * g.Hp * ldn;
+        T* Ht = reinterpret_cast<T*>(a.Ht) + (int64_t)(k * 2 + net) * g.Hp * ldn;
+#pragma unroll 1
+        for (int c = 0; c < HC; ++c) {
+          buf = st.next();
           bwd_chunk<P, ACT, T, HT, NKS>(buf, reinterpret_cast<const float*>(buf + tbb - kTailBytes), a.act, lane, hh,
-                                        x0f, dcur, dx0, Gt, Ht, ldn, 32 * c, tok);
+                                        x0f, dcur, dx0, Gt, Ht, ldn, 32 * c, loff);
+        }
       }
     }
   }
@@ -1024,7 +1083,7 @@ int launch_stack(bool bwd, bool vec, const StackArgs& a, unsigned grid, unsigned
     if (vec) { big((const void*)k_stack_bwd<P, T, HT, true, LB, ACT>); k_stack_bwd<P, T, HT, true, LB, ACT><<<grid, block, lds, st>>>(a); }
     else { big((const void*)k_stack_bwd<P, T, HT, false, LB, ACT>); k_stack_bwd<P, T, HT, false, LB, ACT><<<grid, block, lds, st>>>(a); }
   } else {
-    constexpr int LB = HT <= 2 ? 512 : 256;
+    constexpr int LB = 512;
     if (vec) { big((const void*)k_stack_fwd<P, T, HT, true, LB, ACT>); k_stack_fwd<P, T, HT, true, LB, ACT><<<grid, block, lds, st>>>(a); }
     else { big((const void*)k_stack_fwd<P, T, HT, false, LB, ACT>); k_stack_fwd<P, T, HT, false, LB, ACT><<<grid, block, lds, st>>>(a); }
   }
@@ -1069,8 +1128,8 @@ static int run_stack(const char* name, bool bwd, StackArgs a, int64_t Bn, int h,
   if (bwd) vec = vec && aligned16(a.dz_in) && (a.dz_out == nullptr || aligned16(a.dz_out));
   const int64_t ntok = bwd ? a.Npad : a.N;
   const int64_t ntiles = (ntok + 31) / 32;
-  const int64_t tb = bwd ? a.g.tbb : a.g.tbf;
-  const int64_t ntasks = (int64_t)a.K * (bwd ? 3 : 2) * a.g.HC;
+  const int64_t tb = bwd ? a.g.tbb : 2 * a.g.tbf;   // forward consumes (s, t) task pairs
+  const int64_t ntasks = (int64_t)a.K * (bwd ? 3 : 1) * a.g.HC;
   // tasks per staged block: as many as fit one stream buffer (fewer barriers, deeper prefetch)
   int64_t G = kStageBufBytes / tb;
   if (G < 1) G = 1;
@@ -1078,23 +1137,24 @@ static int run_stack(const char* name, bool bwd, StackArgs a, int64_t Bn, int h,
   a.G = (int)G;
   // waves per block: keep >= 256 blocks (one per CU) before growing the block; W waves share each
   // staged weight block, so larger W cuts L2 -> LDS traffic per token.
-  int W = 1;
-  const int wmax = (bwd ? a.g.HT > 1 : a.g.HT > 2) ? 4 : 8;   // must match the kernels' launch bounds
+  int W = 1;   // token tiles per block
+  const int wmax = bwd ? (a.g.HT > 1 ? 4 : 8) : 4;   // must match the kernels' launch bounds
   while (W < wmax && ntiles / (2 * W) >= 256) W *= 2;
   auto lds_need = [&](int w) -> size_t {
-    return 2 * (size_t)(G * tb) + (bwd ? (size_t)w * a.g.HT * 4096 : 0);
+    return 2 * (size_t)(G * tb) + (size_t)w * a.g.HT * 4096;   // stream buffers + per-tile stash
   };
   while (W > 1 && lds_need(W) > kLdsLimit) W /= 2;
   MIVAE_REQUIRE(lds_need(W) <= kLdsLimit, "%s: task region too large for LDS (h=%d)", name, h);
   const unsigned grid = (unsigned)((ntiles + W - 1) / W);
   const size_t lds = lds_need(W);
+  const unsigned block = (unsigned)(bwd ? W * 64 : W * 128);   // forward: two role waves per tile
   int rc;
   if (act == ACT_GELU) {
-    if (dtype == MIVAE_F32) rc = launch_ht<MmaF32, float, ACT_GELU>(a.g.HT, bwd, vec, a, grid, W * 64, lds, st);
-    else rc = launch_ht<MmaBF16, unsigned short, ACT_GELU>(a.g.HT, bwd, vec, a, grid, W * 64, lds, st);
+    if (dtype == MIVAE_F32) rc = launch_ht<MmaF32, float, ACT_GELU>(a.g.HT, bwd, vec, a, grid, block, lds, st);
+    else rc = launch_ht<MmaBF16, unsigned short, ACT_GELU>(a.g.HT, bwd, vec, a, grid, block, lds, st);
   } else {
-    if (dtype == MIVAE_F32) rc = launch_ht<MmaF32, float, -1>(a.g.HT, bwd, vec, a, grid, W * 64, lds, st);
-    else rc = launch_ht<MmaBF16, unsigned short, -1>(a.g.HT, bwd, vec, a, grid, W * 64, lds, st);
+    if (dtype == MIVAE_F32) rc = launch_ht<MmaF32, float, -1>(a.g.HT, bwd, vec, a, grid, block, lds, st);
+    else rc = launch_ht<MmaBF16, unsigned short, -1>(a.g.HT, bwd, vec, a, grid, block, lds, st);
   }
   MIVAE_REQUIRE(rc == 0, "%s: no kernel instance for HT=%d", name, a.g.HT);
   MIVAE_CHECK_LAUNCH(name);
