@@ -300,16 +300,19 @@ __device__ __forceinline__ void store_acc(T* __restrict__ row, bool valid, int h
     }
 }
 
-// transposed ([feature row][token]) store of one accumulator tile: row = row0 + acc_row(r, hh).
-// `base`, `ld`, `row0` are wave-uniform, so every store is (scalar row pointer) + one 32-bit per-lane
-// offset `loff` = 4 * hh * ld + token (computed once per kernel): no per-store 64-bit VALU address
-// arithmetic and no hoisted address registers.
+// Side outputs of the backward (consumed by the weight-gradient kernel) are stored "token-blocked":
+// element (feature row f, token tau) of a section with F rows lives at ((tau / TB) * F + f) * TB + tau % TB,
+// TB = 16 bytes worth of tokens (8 bf16 / 4 fp32).  The reader's MFMA fragment (row on the lane, TB
+// consecutive tokens per lane) is then ONE fully coalesced 16-byte-per-lane load per operand.
+// Store of one accumulator tile (rows row0 + acc_row(r, hh), token on the lane): `base`, `row0` are
+// wave-uniform, `loff` = (tau / TB) * F * TB + tau % TB + 4 * hh * TB is the per-lane part (computed
+// once per kernel): no per-store 64-bit VALU address arithmetic.
 template <typename T>
-__device__ __forceinline__ void store_tile_t(T* __restrict__ base, int64_t ld, int row0, unsigned loff,
-                                             const f32x16& x) {
+__device__ __forceinline__ void store_tile_t(T* __restrict__ base, int row0, unsigned loff, const f32x16& x) {
+  constexpr int TB = 16 / sizeof(T);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    T* rowp = base + (int64_t)(row0 + (r & 3) + 8 * (r >> 2)) * ld;
+    T* rowp = base + (row0 + (r & 3) + 8 * (r >> 2)) * TB;
     float t1[1] = {x[r]};
     RowIO<T, 1>::store(rowp + loff, t1);
   }
@@ -767,7 +770,7 @@ template <class P, int ACT, typename T, int HT, int NKS>
 __device__ __forceinline__ void bwd_chunk(const char* buf, const float* tail, int act, int lane, int hh,
                                           const typename P::BF (&x0f)[NKS], const f32x16 (&dout)[HT],
                                           f32x16 (&dx0)[HT], T* __restrict__ Gt, T* __restrict__ Ht,
-                                          int64_t ld, int row0, unsigned loff) {
+                                          int row0, unsigned loff, int dbg = 0) {
   const typename P::AF* w1 = reinterpret_cast<const typename P::AF*>(buf) + lane;
   typename P::AF f1[NKS], f2[HT * P::NS], f3[HT * P::NS];
   load_frags<P, NKS>(w1, f1);
@@ -784,10 +787,10 @@ __device__ __forceinline__ void bwd_chunk(const char* buf, const float* tail, in
   ReduceFromAcc<P, HT, 0>::run(f2, dout, dh);   // independent of the activation: overlaps its VALU work
   f32x16 dact;
   act_tile_fd<ACT, P::KS == 16>(act, hid, dact);
-  store_tile_t<T>(Ht, ld, row0, loff, hid);
+  if (!(dbg & 4)) store_tile_t<T>(Ht, row0, loff, hid);
 #pragma unroll
   for (int r = 0; r < 16; ++r) dh[r] *= dact[r];
-  store_tile_t<T>(Gt, ld, row0, loff, dh);
+  if (!(dbg & 4)) store_tile_t<T>(Gt, row0, loff, dh);
   AccumFromAcc<P, HT, 0>::run(f3, dh, dx0);
 }
 
@@ -818,18 +821,22 @@ __global__ void __launch_bounds__(LB) k_stack_bwd(StackArgs a) {
   typename P::BF x0f[NKS];
   load_x0<T, VEC, NKS, P>(zrow, valid && m != 0.f, h, hh, x0f);
   const int64_t ldn = a.Npad;
-  const unsigned loff = (unsigned)(4 * hh * ldn + tok);
+  // per-lane parts of the token-blocked side-output addresses (sections with Hp / hp rows)
+  constexpr int TB = 16 / sizeof(T);
+  const unsigned tblk = (unsigned)(tok / TB), tin = (unsigned)(tok % TB);
+  const unsigned loffH = tblk * (unsigned)(g.Hp * TB) + tin + 4 * hh * TB;
+  const unsigned loffh = tblk * (unsigned)(g.hp * TB) + tin + 4 * hh * TB;
   if (active) {  // x0^T for the dW1 products
-    T* xt = reinterpret_cast<T*>(a.x0t);
+    T* xt = reinterpret_cast<T*>(a.x0t) + (tblk * (unsigned)(g.hp * TB) + tin);
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
       if constexpr (P::KS == 2) {
         float t1[1] = {x0f[ks]};
-        RowIO<T, 1>::store(xt + (int64_t)(2 * ks + hh) * ldn + tok, t1);
+        RowIO<T, 1>::store(xt + (2 * ks + hh) * TB, t1);
       } else {
         u16x8 raw = __builtin_bit_cast(u16x8, x0f[ks]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ((unsigned short*)xt)[(int64_t)(16 * ks + 8 * hh + j) * ldn + tok] = raw[j];
+        for (int j = 0; j < 8; ++j) ((unsigned short*)xt)[(16 * ks + 8 * hh + j) * TB] = raw[j];
       }
     }
   }
@@ -910,8 +917,8 @@ __global__ void __launch_bounds__(LB) k_stack_bwd(StackArgs a) {
             dcur[t][r] = in ? ge * x1[t][r] + dl : 0.f;
             gx1[t][r] = ge;
           }
-          store_tile_t<T>(dS, ldn, 32 * t, loff, dcur[t]);
-          store_tile_t<T>(dS + (int64_t)g.hp * ldn, ldn, 32 * t, loff, dt);
+          store_tile_t<T>(dS, 32 * t, loffh, dcur[t]);
+          store_tile_t<T>(dS + (int64_t)g.hp * ldn, 32 * t, loffh, dt);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             f32x4 v = {dt[4 * q], dt[4 * q + 1], dt[4 * q + 2], dt[4 * q + 3]};
@@ -929,7 +936,7 @@ __global__ void __launch_bounds__(LB) k_stack_bwd(StackArgs a) {
         for (int c = 0; c < HC; ++c) {
           buf = st.next();
           bwd_chunk<P, ACT, T, HT, NKS>(buf, reinterpret_cast<const float*>(buf + tbb - kTailBytes), a.act, lane, hh,
-                                        x0f, dcur, dx0, Gt, Ht, ldn, 32 * c, loff);
+                                        x0f, dcur, dx0, Gt, Ht, 32 * c, loffH, a.dbg);
         }
       }
     }
@@ -966,9 +973,12 @@ __global__ void __launch_bounds__(256) k_dw_partial(DwArgs a) {
   const int type = (int)(id & 1);
   const int kn = (int)(id >> 1);
   const int64_t ldn = a.Npad;
-  const T* A = reinterpret_cast<const T*>(type == 0 ? a.Gt : a.Ht) + ((int64_t)kn * a.Hp + 32 * mt + r32) * ldn;
+  // token-blocked operands: element (row f, token tau) at ((tau / TB) * F + f) * TB + tau % TB
+  constexpr int TB = 16 / sizeof(T);
+  const int64_t sA = (int64_t)a.Hp * TB, sB = (int64_t)a.hp * TB;   // elements per token block
+  const T* A = reinterpret_cast<const T*>(type == 0 ? a.Gt : a.Ht) + (int64_t)kn * a.Hp * ldn + (32 * mt + r32) * TB;
   const T* B = (type == 0 ? reinterpret_cast<const T*>(a.x0t)
-                          : reinterpret_cast<const T*>(a.dSt) + (int64_t)kn * a.hp * ldn) + (int64_t)r32 * ldn;
+                          : reinterpret_cast<const T*>(a.dSt) + (int64_t)kn * a.hp * ldn) + r32 * TB;
   const int64_t t0 = (int64_t)slab * a.slab_len;
   int64_t t1 = t0 + a.slab_len;
   if (t1 > ldn) t1 = ldn;
@@ -982,10 +992,11 @@ __global__ void __launch_bounds__(256) k_dw_partial(DwArgs a) {
     const u16x8 ones_raw = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
     const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_raw);
     for (int64_t k0 = t0; k0 < t1; k0 += 16) {
-      const bf16x8 af = *reinterpret_cast<const bf16x8*>(A + k0 + 8 * hh);
+      const int64_t blk = (k0 >> 3) + hh;
+      const bf16x8 af = *reinterpret_cast<const bf16x8*>(A + blk * sA);
       bf16x8 bf[HT];
 #pragma unroll
-      for (int t = 0; t < HT; ++t) bf[t] = *reinterpret_cast<const bf16x8*>(B + (int64_t)32 * t * ldn + k0 + 8 * hh);
+      for (int t = 0; t < HT; ++t) bf[t] = *reinterpret_cast<const bf16x8*>(B + blk * sB + 32 * t * TB);
 #pragma unroll
       for (int t = 0; t < HT; ++t) acc[t] = P::mma(af, bf[t], acc[t]);
       if (type == 0) accb[0] = P::mma(af, ones, accb[0]);
@@ -996,10 +1007,11 @@ __global__ void __launch_bounds__(256) k_dw_partial(DwArgs a) {
     }
   } else {
     for (int64_t k0 = t0; k0 < t1; k0 += 8) {
-      const f32x4 af = *reinterpret_cast<const f32x4*>(A + k0 + 4 * hh);
+      const int64_t blk = (k0 >> 2) + hh;
+      const f32x4 af = *reinterpret_cast<const f32x4*>(A + blk * sA);
       f32x4 bf[HT];
 #pragma unroll
-      for (int t = 0; t < HT; ++t) bf[t] = *reinterpret_cast<const f32x4*>(B + (int64_t)32 * t * ldn + k0 + 4 * hh);
+      for (int t = 0; t < HT; ++t) bf[t] = *reinterpret_cast<const f32x4*>(B + blk * sB + 32 * t * TB);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
 #pragma unroll
