@@ -73,6 +73,10 @@ class GradReducer:
         self._arrived = [0] * len(self.buckets)
         self._handles: List[Optional[object]] = [None] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
+        # overlap = True: buckets are all-reduced from the grad hooks while backward is still running.
+        # overlap = False (HIP-graph replay of the step, where Python hooks do not run): finish() issues
+        # every bucket after backward.
+        self.overlap = True
 
     # -- hooks ------------------------------------------------------------------------------------
     def _on_grad(self, p: torch.nn.Parameter) -> None:
@@ -82,6 +86,8 @@ class GradReducer:
             # someone replaced .grad (zero_grad(set_to_none=True)): copy back into the bucket view
             raise RuntimeError("GradReducer: parameter .grad was re-allocated; call reducer.zero_grad() "
                                "instead of optimizer.zero_grad(set_to_none=True)")
+        if not self.overlap:
+            return
         self._arrived[bi] += 1
         if self._arrived[bi] == self._bucket_size[bi]:
             self._launch(bi)

@@ -12,6 +12,7 @@ import torch.distributions as D
 
 from . import ops
 from .flows import Flow, fused_stack_spec
+from .nn_bracket import Linear
 from .registrable import Registrable
 
 
@@ -158,9 +159,9 @@ class Posterior(torch.nn.Module, Registrable):
         super().__init__()
         self.samples = samples
         self._features = features
-        self._mu_net = torch.nn.Linear(input_size, features)
+        self._mu_net = Linear(input_size, features)
         self._sigma_net = torch.nn.Sequential(
-            torch.nn.Linear(input_size, features), torch.nn.Softplus(),
+            Linear(input_size, features), torch.nn.Softplus(),
             torch.nn.Hardtanh(min_val=1e-4, max_val=5.0))
         self._mu = None
         self._sigma = None

@@ -91,6 +91,7 @@ class VAELmModel(torch.nn.Module, Registrable):
         self._metrics = {k: RunningMean() for k in ("nll", "avg-recon-weight", "avg-kl-weight", "avg-kl")}
         self._end_index = self.vocab.token_to_index("<eos>")
         self.training_outputs_only = False   # skip probs/preds (unused by the loss) when True
+        self.track_metrics = True            # False under HIP-graph capture (host-side accumulators)
 
     @property
     def is_kl_used(self) -> bool:
@@ -127,10 +128,11 @@ class VAELmModel(torch.nn.Module, Registrable):
                           **{k: v.mean() for k, v in kl_out.items()}},
             "source": src_tokens, "target": tgt_tokens, "latent": latent.z, **decoded,
         }
-        self._metrics["nll"].update(batch_nll)
-        self._metrics["avg-recon-weight"].update(w_r)
-        self._metrics["avg-kl-weight"].update(w_kl)
-        self._metrics["avg-kl"].update(batch_kl)
+        if self.track_metrics:
+            self._metrics["nll"].update(batch_nll)
+            self._metrics["avg-recon-weight"].update(w_r)
+            self._metrics["avg-kl-weight"].update(w_kl)
+            self._metrics["avg-kl"].update(batch_kl)
         return out
 
     def kl_scheduler_step(self) -> None:

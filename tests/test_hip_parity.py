@@ -439,3 +439,23 @@ def test_full_model_elbo_golden(M, name):
         errs[k] = float((p.grad.cpu().double() - ref.double()).abs().max()) / max(float(ref.abs().max()), 1e-3 * scale)
     worst = max(errs, key=errs.get)
     assert errs[worst] < 5e-4, (worst, errs[worst])
+
+
+# ------------------------------------------------------------------------------------ bracket helper
+def test_splitk_linear_matches_torch_linear(M):
+    """nn_bracket.Linear (token-split weight-gradient GEMM) == torch.nn.Linear, forward and backward."""
+    from nonauto_lm_amd.nn_bracket import Linear
+    torch.manual_seed(3)
+    ref = torch.nn.Linear(48, 80).to(DEV)
+    lin = Linear(48, 80).to(DEV)
+    lin.load_state_dict(ref.state_dict())
+    x = torch.randn(64, 128, 48, device=DEV)            # 8192 tokens -> split path
+    cot = torch.randn(64, 128, 80, device=DEV)
+    xr, xl = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    (ref(xr) * cot).sum().backward()
+    yl = lin(xl)
+    (yl * cot).sum().backward()
+    assert torch.equal(yl, ref(x))
+    assert rel_err(xl.grad, xr.grad) < 1e-6
+    assert rel_err(lin.weight.grad, ref.weight.grad) < 1e-5 and rel_err(lin.bias.grad, ref.bias.grad) < 1e-5
+    assert list(lin.state_dict()) == list(ref.state_dict())
