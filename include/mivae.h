@@ -167,6 +167,23 @@ int mivae_elbo_fwd(const float* recon, const float* kl, float* out3, int64_t B, 
 int mivae_elbo_bwd(const float* recon, const float* kl, const float* gout3, float* drecon, float* dkl,
                    int64_t B, int64_t n, float recon_weight, float kl_weight, int iwae, void* stream);
 
+/* ---- reconstruction term: label-smoothing NLL over the vocabulary ------------------------------ */
+/* per_seq[b] = sum_s w[b,s] * nll[b,s] / clamp(sum_s w[b,s], 1e-13) with
+ * nll = -sum_v q_v log_softmax(logits[b,s,:])_v, q = (1 - smoothing) onehot(target) + smoothing / V
+ * (smoothing = 0: plain gather).  Replaces LabelSmoothingNLL.forward with size_average=False,
+ * models/base/losses.py:128-169 (the caller passes smoothing = 0 in eval mode, losses.py:144).
+ * logits (Bn,S,V) in `dtype`; target (Bn,S) i64; weights (Bn,S) f32.  Also written for the backward:
+ * lse (Bn*S) log-sum-exp per token, tokscale (Bn*S) = w / clamp(sum w); tok_nll (Bn*S) is scratch.
+ * Rows with weight 0 are not read.  One read of the logits. */
+int mivae_nll_fwd(const void* logits, const int64_t* target, const float* weights, float* per_seq,
+                  float* lse, float* tokscale, float* tok_nll, int64_t Bn, int64_t S, int64_t V,
+                  float smoothing, int dtype, void* stream);
+/* dlogits[b,s,v] = dper_seq[b] * tokscale[b,s] * (softmax(logits[b,s,:])_v - q_v): autograd of the
+ * chain above (losses.py:141-164).  One read of the logits, one write of dlogits (same dtype). */
+int mivae_nll_bwd(const void* logits, const int64_t* target, const float* lse, const float* tokscale,
+                  const float* dper_seq, void* dlogits, int64_t Bn, int64_t S, int64_t V,
+                  float smoothing, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

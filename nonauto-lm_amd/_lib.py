@@ -38,6 +38,8 @@ SIGNATURES = {
     "mivae_kl_bwd": [P, P, P, P, P, I64, I32, F32, P],
     "mivae_elbo_fwd": [P, P, P, I64, I64, F32, F32, I32, P],
     "mivae_elbo_bwd": [P, P, P, P, P, I64, I64, F32, F32, I32, P],
+    "mivae_nll_fwd": [P, P, P, P, P, P, P, I64, I64, I64, F32, I32, P],
+    "mivae_nll_bwd": [P, P, P, P, P, P, I64, I64, I64, F32, I32, P],
     "mivae_nice_pack_bytes": [I64, I64, I32],
     "mivae_nice_pack": [P, P, I64, I64, I64, I32, I32, P],
     "mivae_nice_stack_fwd": [P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I32, I32, I32, F32, F32, I32, P],

@@ -9,6 +9,7 @@ from typing import Callable, Dict, List, NamedTuple, Union
 import torch
 import torch.nn.functional as F
 
+from . import ops
 from .registrable import FromParams, Registrable
 
 
@@ -348,16 +349,9 @@ class LabelSmoothingNLL(torch.nn.Module):
         self._size_average = size_average
 
     def forward(self, logits, target, weights):
-        V = logits.size(-1)
-        logp = torch.log_softmax(logits.reshape(-1, V).float(), dim=-1)
-        tgt = target.reshape(-1, 1).long()
-        nll = -logp.gather(1, tgt)
-        if self._smoothing is not None and self._smoothing > 0.0 and self.training:
-            # sum_v q_v * (-logp_v) with q = (1 - s) onehot + s / V
-            nll = (1.0 - self._smoothing) * nll - (self._smoothing / V) * logp.sum(-1, keepdim=True)
-        nll = nll.view(*target.shape) * weights
-        wsum = weights.reshape(weights.size(0), -1).sum(1)
-        per_seq = nll.reshape(nll.size(0), -1).sum(1) / wsum.clamp(min=1e-13)
+        smoothing = self._smoothing if (self._smoothing is not None and self._smoothing > 0.0 and self.training) else 0.0
+        per_seq = ops.label_smoothing_nll(logits, target, weights, smoothing)
         if self._size_average:
+            wsum = weights.reshape(weights.size(0), -1).sum(1)
             return per_seq.sum() / wsum.gt(0).float().sum().clamp(min=1e-13)
         return per_seq

@@ -361,6 +361,46 @@ def elbo_tail(recon, kl, batch: int, samples: int, recon_weight: float, kl_weigh
     return out[0], out[1], out[2]
 
 
+# ----------------------------------------------------------------------------------- reconstruction NLL
+class _NLL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, weights, smoothing):
+        Bn, V = logits.size(0), logits.size(-1)
+        S = target.numel() // max(Bn, 1)
+        lg = logits.contiguous()
+        if lg.dtype not in (torch.float32, torch.bfloat16):
+            lg = lg.float()
+        tgt = target.reshape(Bn, S).contiguous().long()
+        w = weights.reshape(Bn, S).contiguous().float()
+        dev = lg.device
+        per_seq = torch.empty(Bn, dtype=torch.float32, device=dev)
+        aux = torch.empty(3, Bn * S, dtype=torch.float32, device=dev)      # lse, tokscale, scratch
+        with _timed("nll_fwd"):
+            L.call("mivae_nll_fwd", L.ptr(lg), L.ptr(tgt), L.ptr(w), L.ptr(per_seq), L.ptr(aux[0]), L.ptr(aux[1]),
+                   L.ptr(aux[2]), Bn, S, V, float(smoothing), L.dtype_code(lg.dtype), L.stream())
+        ctx.save_for_backward(lg, tgt, aux)
+        ctx.meta = (Bn, S, V, float(smoothing), logits.dtype)
+        return per_seq
+
+    @staticmethod
+    def backward(ctx, dper):
+        lg, tgt, aux = ctx.saved_tensors
+        Bn, S, V, smoothing, in_dtype = ctx.meta
+        dl = torch.empty_like(lg)
+        with _timed("nll_bwd"):
+            L.call("mivae_nll_bwd", L.ptr(lg), L.ptr(tgt), L.ptr(aux[0]), L.ptr(aux[1]),
+                   L.ptr(dper.contiguous().float()), L.ptr(dl), Bn, S, V, smoothing, L.dtype_code(lg.dtype),
+                   L.stream())
+        return dl.to(in_dtype), None, None, None
+
+
+def label_smoothing_nll(logits, target, weights, smoothing: float = 0.0):
+    """a18: per-sequence weighted token-mean NLL, LabelSmoothingNLL.forward with size_average=False
+    (models/base/losses.py:128-164).  logits (Bn, ..., V); target, weights (Bn, ...)."""
+    L.require_gpu(logits, target, weights)
+    return _NLL.apply(logits, target, weights, smoothing or 0.0)
+
+
 # ----------------------------------------------------------------------------------- fused NICE stack
 _PTR_CACHE = {}
 

@@ -388,6 +388,68 @@ def test_elbo_tail_vs_oracle(M, B, n, iwae):
     assert rel_err(rg.grad, rr.grad) < TOL and rel_err(kg.grad, kr.grad) < TOL
 
 
+# ------------------------------------------------------------------------------------ reconstruction NLL (a18)
+def test_nll_golden(M):
+    """Reference LabelSmoothingNLL outputs and d/dlogits captured in tests/golden/kl_nll.npz (V=11: scalar path)."""
+    g = load_golden("kl_nll")
+    tgt, w = dev(g["nll.target"]), dev(g["nll.weights"])
+    for sm in (0.0, 0.1):
+        for mode in ("train", "eval"):
+            mod = M.LabelSmoothingNLL(sm, size_average=False)
+            mod.train(mode == "train")
+            lg = dev(g["nll.logits"]).clone().requires_grad_(True)
+            val = mod(lg, tgt, weights=w)
+            assert rel_err(val, g[f"nll.{mode}.s{sm}"]) < TOL, (sm, mode)
+            if mode == "train":
+                val.sum().backward()
+                assert rel_err(lg.grad, g[f"nll.train.s{sm}.grad"]) < TOL
+
+
+@pytest.mark.parametrize("Bn,S,V,dtype,sm", [
+    (6, 9, 64, torch.float32, 0.0), (6, 9, 1000, torch.float32, 0.1), (3, 5, 8192, torch.float32, 0.0),
+    (4, 7, 1027, torch.float32, 0.2), (5, 6, 8192, torch.bfloat16, 0.0), (4, 3, 1000, torch.bfloat16, 0.1),
+    (2, 70, 33, torch.bfloat16, 0.0), (1, 1, 8, torch.float32, 0.0)])
+def test_nll_vs_oracle(M, Bn, S, V, dtype, sm):
+    gen = torch.Generator().manual_seed(Bn * 131 + V)
+    logits = (torch.randn(Bn, S, V, generator=gen) * 3).to(dtype)
+    target = torch.randint(1, V, (Bn, S), generator=gen)
+    lengths = torch.randint(0, S + 1, (Bn,), generator=gen)           # includes empty sentences
+    target[torch.arange(S)[None, :] >= lengths[:, None]] = 0
+    w = O.tokens_mask(target).float()
+    gout = torch.randn(Bn, generator=gen)
+    lr = logits.float().clone().requires_grad_(True)                 # oracle on the same (rounded) inputs, fp32 math
+    ref = O.label_smoothing_nll(lr, target, w, sm, training=True)
+    (ref * gout).sum().backward()
+    lg = dev(logits).clone().requires_grad_(True)
+    got = M.ops.label_smoothing_nll(lg, dev(target), dev(w), sm)
+    (got * dev(gout)).sum().backward()
+    assert got.dtype == torch.float32 and lg.grad.dtype == dtype
+    assert rel_err(got, ref) < TOL
+    # the gradient is rounded once to the logits' dtype on store
+    assert rel_err(lg.grad.float(), lr.grad) < (TOL if dtype == torch.float32 else 4e-3)
+    # padded rows get exactly zero gradient
+    assert torch.equal(lg.grad[dev(w) == 0], torch.zeros_like(lg.grad[dev(w) == 0]))
+
+
+def test_nll_full_size_properties(M):
+    """BASELINE C2 size (N = 16384 tokens, V = 8192, bf16): size-independent properties -- shift invariance of the
+    loss, sum_v dlogits = 0 per row (softmax minus a distribution), and agreement with torch's cross_entropy."""
+    B, S, V = 256, 64, 8192
+    gen = torch.Generator().manual_seed(5)
+    logits = dev((torch.randn(B, S, V, generator=gen) * 2).to(torch.bfloat16))
+    target = dev(torch.randint(1, V, (B, S), generator=gen))
+    w = torch.ones(B, S, device="cuda")
+    lg = logits.clone().requires_grad_(True)
+    per = M.ops.label_smoothing_nll(lg, target, w, 0.0)
+    per.sum().backward()
+    ce = torch.nn.functional.cross_entropy(logits.float().view(-1, V), target.view(-1), reduction="none").view(B, S).mean(1)
+    assert rel_err(per, ce) < TOL
+    assert lg.grad.float().sum(-1).abs().max().item() < 2.0 ** -8 / S  # one bf16 rounding of the -1/S one-hot entry
+    shifted = (logits.float() + 3.0).to(torch.bfloat16)
+    if torch.equal(shifted.float() - 3.0, logits.float()):           # only when the shift is exact in bf16
+        assert rel_err(M.ops.label_smoothing_nll(shifted, target, w, 0.0), per) < TOL
+
+
 # ------------------------------------------------------------------------------------ full model
 def _model_from_golden(M, g):
     D = g["sd._posterior._mu_net.weight"].shape[0]
