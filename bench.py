@@ -104,9 +104,9 @@ def cpu_baseline(model, tokens, D, H, K, budget_s=20.0):
                       f"({dt * 1e3:.1f} ms/step); latent path = oracle/latent_path.py, enc/dec = stock PyTorch CPU"}
 
 
-def flow_kernel_times(model, tokens, dtype, reps=50):
-    """Average GPU duration of the three dominant hand-written launches (fused NICE stack forward, its
-    backward, the weight-gradient kernel pair) on the bench shape: each launch is captured alone into a
+def flow_kernel_times(model, tokens, dtype, reps=50, graph=True):
+    """Average GPU duration of the dominant hand-written launches (reconstruction NLL forward / backward over the
+    (N, V) logits, fused NICE stack forward, its backward, the weight-gradient kernel pair) on the bench shape: each launch is captured alone into a
     HIP graph through the C ABI and replayed `reps` times between two HIP events on the launch stream,
     so no host launch gap is included."""
     import nonauto_lm_amd as M
@@ -133,7 +133,15 @@ def flow_kernel_times(model, tokens, dtype, reps=50):
     dW1, db1, dW2, db2 = (e(K, 2, H, h, dt=torch.float32), e(K, 2, H, dt=torch.float32),
                           e(K, 2, h, H, dt=torch.float32), e(K, 2, h, dt=torch.float32))
     actid = ops.ACT_IDS[act]
+    V = VOCAB
+    logits, dlogits = torch.randn(B, S, V, device=dev).to(dtype), e(B, S, V)
+    w = mask.float()
+    per_seq, aux, dper = e(B, dt=torch.float32), e(3, N, dt=torch.float32), torch.ones(B, device=dev)
     calls = {
+        "nll_fwd": lambda: L.call("mivae_nll_fwd", L.ptr(logits), L.ptr(tokens), L.ptr(w), L.ptr(per_seq), L.ptr(aux[0]),
+                                  L.ptr(aux[1]), L.ptr(aux[2]), B, S, V, 0.0, code, L.stream()),
+        "nll_bwd": lambda: L.call("mivae_nll_bwd", L.ptr(logits), L.ptr(tokens), L.ptr(aux[0]), L.ptr(aux[1]), L.ptr(dper),
+                                  L.ptr(dlogits), B, S, V, 0.0, code, L.stream()),
         "nice_stack_fwd": lambda: L.call("mivae_nice_stack_fwd", L.ptr(z), L.ptr(z_out), L.ptr(hist), L.ptr(mask),
                                          L.ptr(packed), L.ptr(tok), B, 1, S, D, H, K, actid, 0, 1, 0.0, 1.0, code, L.stream()),
         "nice_stack_bwd": lambda: L.call("mivae_nice_stack_bwd", L.ptr(z), L.ptr(z_out), L.ptr(hist), L.ptr(mask),
@@ -146,6 +154,11 @@ def flow_kernel_times(model, tokens, dtype, reps=50):
     for name, fn in calls.items():
         fn()                                   # eager once (module load, LDS opt-in), also produces the inputs of the next
         torch.cuda.synchronize()
+        if not graph:                          # plain launches (the rocprofv3 PMC passes use this)
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            continue
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             fn()
@@ -159,6 +172,18 @@ def flow_kernel_times(model, tokens, dtype, reps=50):
         torch.cuda.synchronize()
         out[name] = {"launches": reps, "avg_us": 1e3 * a.elapsed_time(b) / reps}
     return out
+
+
+def pmc_traffic(config, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/<round>/pmc_traffic.json,
+    produced by tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 corrections applied); None if
+    that kernel/config was not collected."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(config, {}).get(kernel, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
 
 
 def main():
@@ -229,6 +254,7 @@ def main():
         e = 2 if dtype_name == "bf16" else 4
         N = B * S
         h = D // 2
+        n_real = int((tokens != 0).sum().item())
         w_bytes = K * 2 * (2 * h * H + H + h) * e
         # algorithmic bytes per launch (DESIGN.md "Kernels"): fused K-step forward reads z and
         # writes z' once (+ int64 mask, per-token value, packed weights); backward reads z', dz', writes dz.
@@ -237,8 +263,12 @@ def main():
             "nice_stack_bwd": 3 * N * D * e + 8 * N + 4 * N + 2 * w_bytes,
             # weight gradients: the side outputs (K x 2 x (2H + h) x N) + x0^T in, fp32 gradients out
             "nice_dw": (K * 2 * (2 * H + h) + h) * N * e + 2 * w_bytes,
+            # reconstruction NLL: forward reads the logits once; backward reads them and writes d logits
+            # (rows of padding tokens are skipped: count real tokens only)
+            "nll_fwd": n_real * VOCAB * e + 16 * N + 12 * N,
+            "nll_bwd": (n_real + N) * VOCAB * e + 16 * N,
         }
-        flops = {"nice_stack_fwd": 4 * K * N * D * H, "nice_stack_bwd": 8 * K * N * D * H, "nice_dw": 4 * K * N * D * H}
+        flops = {"nll_fwd": 0, "nll_bwd": 0, "nice_stack_fwd": 4 * K * N * D * H, "nice_stack_bwd": 8 * K * N * D * H, "nice_dw": 4 * K * N * D * H}
         kern = flow_kernel_times(model, tokens, torch.bfloat16 if dtype_name == "bf16" else torch.float32)
         kernel_timing = ("each launch captured alone in a HIP graph (C ABI) and replayed 50x between two HIP events "
                          "on the launch stream, same process, bench shape, trained weights")
@@ -248,7 +278,7 @@ def main():
             us = kern[dom]["avg_us"]
             ach = algo[dom] / (us * 1e-6) / 1e9
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args.config, dom),
                         "avg_us": round(us, 2), "algorithmic_bytes": algo[dom],
                         "mfma_tflops": round(flops[dom] / (us * 1e-6) / 1e12, 2)}
             for k in kern:

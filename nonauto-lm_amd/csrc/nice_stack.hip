@@ -1042,40 +1042,41 @@ __global__ void __launch_bounds__(256) k_dw_partial(DwArgs a) {
   }
 }
 
-// element (row of A tile, col of B tile t) of a dumped accumulator
-__device__ __forceinline__ int64_t dump_index(int64_t item, int HT, int t, int rr, int cc) {
-  const int hh = (rr >> 2) & 1, r = (rr & 3) + 4 * (rr >> 3);
-  return ((item * HT + t) * 64 + cc + 32 * hh) * 16 + r;
-}
-
-__global__ void k_dw_reduce(DwArgs a) {
-  const int64_t n1 = (int64_t)a.K * 2 * a.H * a.h;   // dW1 elements == dW2 elements
+__global__ void __launch_bounds__(256) k_dw_reduce(DwArgs a) {
+  // One thread per dumped accumulator element, in dump order: for a fixed slab consecutive threads read
+  // consecutive floats (coalesced); the slabs of one (step, net, type, row tile) are nslab consecutive
+  // dumps, summed in slab order (fixed order => bit-reproducible).  The permuted store is 4 B per lane
+  // but the outputs are only the weight shapes.
+  const int64_t n1 = (int64_t)a.K * 2 * 2 * a.HC * a.HT * 1024;   // dumped elements per slab
   const int64_t nb1 = (int64_t)a.K * 2 * a.H, nb2 = (int64_t)a.K * 2 * a.h;
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < n1) {            // dW1[kn][row < H][col < h]
-    const int col = (int)(idx % a.h); int64_t q = idx / a.h;
-    const int row = (int)(q % a.H); const int kn = (int)(q / a.H);
-    const int64_t item0 = (((int64_t)kn * 2 + 0) * a.HC + row / 32) * a.nslab;
+  if (idx < n1) {
+    const int e = (int)(idx & 1023); int64_t q = idx >> 10;
+    const int t = (int)(q % a.HT); q /= a.HT;
+    const int mt = (int)(q % a.HC); q /= a.HC;
+    const int type = (int)(q & 1); const int kn = (int)(q >> 1);
+    const int r = e & 15, cl = e >> 4, cc = cl & 31, hh = cl >> 5;
+    const int row = 32 * mt + (r & 3) + 4 * hh + 8 * (r >> 2), col = 32 * t + cc;
+    if (row >= a.H || col >= a.h) return;
+    const int64_t item0 = (((int64_t)kn * 2 + type) * a.HC + mt) * a.nslab;
+    const float* p = a.part + (item0 * a.HT + t) * 1024 + e;
+    const int64_t stride = (int64_t)a.HT * 1024;
     float s = 0.f;
-    for (int sl = 0; sl < a.nslab; ++sl) s += a.part[dump_index(item0 + sl, a.HT, col / 32, row % 32, col % 32)];
-    a.dW1[idx] = s;
-  } else if (idx < 2 * n1) {  // dW2[kn][out < h][hid < H] = (Ht . dSt^T)[hid][out]
-    idx -= n1;
-    const int hid = (int)(idx % a.H); int64_t q = idx / a.H;
-    const int out = (int)(q % a.h); const int kn = (int)(q / a.h);
-    const int64_t item0 = (((int64_t)kn * 2 + 1) * a.HC + hid / 32) * a.nslab;
-    float s = 0.f;
-    for (int sl = 0; sl < a.nslab; ++sl) s += a.part[dump_index(item0 + sl, a.HT, out / 32, hid % 32, out % 32)];
-    a.dW2[idx] = s;
-  } else if (idx < 2 * n1 + nb1) {
-    idx -= 2 * n1;
+#pragma unroll 8
+    for (int sl = 0; sl < a.nslab; ++sl) s += p[sl * stride];
+    if (type == 0) a.dW1[((int64_t)kn * a.H + row) * a.h + col] = s;
+    else a.dW2[((int64_t)kn * a.h + col) * a.H + row] = s;
+    return;
+  }
+  idx -= n1;
+  if (idx < nb1) {
     const int row = (int)(idx % a.H); const int kn = (int)(idx / a.H);
     const int64_t item0 = (((int64_t)kn * 2 + 0) * a.HC + row / 32) * a.nslab;
     float s = 0.f;
     for (int sl = 0; sl < a.nslab; ++sl) s += a.partb1[(item0 + sl) * 32 + row % 32];
     a.db1[idx] = s;
-  } else if (idx < 2 * n1 + nb1 + nb2) {
-    idx -= 2 * n1 + nb1;
+  } else if (idx < nb1 + nb2) {
+    idx -= nb1;
     const int out = (int)(idx % a.h); const int kn = (int)(idx / a.h);
     float s = 0.f;
     for (int sl = 0; sl < a.nslab; ++sl) s += a.partb2[((int64_t)kn * a.nslab + sl) * a.hp + out];
@@ -1176,7 +1177,7 @@ static int run_stack(const char* name, bool bwd, StackArgs a, int64_t Bn, int h,
 // slab geometry of the weight-gradient kernel, shared by the workspace query and the launch
 static void dw_geom(int64_t Npad, const Geom& g, int& nslab, int& slab_len, int64_t& nitems) {
   const int64_t items0 = (int64_t)g.K * 2 * 2 * g.HC;
-  int64_t want = (4096 + items0 - 1) / items0;
+  int64_t want = (2048 + items0 - 1) / items0;
   const int64_t maxs = (Npad + 63) / 64;
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
@@ -1292,7 +1293,7 @@ extern "C" int mivae_nice_dw(const void* Gt, const void* Ht, const void* dSt, co
                                : launch_dw<MmaF32, float>(g.HT, a, (hipStream_t)stream);
   MIVAE_REQUIRE(rc == 0, "nice_dw: no kernel instance");
   MIVAE_CHECK_LAUNCH("nice_dw_partial");
-  const int64_t nout = 2 * (int64_t)K * 2 * H * h + (int64_t)K * 2 * (H + h);
+  const int64_t nout = (int64_t)K * 2 * 2 * g.HC * g.HT * 1024 + (int64_t)K * 2 * (H + h);
   k_dw_reduce<<<(unsigned)((nout + 255) / 256), 256, 0, (hipStream_t)stream>>>(a);
   MIVAE_CHECK_LAUNCH("nice_dw_reduce");
   return MIVAE_OK;

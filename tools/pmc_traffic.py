@@ -1,0 +1,50 @@
+"""Turn the rocprofv3 PMC passes of tools/pmc_target.py into profiles/pmc_traffic.json.
+
+    python tools/pmc_traffic.py <config> <fetch_dir> <write_dir> [out.json]
+
+Each directory holds one `--pmc FETCH_SIZE` or `--pmc WRITE_SIZE` run (--output-format csv).  Per kernel the
+counter is averaged over its dispatches; units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md
+(HBM section): both counters are in KiB; on gfx950 FETCH_SIZE tallies the 128-byte requests of wide coalesced
+reads at 64 bytes, so the read side is doubled; WRITE_SIZE is exact for 16-byte-per-lane stores."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+NAMES = {"k_nll_fwd": "nll_fwd", "k_nll_bwd": "nll_bwd", "k_stack_fwd": "nice_stack_fwd", "k_stack_bwd": "nice_stack_bwd",
+         "k_dw_partial": "nice_dw", "k_dw_reduce": "nice_dw", "k_nll_seq": "nll_fwd"}
+
+
+def collect(directory, counter):
+    per = defaultdict(lambda: defaultdict(list))          # logical kernel -> device kernel -> values
+    for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(path)):
+            if row["Counter_Name"] != counter:
+                continue
+            for key, name in NAMES.items():
+                if key + "<" in row["Kernel_Name"] or key + "(" in row["Kernel_Name"]:
+                    per[name][key].append(float(row["Counter_Value"]))
+    # one logical launch = one dispatch of each of its device kernels
+    return {name: sum(sum(v) / len(v) for v in ks.values()) for name, ks in per.items()}
+
+
+def main():
+    config, fdir, wdir = sys.argv[1:4]
+    out = sys.argv[4] if len(sys.argv) > 4 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                             "profiles", "pmc_traffic.json")
+    fetch, write = collect(fdir, "FETCH_SIZE"), collect(wdir, "WRITE_SIZE")
+    table = json.load(open(out)) if os.path.exists(out) else {}
+    table.setdefault("_method", "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of tools/pmc_target.py; "
+                                "KiB -> bytes; FETCH_SIZE x2 (gfx950 128-byte requests tallied at 64 B); per launch")
+    table[config] = {}
+    for name in sorted(set(fetch) | set(write)):
+        rd, wr = 2.0 * 1024.0 * fetch.get(name, 0.0), 1024.0 * write.get(name, 0.0)
+        table[config][name] = {"read_bytes": round(rd), "write_bytes": round(wr), "hbm_bytes_per_launch": round(rd + wr)}
+    json.dump(table, open(out, "w"), indent=1, sort_keys=True)
+    print(json.dumps(table[config], indent=1))
+
+
+if __name__ == "__main__":
+    main()
