@@ -3,12 +3,14 @@ reparameterisation + log q, base log p, KL / ELBO) behind the reference's module
 
 HIP kernels + C ABI: csrc/ -> lib/libmivae.so (include/mivae.h); host mirror: this package."""
 from . import _lib, ops
-from .flows import (ActNorm, Coupling, FeedForwardCoupling, Flow, InvertibleLinear,
-                    InvertibleLinearFlow, InvertibleMultiHeadFlow, NICECoupling)
-from .latent import (DefaultKLLoss, DefaultPosterior, DefaultPrior, FlowPrior, KLLoss, LatentSample,
+from .flows import (ActNorm, AttentionCoupling, Coupling, FeedForwardCoupling, Flow, InvertibleLinear,
+                    InvertibleLinearFlow, InvertibleMultiHeadFlow, NICECoupling, RecurrentCoupling)
+from .latent import (DefaultKLLoss, DefaultPosterior, DefaultPrior, FlowPrior, InfoVAEKLLoss, KLLoss, LatentSample,
                      Posterior, PosteriorSample, Prior, PriorSample)
 from .model import NonAutoModel, SimpleVocab, VAELmModel, WeightScheduler
-from .nn_bracket import Activation, FeedForward, LabelSmoothingNLL
+from .auto import AutoDecoder, AutoModel, RecurrentDecoder
+from .nn_bracket import (Activation, Embedder, Encoder, FeedForward, LabelSmoothingNLL, RecurrentCell, RecurrentCore,
+                         RecurrentEncoder)
 from .registrable import FromParams, Registrable
 
 __all__ = [n for n in dir() if not n.startswith("_")]

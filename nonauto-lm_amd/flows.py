@@ -10,7 +10,7 @@ from typing import List, Optional, Tuple, Union
 import torch
 
 from . import ops
-from .nn_bracket import Activation, FeedForward
+from .nn_bracket import Activation, FeedForward, PositionalEncoding, RecurrentCore, TransformerDecoderLayer
 from .registrable import Registrable
 
 
@@ -74,6 +74,52 @@ class FeedForwardCoupling(Coupling):
             return None
         lin, out = self._feedforward._linear_layers[0], self._feedforward._output
         return [lin.weight, lin.bias, out.weight, out.bias]
+
+
+@Coupling.register("attention")
+class AttentionCoupling(Coupling):
+    """couplings.py:54-81 (a11): positional encoding + causal self-attention layers of width h on x0.
+    The network itself stays on library ops; inside NICECoupling its s/t outputs
+    feed the HIP affine + masked log-det kernel."""
+
+    def __init__(self, input_size: int, hidden_size: int, num_layers: int, num_heads: int,
+                 dropout: float = 0.0) -> None:
+        super().__init__(input_size)
+        self._pos_enc = PositionalEncoding(input_size)
+        self._layers = torch.nn.ModuleList(
+            [TransformerDecoderLayer(input_size, hidden_size, num_heads, dropout=dropout) for _ in range(num_layers)])
+        self._dropout = torch.nn.Dropout(dropout) if dropout > 0.0 else torch.nn.Identity()
+
+    def forward(self, z, mask=None):
+        z = self._pos_enc(self._dropout(z)) * mask.unsqueeze(-1).to(z.dtype)
+        for layer in self._layers:
+            z = layer(z, mask)
+        return z
+
+
+@Coupling.register("recurrent")
+class RecurrentCoupling(Coupling):
+    """couplings.py:84-119 (a11): recurrent core over x0 + projection back to h features."""
+
+    def __init__(self, core: RecurrentCore, hidden_sizes: List[int] = None, ff_activation: str = "gelu",
+                 dropout: float = 0.0) -> None:
+        super().__init__(core.get_input_size())
+        self._core = core
+        if hidden_sizes is None:
+            self._projection = torch.nn.Linear(core.get_output_size(), core.get_input_size())
+        else:
+            self._projection = FeedForward(input_size=core.get_output_size(), num_layers=len(hidden_sizes),
+                                           hidden_sizes=hidden_sizes, activations=Activation.by_name(ff_activation),
+                                           dropout=dropout, output_size=core.get_input_size())
+        self._dropout = torch.nn.Dropout(dropout) if dropout > 0.0 else torch.nn.Identity()
+
+    def forward(self, z, mask=None):
+        return self._projection(self._core(self._dropout(z), mask))
+
+    @classmethod
+    def from_params(cls, **params):
+        core = RecurrentCore.from_params(**params.pop("core"))
+        return cls(core, **params)
 
 
 @Flow.register("nice")

@@ -307,6 +307,122 @@ class TransformerEncoder(Encoder):
         return x * m
 
 
+# ----------------------------------------------------------------------------------- recurrent bracket
+class RecurrentCore(torch.nn.Module, Registrable):
+    """RNN / LSTM / GRU over padded sequences (nn/recurrent.py:8-38): pack by mask lengths, run the library
+    recurrent module (MIOpen), pad back to the mask's length.  Bracket code (stock ops), not part of the path."""
+
+    def __init__(self, module: torch.nn.Module, input_size: int) -> None:
+        super().__init__()
+        self._module = module
+        self._input_size = input_size
+        self._num_directions = 2 if getattr(module, "bidirectional", False) else 1
+
+    def forward(self, tokens, mask):
+        from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
+        lengths = mask.sum(dim=1).long()
+        packed = pack_padded_sequence(tokens, lengths.detach().cpu(), batch_first=True, enforce_sorted=False)
+        encoded, _ = self._module(packed)
+        output, _ = pad_packed_sequence(encoded, batch_first=True, total_length=mask.size(1))
+        return output
+
+    def get_input_size(self) -> int:
+        return self._input_size
+
+    def get_output_size(self) -> int:
+        return self._module.hidden_size * self._num_directions
+
+
+@RecurrentCore.register("rnn")
+class RNNCore(RecurrentCore):
+    def __init__(self, input_size, hidden_size, num_layers=1, nonlinearity="tanh", bias=True, dropout=0.0,
+                 bidirectional=False):
+        super().__init__(torch.nn.RNN(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers,
+                                      nonlinearity=nonlinearity, bias=bias, batch_first=True, dropout=dropout,
+                                      bidirectional=bidirectional), input_size)
+
+
+@RecurrentCore.register("lstm")
+class LSTMCore(RecurrentCore):
+    def __init__(self, input_size, hidden_size, num_layers=1, bias=True, dropout=0.0, bidirectional=False,
+                 stateful=False):
+        super().__init__(torch.nn.LSTM(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers,
+                                       bias=bias, batch_first=True, dropout=dropout,
+                                       bidirectional=bidirectional), input_size)
+
+
+@RecurrentCore.register("gru")
+class GRUCore(RecurrentCore):
+    def __init__(self, input_size, hidden_size, num_layers=1, bias=True, dropout=0.0, bidirectional=False,
+                 stateful=False):
+        super().__init__(torch.nn.GRU(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers,
+                                      bias=bias, batch_first=True, dropout=dropout,
+                                      bidirectional=bidirectional), input_size)
+
+
+class RecurrentCell(torch.nn.Module, Registrable):
+    """One-step cells for the autoregressive decoder (nn/recurrent.py:126-177)."""
+
+    def __init__(self, module: torch.nn.RNNCellBase) -> None:
+        super().__init__()
+        self._module = module
+
+    def forward(self, input_tensor, hx=None):
+        return self._module(input_tensor, hx)
+
+    def get_input_size(self) -> int:
+        return self._module.input_size
+
+    def get_output_size(self) -> int:
+        return self._module.hidden_size
+
+
+@RecurrentCell.register("lstm")
+class LSTMCell(RecurrentCell):
+    def __init__(self, input_size, hidden_size, bias=True):
+        super().__init__(torch.nn.LSTMCell(input_size=input_size, hidden_size=hidden_size, bias=bias))
+
+
+@RecurrentCell.register("gru")
+class GRUCell(RecurrentCell):
+    def __init__(self, input_size, hidden_size, bias=True):
+        super().__init__(torch.nn.GRUCell(input_size=input_size, hidden_size=hidden_size, bias=bias))
+
+
+@Encoder.register("recurrent")
+class RecurrentEncoder(Encoder):
+    """encoders/rnn.py:9-69: recurrent core (+ optional feed-forward), output masked."""
+
+    def __init__(self, core: RecurrentCore, hidden_sizes: List[int] = None, ff_activation: str = "elu",
+                 dropout: float = 0.0) -> None:
+        super().__init__(core.get_input_size())
+        self._core = core
+        self._dropout = _maybe_dropout(dropout)
+        if hidden_sizes is None:
+            self._feedforward = torch.nn.Identity()
+            self._output_size = core.get_output_size()
+        else:
+            self._feedforward = FeedForward(input_size=core.get_output_size(), num_layers=len(hidden_sizes),
+                                            hidden_sizes=hidden_sizes, activations=Activation.by_name(ff_activation),
+                                            dropout=dropout)
+            self._output_size = self._feedforward.get_output_size()
+
+    def get_output_size(self) -> int:
+        return self._output_size
+
+    def _preprocess_embedding(self, x):
+        return self._dropout(x)
+
+    def encoder(self, x, mask):
+        out = self._feedforward(self._core(x, mask))
+        return out * mask.unsqueeze(-1).to(out.dtype)
+
+    @classmethod
+    def from_params(cls, **params):
+        core = RecurrentCore.from_params(**params.pop("core"))
+        return cls(core, **params)
+
+
 class Decoder(torch.nn.Module, Registrable):
     def __init__(self, skip_z=False):
         super().__init__()

@@ -270,6 +270,30 @@ def kl_default(log_q, log_p, free_bits_alpha: Optional[float] = None):
     return kl
 
 
+def infovae_kl(log_q, log_p, latent, prior_z, prior_std: float, alpha: float, reg_weight: float,
+               kernel_type: str = "rbf", free_bits_alpha: Optional[float] = None):
+    """InfoVAEKLLoss.forward with the prior draw injected.  nn/kl_loss.py:75-149 (direct (B, B, F) form).
+
+    Returns dict(loss, mmd-part, kl-part)."""
+    def kernel(a, b):
+        a = a.unsqueeze(1)                                               # kl_loss.py:114
+        z_dim = b.size(-1) if a.dim() == 3 else b.size(-2) + b.size(-1)   # :127 / :142 (sic)
+        c = 2.0 * z_dim * prior_std
+        diff2 = (a - b).pow(2).reshape(a.size(0), a.size(0), -1)
+        if kernel_type == "rbf":
+            return torch.exp(-diff2.mean(-1) / c)                        # :130-132
+        k = c / (1e-13 + c + diff2.sum(-1))                              # :143-145
+        return k.sum(-1) - k.diag()                                      # :148
+
+    batch = log_q.size(0)
+    kl = log_q - log_p
+    mmd = kernel(prior_z, prior_z).mean(-1) + kernel(latent, latent).mean(-1) - 2 * kernel(prior_z, latent).mean(-1)
+    loss = (1.0 - alpha) * kl + (alpha + reg_weight - 1.0) / (batch * (batch - 1)) * mmd
+    if free_bits_alpha is not None:
+        loss = loss.clamp(min=free_bits_alpha)
+    return {"loss": loss, "mmd-part": mmd, "kl-part": kl}
+
+
 def elbo_tail(recon, kl, batch: int, samples: int, recon_weight=1.0, kl_weight=1.0, iwae=False):
     """ELBO assembly of VAELmModel.forward.  models/base/model.py:156-193.
 

@@ -26,7 +26,9 @@ plumbing_stubs.install()
 
 import vae_lm.training  # noqa: E402,F401  (must come first, F10)
 from vae_lm.models.base.flows import ActNorm, NICECoupling  # noqa: E402
-from vae_lm.models.base.flows.couplings import FeedForwardCoupling  # noqa: E402
+from vae_lm.models.base.flows.couplings import (  # noqa: E402
+    AttentionCoupling, FeedForwardCoupling, RecurrentCoupling)
+from vae_lm.nn.recurrent import LSTMCore, GRUCore  # noqa: E402
 from vae_lm.models.base.flows.invertible_flows import (  # noqa: E402
     InvertibleLinearFlow, InvertibleMultiHeadFlow)
 from vae_lm.models.base import LatentSample  # noqa: E402
@@ -38,7 +40,7 @@ from vae_lm.models.nonauto_lm.priors import FlowPrior as NAFlowPrior  # noqa: E4
 from vae_lm.models.nonauto_lm.posteriors import DefaultPosterior as NAPosterior  # noqa: E402
 from vae_lm.models.auto_lm.priors import FlowPrior as AFlowPrior  # noqa: E402
 from vae_lm.models.auto_lm.posteriors import DefaultPosterior as APosterior  # noqa: E402
-from vae_lm.nn.kl_loss import DefaultKLLoss  # noqa: E402
+from vae_lm.nn.kl_loss import DefaultKLLoss, InfoVAEKLLoss  # noqa: E402
 from vae_lm.nn.utils import get_tokens_mask  # noqa: E402
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(HERE)), "tests", "golden")
@@ -85,6 +87,8 @@ def jitter(module, gen, scale=0.15):
     """Move weights off the default init so s is not ~0 (makes exp/log-det tests meaningful)."""
     with torch.no_grad():
         for p in module.parameters():
+            if not p.requires_grad:      # frozen sinusoid tables (`_pos_enc`) are constants, not weights
+                continue
             p.add_(scale * torch.randn(p.shape, generator=gen))
 
 
@@ -163,6 +167,66 @@ def gen_nice_auto(name, B, D, H, K, seed):
             tot = tot + ld
         out["inv.zK"] = z
         out["inv.logp"] = prior.base_dist.log_prob(eps).sum(-1) + tot
+    save(name, **out)
+
+
+def gen_nice_coupling(name, kind, B, S, D, K, mask_kind, seed):
+    """a11: NICE steps whose s/t networks are attention or recurrent couplings (couplings.py:54-119)."""
+    gen = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    h = D // 2
+    if kind == "attention":
+        make = lambda: AttentionCoupling(h, 2 * h, 1, 2)                      # noqa: E731
+    elif kind == "lstm":
+        make = lambda: RecurrentCoupling(LSTMCore(h, 12))                     # noqa: E731
+    else:
+        make = lambda: RecurrentCoupling(GRUCore(h, 10), hidden_sizes=[14])   # noqa: E731
+    prior = NAFlowPrior(D, [NICECoupling(make()) for _ in range(K)])
+    jitter(prior, gen, 0.05)
+    z0 = torch.randn(B, S, D, generator=gen, requires_grad=True)
+    mask = make_mask(mask_kind, B, S, gen)
+    out = {"z0": z0, "mask": mask, "kind": np.array(kind)}
+    out.update(state(prior, "sd."))
+    zK, logp = prior.forward_pass(z0, mask)
+    out["fwd.zK"], out["fwd.logp"] = zK, logp
+    cz, cl = torch.randn(zK.shape, generator=gen), torch.randn(logp.shape, generator=gen)
+    out["cot.z"], out["cot.logp"] = cz, cl
+    ((zK * cz).sum() + (logp * cl).sum()).backward()
+    out["grad.z0"] = z0.grad
+    out.update(grads(prior, "grad.sd."))
+    eps = torch.randn(B, S, D, generator=gen) * mask.unsqueeze(-1)
+    out["inv.eps"] = eps
+    with torch.no_grad():
+        zi, lpi = prior.backward_pass(eps, mask)
+        out["inv.zK"], out["inv.logp"] = zi, lpi
+    save(name, **out)
+
+
+def gen_infovae(name, seed):
+    """a19: InfoVAEKLLoss (kl_loss.py:52-149) on 3-D and 2-D latents, rbf and imq kernels; the prior draw of
+    `_compute_mmd` (kl_loss.py:102) is recorded by replaying the global RNG."""
+    gen = torch.Generator().manual_seed(seed)
+    out = {}
+    for tag, shape, prior in (("3d", (6, 5, 8), NAFlowPrior(8, [], mu=0.0, std=1.2)),
+                              ("2d", (7, 12), AFlowPrior(12, [], mu=0.0, std=0.8))):
+        z = torch.randn(*shape, generator=gen, requires_grad=True)
+        logq = torch.randn(shape[0], generator=gen) - 8
+        logp = torch.randn(shape[0], generator=gen) - 9
+        out[f"{tag}.z"], out[f"{tag}.logq"], out[f"{tag}.logp"] = z, logq, logp
+        out[f"{tag}.std"] = np.float32(prior.std)
+        for kernel in ("rbf", "imq"):
+            for fb in (None, 0.4):
+                mod = InfoVAEKLLoss(alpha=0.3, reg_weight=50, prior=prior, kernel_type=kernel, free_bits_alpha=fb)
+                torch.manual_seed(seed + 7)
+                prior_z = prior.base_dist.sample(z.size()[:-1])
+                torch.manual_seed(seed + 7)
+                res = mod(logq, logp, latent=z)
+                key = f"{tag}.{kernel}.fb{fb}"
+                out[key + ".prior_z"] = prior_z
+                for k, v in res.items():
+                    out[f"{key}.{k}"] = v
+                g, = torch.autograd.grad(res["loss"].sum(), z)
+                out[key + ".grad_z"] = g
     save(name, **out)
 
 
@@ -380,7 +444,92 @@ def gen_model(name, B, S, D, H, K, V, n, iwae, free_bits, label_smoothing, seed)
     save(name, **out)
 
 
+def auto_config(D, E, H, K, n, iwae, free_bits, label_smoothing, kl="default"):
+    return dict(
+        type="auto",
+        embedder=dict(embedding_dim=E),
+        encoder=dict(type="recurrent", core=dict(type="lstm", input_size=E, hidden_size=E)),
+        decoder=dict(type="auto-recurrent", cell=dict(type="lstm", input_size=E, hidden_size=D),
+                     embedder=dict(embedding_dim=E), max_timesteps=12, teacher_forcing_ratio=1.0),
+        posterior=dict(type="default", input_size=E, features=D, samples=n),
+        prior=dict(type="flow", features=D, flows=[
+            dict(type="nice", coupling=dict(type="feed-forward", input_size=D // 2, hidden_sizes=[H],
+                                            activation="gelu")) for _ in range(K)]),
+        kl_loss=(dict(type="default", free_bits_alpha=free_bits) if kl == "default" else
+                 dict(type="info-vae", alpha=0.3, reg_weight=20, kernel_type="rbf", free_bits_alpha=free_bits)),
+        recon_scheduler=dict(type="constant", weight=1.0),
+        kl_scheduler=dict(type="constant", weight=0.7),
+        iwae=iwae,
+        label_smoothing=label_smoothing,
+    )
+
+
+def gen_model_auto(name, B, S, D, E, H, K, V, n, iwae, free_bits, label_smoothing, seed):
+    """C4: AutoModel (auto_lm/model.py) with an LSTM encoder and the LSTM-cell decoder, teacher forcing 1.0 and no
+    word dropout (so the host RNG draws of decoder.py:119-121 do not change the inputs)."""
+    gen = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    vocab = plumbing_stubs.Vocabulary(V)
+    model = VAELmModel.from_params(vocab=vocab, **auto_config(D, E, H, K, n, iwae, free_bits, label_smoothing))
+    model.train()
+    lens = torch.randint(3, S + 1, (B,), generator=gen)
+    lens[0] = S
+    tokens = torch.randint(4, V, (B, S), generator=gen)
+    tokens[:, 0] = vocab.token_to_index("<sos>", namespace="target")
+    tokens = tokens * (torch.arange(S)[None, :] < lens[:, None])
+    rec = {}
+    orig_post, orig_prior = model.sample_from_posterior, model._get_prior_log_prob
+
+    def post_hook(encoded, random=True):
+        res = orig_post(encoded, random=random)
+        rec["ctx"], rec["logq"] = encoded.ctx, res.log_prob
+        rec["z"], rec["mu"], rec["sigma"] = res.latent.z, res.latent.mu, res.latent.sigma
+        return res
+
+    def prior_hook(z, mask=None):
+        res = orig_prior(z, mask)
+        rec["logp"] = res
+        return res
+
+    model.sample_from_posterior, model._get_prior_log_prob = post_hook, prior_hook
+    torch.manual_seed(seed + 1000)
+    eps = torch.distributions.Normal(torch.zeros(D), torch.ones(D)).sample((B, n))
+    torch.manual_seed(seed + 1000)
+    outd = model(tokens, tokens)
+    info = outd["loss_info"]
+    info["batch-loss"].backward()
+    out = {"tokens": tokens, "eps": eps, "samples": np.int64(n), "iwae": np.int64(iwae),
+           "free_bits": np.float32(-1.0 if free_bits is None else free_bits),
+           "label_smoothing": np.float32(label_smoothing), "kl_weight": np.float32(0.7),
+           "recon_weight": np.float32(1.0), "H": np.int64(H), "K": np.int64(K), "V": np.int64(V),
+           "E": np.int64(E), "D": np.int64(D)}
+    out.update(state(model, "sd."))
+    for k in ("ctx", "logq", "logp", "z", "mu", "sigma"):
+        out["rec." + k] = rec[k]
+    out["rec.logits"] = outd["logits"]
+    out["rec.preds"] = outd["preds"]
+    for k in ("batch-kl", "batch-nll", "batch-loss"):
+        out["info." + k] = info[k]
+    out.update(grads(model, "grad.sd."))
+    save(name, **out)
+
+
 if __name__ == "__main__":
+    only = set(sys.argv[1:])
+    if only:                         # regenerate selected fixtures: python gen_golden.py name [name ...]
+        _save = save
+
+        def save(name, **arrays):    # noqa: F811
+            if name in only:
+                _save(name, **arrays)
+    gen_nice_coupling("nice_attention", "attention", 4, 7, 16, 2, "ragged", 21)
+    gen_nice_coupling("nice_lstm", "lstm", 4, 7, 16, 2, "ragged", 22)
+    gen_nice_coupling("nice_gru_ff", "gru", 3, 5, 12, 2, "ragged", 23)
+    gen_infovae("infovae", 24)
+    gen_model_auto("model_auto_n1", 6, 9, 16, 24, 32, 2, 40, 1, False, None, 0.0, 25)
+    gen_model_auto("model_auto_n2_iwae", 5, 8, 32, 16, 32, 3, 40, 2, True, 0.5, 0.1, 26)
+    if only:
+        sys.exit(0)
     gen_nice("nice_tiny_full", 4, 6, 8, 16, 4, "full", 13)
     gen_nice("nice_tiny_ragged", 4, 6, 8, 16, 4, "ragged", 14)
     gen_nice("nice_tiny_holes", 4, 6, 8, 16, 4, "holes", 15)

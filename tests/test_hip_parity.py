@@ -503,6 +503,105 @@ def test_full_model_elbo_golden(M, name):
     assert errs[worst] < 5e-4, (worst, errs[worst])
 
 
+# ------------------------------------------------------------------------------------ a11 / a19 / C4
+def _grad_errs(model, g, prefix="grad.sd."):
+    scale = max(float(v.abs().max()) for k, v in g.items() if k.startswith(prefix))
+    errs = {}
+    for k, p in model.named_parameters():
+        if p.grad is None or prefix + k not in g:
+            continue
+        ref = g[prefix + k]
+        errs[k] = float((p.grad.cpu().double() - ref.double()).abs().max()) / max(float(ref.abs().max()), 1e-3 * scale)
+    return errs
+
+
+@pytest.mark.parametrize("name", ["nice_attention", "nice_lstm", "nice_gru_ff"])
+def test_nice_with_library_couplings_golden(M, name):
+    """a11: NICE steps whose s/t nets are attention / recurrent couplings (library ops) feeding the HIP affine +
+    masked log-det kernel, forward, gradients and inverse, vs the reference's recorded values."""
+    g = load_golden(name)
+    kind = str(g["kind"]) if not isinstance(g["kind"], str) else g["kind"]
+    D = g["z0"].shape[-1]
+    h = D // 2
+    K = 2
+    if "attention" in kind:
+        coupling = dict(type="attention", input_size=h, hidden_size=2 * h, num_layers=1, num_heads=2)
+    elif "lstm" in kind:
+        coupling = dict(type="recurrent", core=dict(type="lstm", input_size=h, hidden_size=12))
+    else:
+        coupling = dict(type="recurrent", core=dict(type="gru", input_size=h, hidden_size=10), hidden_sizes=[14])
+    prior = M.Prior.from_params(type="flow", features=D, flows=[dict(type="nice", coupling=dict(coupling)) for _ in range(K)])
+    sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    missing, unexpected = prior.load_state_dict(sd, strict=False)
+    assert not unexpected and all("_pos_enc" in m or "_device_probe" in m for m in missing), (missing, unexpected)
+    prior = prior.to(DEV)
+    z0 = dev(g["z0"]).clone().requires_grad_(True)
+    mask = dev(g["mask"])
+    zK, logp = prior.forward_pass(z0, mask)
+    assert rel_err(zK, g["fwd.zK"]) < 2e-5 and rel_err(logp, g["fwd.logp"]) < 2e-5
+    ((zK * dev(g["cot.z"])).sum() + (logp * dev(g["cot.logp"])).sum()).backward()
+    assert rel_err(z0.grad, g["grad.z0"]) < 1e-4
+    errs = _grad_errs(prior, g)
+    assert errs and max(errs.values()) < 5e-4, max(errs, key=errs.get)
+    with torch.no_grad():
+        zi, lpi = prior.backward_pass(dev(g["inv.eps"]), mask)
+    assert rel_err(zi, g["inv.zK"]) < 2e-5 and rel_err(lpi, g["inv.logp"]) < 2e-5
+
+
+def test_infovae_kl_golden(M):
+    """a19: InfoVAEKLLoss (Gram-matrix form) vs the reference's recorded loss / parts / d loss / d z."""
+    g = load_golden("infovae")
+    for tag, D in (("3d", 8), ("2d", 12)):
+        prior = M.DefaultPrior(D, mu=0.0, std=float(g[f"{tag}.std"])).to(DEV)
+        for kernel in ("rbf", "imq"):
+            for fb in (None, 0.4):
+                key = f"{tag}.{kernel}.fb{fb}"
+                mod = M.InfoVAEKLLoss(alpha=0.3, reg_weight=50, prior=prior, kernel_type=kernel, free_bits_alpha=fb)
+                z = dev(g[f"{tag}.z"]).clone().requires_grad_(True)
+                out = mod(dev(g[f"{tag}.logq"]), dev(g[f"{tag}.logp"]), latent=z, prior_z=dev(g[key + ".prior_z"]))
+                for k in ("loss", "mmd-part", "kl-part"):
+                    assert rel_err(out[k], g[f"{key}.{k}"]) < 2e-5, (key, k)
+                gz, = torch.autograd.grad(out["loss"].sum(), z)
+                assert rel_err(gz, g[key + ".grad_z"]) < 1e-4, key
+
+
+@pytest.mark.parametrize("name", ["model_auto_n1", "model_auto_n2_iwae"])
+def test_auto_model_elbo_golden(M, name):
+    """C4: AutoModel.forward end to end (LSTM encoder, LSTM-cell decoder on library ops; 2-D latent path in HIP)
+    with the reference's recorded weights, tokens and eps: loss_info and every parameter gradient."""
+    g = load_golden(name)
+    D, E, H, K, V, n = (int(g[k]) for k in ("D", "E", "H", "K", "V", "samples"))
+    fb = float(g["free_bits"])
+    cfg = dict(
+        type="auto", embedder=dict(embedding_dim=E),
+        encoder=dict(type="recurrent", core=dict(type="lstm", input_size=E, hidden_size=E)),
+        decoder=dict(type="auto-recurrent", cell=dict(type="lstm", input_size=E, hidden_size=D),
+                     embedder=dict(embedding_dim=E), max_timesteps=12, teacher_forcing_ratio=1.0),
+        posterior=dict(type="default", input_size=E, features=D, samples=n),
+        prior=dict(type="flow", features=D, flows=[
+            dict(type="nice", coupling=dict(type="feed-forward", input_size=D // 2, hidden_sizes=[H],
+                                            activation="gelu")) for _ in range(K)]),
+        kl_loss=dict(type="default", free_bits_alpha=None if fb < 0 else fb),
+        recon_scheduler=dict(type="constant", weight=float(g["recon_weight"])),
+        kl_scheduler=dict(type="constant", weight=float(g["kl_weight"])),
+        iwae=bool(int(g["iwae"])), label_smoothing=float(g["label_smoothing"]))
+    model = M.VAELmModel.from_params(vocab=M.SimpleVocab(V), **cfg)
+    sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all("_device_probe" in m for m in missing), (missing, unexpected)
+    model = model.to(DEV).train()
+    tokens = dev(g["tokens"])
+    out = model(tokens, tokens, eps=dev(g["eps"]))
+    assert rel_err(out["latent"], g["rec.z"]) < 2e-5
+    for k in ("batch-loss", "batch-kl", "batch-nll"):
+        assert rel_err(out["loss_info"][k], g["info." + k]) < 2e-5, k
+    assert torch.equal(out["preds"].reshape(g["rec.preds"].shape).cpu(), g["rec.preds"])
+    out["loss_info"]["batch-loss"].backward()
+    errs = _grad_errs(model, g)
+    worst = max(errs, key=errs.get)
+    assert errs[worst] < 5e-4, (worst, errs[worst])
+
+
 # ------------------------------------------------------------------------------------ bracket helper
 def test_splitk_linear_matches_torch_linear(M):
     """nn_bracket.Linear (token-split weight-gradient GEMM) == torch.nn.Linear, forward and backward."""

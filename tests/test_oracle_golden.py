@@ -211,6 +211,50 @@ def test_full_model_latent_path_and_elbo(name):
         assert rel_err(out[k], g["info." + k]) < 1e-5, k
 
 
+def test_infovae_kl():
+    """a19: oracle restatement of InfoVAEKLLoss vs the reference's recorded outputs (prior draw replayed)."""
+    g = load_golden("infovae")
+    for tag in ("3d", "2d"):
+        for kernel in ("rbf", "imq"):
+            for fb in (None, 0.4):
+                key = f"{tag}.{kernel}.fb{fb}"
+                z = g[f"{tag}.z"].clone().requires_grad_(True)
+                out = O.infovae_kl(g[f"{tag}.logq"], g[f"{tag}.logp"], z, g[key + ".prior_z"], float(g[f"{tag}.std"]),
+                                   0.3, 50, kernel, fb)
+                for k in ("loss", "mmd-part", "kl-part"):
+                    assert rel_err(out[k], g[f"{key}.{k}"]) < TOL, (key, k)
+                gz, = torch.autograd.grad(out["loss"].sum(), z)
+                assert rel_err(gz, g[key + ".grad_z"]) < 1e-5, key
+
+
+@pytest.mark.parametrize("name", ["model_auto_n1", "model_auto_n2_iwae"])
+def test_auto_model_latent_path_and_elbo(name):
+    """C4: the hot path inside a full reference AutoModel.forward (sentence-level (B, D) latent) replayed from its
+    recorded encoder context / logits: posterior -> flow prior -> KL -> NLL (without <sos>) -> ELBO tail
+    (auto_lm/model.py:71-121, base/model.py:136-193)."""
+    g = load_golden(name)
+    n, iwae = int(g["samples"]), bool(int(g["iwae"]))
+    fb = float(g["free_bits"])
+    fb = None if fb < 0 else fb
+    tokens = g["tokens"]
+    B = tokens.size(0)
+    ctx = g["rec.ctx"]
+    mu = ctx @ g["sd._posterior._mu_net.weight"].t() + g["sd._posterior._mu_net.bias"]
+    sigma = O.sigma_head(ctx @ g["sd._posterior._sigma_net.0.weight"].t() + g["sd._posterior._sigma_net.0.bias"])
+    z, _ = O.posterior_sample(mu, sigma, g["eps"], None, n)
+    logq = O.posterior_log_prob(z, mu, sigma, None, n)
+    assert rel_err(z, g["rec.z"]) < TOL and rel_err(logq, g["rec.logq"]) < TOL
+    ps = nice_params(g, "sd._prior._flows.")
+    _, logp = O.flow_prior_forward(z, O.nice_steps(ps), None)
+    assert rel_err(logp, g["rec.logp"]) < TOL
+    tgt = tokens.repeat_interleave(n, 0)
+    logits = g["rec.logits"].reshape(B * n, *g["rec.logits"].shape[2:])
+    recon = O.label_smoothing_nll(logits, tgt[:, 1:], O.tokens_mask(tgt).float()[:, 1:], float(g["label_smoothing"]), True)
+    out = O.elbo_tail(recon, O.kl_default(logq, logp, fb), B, n, float(g["recon_weight"]), float(g["kl_weight"]), iwae)
+    for k in ("batch-loss", "batch-kl", "batch-nll"):
+        assert rel_err(out[k], g["info." + k]) < 1e-5, k
+
+
 def test_integer_helpers_bit_exact():
     g = load_golden("model_n1")
     tokens = g["tokens"]
