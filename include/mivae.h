@@ -116,9 +116,13 @@ int mivae_nice_stack_fwd(const void* z_in, void* z_out, void* x1_hist, const int
 /* token count padded to the slab granule (leading dimension of Gt / Ht / dSt / x0t) */
 int64_t mivae_nice_stack_npad(int64_t N);
 /* Backward of the forward direction.  dz_out (N,D) / dlogp (Bn) may be NULL.  Emits dz_in and the
- * token-contiguous operands of the weight-gradient products: Gt, Ht (K,2,Hp,Npad) = d pre-activation
- * and hidden activations, dSt (K,2,hp,Npad) = ds / dt, x0t (hp,Npad) = (x0 * mask)^T; Hp, hp = H, h
- * rounded up to 32.  (Autograd of couplings.py:141-162 + nn/feedforward.py:93-98 w.r.t. z.) */
+ * operands of the weight-gradient products: Gt, Ht (K*2*Hp*Npad elements) = d pre-activation and hidden
+ * activations, dSt (K*2*hp*Npad) = ds / dt, x0t (hp*Npad) = (x0 * mask)^T; Hp, hp = H, h rounded up to
+ * 32, Npad = mivae_nice_stack_npad(N).  Layout of each (F, Npad) matrix is TOKEN-BLOCKED:
+ * element (feature f, token t) at ((t / TB) * F + f) * TB + t % TB with TB = 16 bytes of tokens (8 bf16,
+ * 4 fp32), so both kernels move whole 16-byte vectors along the token axis.  The four buffers are
+ * opaque hand-offs to mivae_nice_dw.  (Autograd of couplings.py:141-162 + nn/feedforward.py:93-98
+ * w.r.t. z.) */
 int mivae_nice_stack_bwd(const void* z_in, const void* z_out, const void* x1_hist, const int64_t* mask,
                          const void* packed, const void* dz_out, const float* dlogp, void* dz_in,
                          void* Gt, void* Ht, void* dSt, void* x0t, int64_t Bn, int64_t mask_div,
