@@ -49,6 +49,11 @@ class TrainStep:
     def _capture(self, warmup: int):
         self.reducer.overlap = False
         self.model.track_metrics = False
+        # the AccumulateGrad nodes (kept alive by the reducer's hooks) were created on the default stream while
+        # capture runs on torch's capture stream: intentional, the buckets are only touched inside the graphs
+        quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+        if quiet is not None:
+            quiet(False)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):             # warm-up on a side stream (allocator, lazy init, autotune)
