@@ -194,6 +194,7 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bucket-mb", type=int, default=32)
+    ap.add_argument("--torch-adam", action="store_true", help="stock torch.optim.Adam + separate clip passes")
     ap.add_argument("--eager", action="store_true", help="no HIP-graph replay of the step (hook-overlapped all-reduce)")
     args = ap.parse_args()
 
@@ -218,8 +219,11 @@ def main():
     model = M.VAELmModel.from_params(vocab=M.SimpleVocab(VOCAB), **model_config(D, H, K)).to(dev).train()
     model.training_outputs_only = True             # skip probs/preds, unused by the loss
     dp.broadcast_parameters(model)
-    reducer = dp.GradReducer(model.parameters(), bucket_bytes=args.bucket_mb << 20)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, foreach=True, capturable=not args.eager)
+    reducer = dp.GradReducer(model.parameters(), bucket_bytes=args.bucket_mb << 20, flatten_params=not args.torch_adam)
+    if args.torch_adam:
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, foreach=True, capturable=not args.eager)
+    else:                                          # clip + Adam + zero_grad fused over the flat buckets (libmivae)
+        opt = dp.FusedAdam(reducer, lr=1e-4)
     scalars = dp.PackedScalars(["batch-loss", "batch-kl", "batch-nll", "done"], dev)
     tokens = synthetic_tokens(B, S, ragged, 13 + rank).to(dev)     # per-rank shard of the global batch
 

@@ -188,6 +188,24 @@ int mivae_nll_bwd(const void* logits, const int64_t* target, const float* lse, c
                   const float* dper_seq, void* dlogits, int64_t Bn, int64_t S, int64_t V,
                   float smoothing, int dtype, void* stream);
 
+/* ---- step-harness tail on flat buffers ---------------------------------------------------------- */
+/* Gradient clipping + Adam + zero_grad of DefaultTrainer._train_batch (training/trainers/trainer.py:286-289
+ * clip_grad_norm_ / clip_grad_value_, :359-367 optimizer.step() / zero_grad(), optimizer = torch.optim.Adam
+ * via nn/optimizer.py:11-33) over the flat parameter / gradient buckets of the DP reducer.
+ * mivae_sumsq_partial writes mivae_sumsq_blocks(n) fixed-order partial sums of g^2; the partial arrays of all
+ * buckets are laid out back to back.  mivae_adam_clip_step folds ALL npartial partials into the global norm
+ * (same order in every block), scales by min(1, max_norm / (norm + 1e-6)) (max_norm <= 0: off), clamps to
+ * +-max_value (<= 0: off), applies Adam (torch formula, L2 weight_decay) with step count *step + 1, writes
+ * p, m, v and zeroes g.  *step is advanced separately with mivae_scalar_add(step, 1) after all buckets.
+ * n must be a multiple of 4 floats, buffers 16-byte aligned.  norm_out may be NULL. */
+int64_t mivae_sumsq_blocks(int64_t n);
+int mivae_sumsq_partial(const float* g, float* partial, int64_t n, void* stream);
+int mivae_adam_clip_step(float* p, float* g, float* m, float* v, const float* partial, int64_t npartial,
+                         const float* step, float* norm_out, int64_t n, double lr, double beta1,
+                         double beta2, float eps, float weight_decay, float max_norm, float max_value,
+                         void* stream);
+int mivae_scalar_add(float* x, float delta, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,7 @@ P = ctypes.c_void_p
 I64 = ctypes.c_int64
 I32 = ctypes.c_int
 F32 = ctypes.c_float
+F64 = ctypes.c_double
 
 # name -> argument ctypes (every entry returns int status unless listed in _RET)
 SIGNATURES = {
@@ -40,6 +41,10 @@ SIGNATURES = {
     "mivae_elbo_bwd": [P, P, P, P, P, I64, I64, F32, F32, I32, P],
     "mivae_nll_fwd": [P, P, P, P, P, P, P, I64, I64, I64, F32, I32, P],
     "mivae_nll_bwd": [P, P, P, P, P, P, I64, I64, I64, F32, I32, P],
+    "mivae_sumsq_blocks": [I64],
+    "mivae_sumsq_partial": [P, P, I64, P],
+    "mivae_adam_clip_step": [P, P, P, P, P, I64, P, P, I64, F64, F64, F64, F32, F32, F32, F32, P],
+    "mivae_scalar_add": [P, F32, P],
     "mivae_nice_pack_bytes": [I64, I64, I32],
     "mivae_nice_pack": [P, P, I64, I64, I64, I32, I32, P],
     "mivae_nice_stack_fwd": [P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I32, I32, I32, F32, F32, I32, P],
@@ -52,6 +57,7 @@ _RET = {
     "mivae_last_error": ctypes.c_char_p,
     "mivae_col_workspace_floats": I64,
     "mivae_nice_pack_bytes": I64,
+    "mivae_sumsq_blocks": I64,
     "mivae_nice_stack_npad": I64,
     "mivae_nice_dw_workspace_floats": I64,
 }

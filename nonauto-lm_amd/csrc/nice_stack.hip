@@ -1043,32 +1043,40 @@ __global__ void __launch_bounds__(256) k_dw_partial(DwArgs a) {
 }
 
 __global__ void __launch_bounds__(256) k_dw_reduce(DwArgs a) {
-  // One thread per dumped accumulator element, in dump order: for a fixed slab consecutive threads read
-  // consecutive floats (coalesced); the slabs of one (step, net, type, row tile) are nslab consecutive
-  // dumps, summed in slab order (fixed order => bit-reproducible).  The permuted store is 4 B per lane
-  // but the outputs are only the weight shapes.
+  // A block of 4 waves owns 64 consecutive dumped accumulator elements (dump order: for a fixed slab, the
+  // 64 lanes of a wave read 64 consecutive floats); wave g sums slabs g, g+4, ... and the four partial sums
+  // are combined through LDS in wave order (fixed order => bit-reproducible).  The slabs of one (step, net,
+  // type, row tile) are nslab consecutive dumps.  The permuted store is 4 B per lane but the outputs are
+  // only the weight shapes.
+  __shared__ float red[4][64];
   const int64_t n1 = (int64_t)a.K * 2 * 2 * a.HC * a.HT * 1024;   // dumped elements per slab
+  const int64_t nblk1 = n1 / 64;
   const int64_t nb1 = (int64_t)a.K * 2 * a.H, nb2 = (int64_t)a.K * 2 * a.h;
-  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < n1) {
+  if ((int64_t)blockIdx.x < nblk1) {
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    int64_t idx = (int64_t)blockIdx.x * 64 + lane;
     const int e = (int)(idx & 1023); int64_t q = idx >> 10;
     const int t = (int)(q % a.HT); q /= a.HT;
     const int mt = (int)(q % a.HC); q /= a.HC;
     const int type = (int)(q & 1); const int kn = (int)(q >> 1);
-    const int r = e & 15, cl = e >> 4, cc = cl & 31, hh = cl >> 5;
-    const int row = 32 * mt + (r & 3) + 4 * hh + 8 * (r >> 2), col = 32 * t + cc;
-    if (row >= a.H || col >= a.h) return;
     const int64_t item0 = (((int64_t)kn * 2 + type) * a.HC + mt) * a.nslab;
     const float* p = a.part + (item0 * a.HT + t) * 1024 + e;
     const int64_t stride = (int64_t)a.HT * 1024;
     float s = 0.f;
-#pragma unroll 8
-    for (int sl = 0; sl < a.nslab; ++sl) s += p[sl * stride];
+#pragma unroll 4
+    for (int sl = grp; sl < a.nslab; sl += 4) s += p[sl * stride];
+    red[grp][lane] = s;
+    __syncthreads();
+    if (grp != 0) return;
+    s = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    const int r = e & 15, cl = e >> 4, cc = cl & 31, hh = cl >> 5;
+    const int row = 32 * mt + (r & 3) + 4 * hh + 8 * (r >> 2), col = 32 * t + cc;
+    if (row >= a.H || col >= a.h) return;
     if (type == 0) a.dW1[((int64_t)kn * a.H + row) * a.h + col] = s;
     else a.dW2[((int64_t)kn * a.h + col) * a.H + row] = s;
     return;
   }
-  idx -= n1;
+  int64_t idx = ((int64_t)blockIdx.x - nblk1) * blockDim.x + threadIdx.x;
   if (idx < nb1) {
     const int row = (int)(idx % a.H); const int kn = (int)(idx / a.H);
     const int64_t item0 = (((int64_t)kn * 2 + 0) * a.HC + row / 32) * a.nslab;
@@ -1293,8 +1301,8 @@ extern "C" int mivae_nice_dw(const void* Gt, const void* Ht, const void* dSt, co
                                : launch_dw<MmaF32, float>(g.HT, a, (hipStream_t)stream);
   MIVAE_REQUIRE(rc == 0, "nice_dw: no kernel instance");
   MIVAE_CHECK_LAUNCH("nice_dw_partial");
-  const int64_t nout = (int64_t)K * 2 * 2 * g.HC * g.HT * 1024 + (int64_t)K * 2 * (H + h);
-  k_dw_reduce<<<(unsigned)((nout + 255) / 256), 256, 0, (hipStream_t)stream>>>(a);
+  const int64_t nblk = (int64_t)K * 2 * 2 * g.HC * g.HT * 16 + ((int64_t)K * 2 * (H + h) + 255) / 256;
+  k_dw_reduce<<<(unsigned)nblk, 256, 0, (hipStream_t)stream>>>(a);
   MIVAE_CHECK_LAUNCH("nice_dw_reduce");
   return MIVAE_OK;
 }

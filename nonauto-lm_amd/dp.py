@@ -37,11 +37,16 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> N
 
 
 class GradReducer:
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 32 << 20, group=None):
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 32 << 20, group=None,
+                 flatten_params: bool = False):
+        """flatten_params: also move the parameters themselves into flat buffers with the buckets' layout
+        (p.data becomes a view; names, shapes and state-dict keys are unchanged), so that FusedAdam can update
+        a whole bucket in one kernel.  Call after the model is on its device; do not `.to()` it afterwards."""
         self.group = group
         self.world = world_size(group)
         self.params = [p for p in params if p.requires_grad]
         self.buckets: List[torch.Tensor] = []
+        self.flat_params: List[Optional[torch.Tensor]] = []
         self._bucket_of: Dict[int, int] = {}
         self._bucket_size: List[int] = []
         order = list(reversed(self.params))
@@ -64,6 +69,15 @@ class GradReducer:
                 offs.append(total)
                 total += (p.numel() + 63) // 64 * 64
             flat = torch.zeros(total, dtype=ps[0].dtype, device=ps[0].device)
+            pflat = None
+            if flatten_params:
+                pflat = torch.zeros(total, dtype=ps[0].dtype, device=ps[0].device)
+                with torch.no_grad():
+                    for p, o in zip(ps, offs):
+                        view = pflat[o:o + p.numel()].view_as(p)
+                        view.copy_(p.data)
+                        p.data = view
+            self.flat_params.append(pflat)
             for p, o in zip(ps, offs):
                 p.grad = flat[o:o + p.numel()].view_as(p)
                 self._bucket_of[id(p)] = bi
@@ -135,6 +149,66 @@ class GradReducer:
             for b in self.buckets:
                 b.clamp_(-max_value, max_value)
         return norm
+
+
+class FusedAdam:
+    """torch.optim.Adam (the reference's `Optimizer: "adam"`, nn/optimizer.py:11-33) + the two gradient clips
+    + zero_grad of DefaultTrainer._train_batch (trainer.py:286-289, 359-367) over the reducer's flat buckets:
+    two kernel launches per bucket (libmivae `mivae_sumsq_partial`, `mivae_adam_clip_step`) instead of four
+    multi-tensor walks over every parameter.  The step counter lives on the device, so the whole update can sit
+    inside a HIP graph.  Needs GradReducer(..., flatten_params=True) and fp32 parameters."""
+
+    def __init__(self, reducer: "GradReducer", lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.0, amsgrad: bool = False):
+        from . import _lib as L
+        if amsgrad:
+            raise NotImplementedError("FusedAdam: amsgrad is not supported")
+        if any(fp is None for fp in reducer.flat_params):
+            raise ValueError("FusedAdam needs GradReducer(..., flatten_params=True)")
+        if any(b.dtype != torch.float32 for b in reducer.buckets):
+            raise ValueError("FusedAdam: fp32 parameters only")
+        L.require_gpu(*reducer.buckets)
+        self._L = L
+        self.reducer = reducer
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        dev = reducer.buckets[0].device
+        self.exp_avg = [torch.zeros_like(b) for b in reducer.buckets]
+        self.exp_avg_sq = [torch.zeros_like(b) for b in reducer.buckets]
+        self.step_count = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._nblk = [L.query("mivae_sumsq_blocks", b.numel()) for b in reducer.buckets]
+        self._partial = torch.zeros(max(sum(self._nblk), 1), dtype=torch.float32, device=dev)
+
+    def step(self, max_norm: Optional[float] = None, max_value: Optional[float] = None) -> torch.Tensor:
+        """Clip (global L2 norm, then value), Adam update, zero the gradient buckets.  Returns the pre-clip
+        gradient norm as a device scalar."""
+        L = self._L
+        st = L.stream()
+        off = 0
+        for b, nb in zip(self.reducer.buckets, self._nblk):
+            L.call("mivae_sumsq_partial", L.ptr(b), self._partial.data_ptr() + 4 * off, b.numel(), st)
+            off += nb
+        for i, b in enumerate(self.reducer.buckets):
+            L.call("mivae_adam_clip_step", L.ptr(self.reducer.flat_params[i]), L.ptr(b), L.ptr(self.exp_avg[i]),
+                   L.ptr(self.exp_avg_sq[i]), L.ptr(self._partial), off, L.ptr(self.step_count),
+                   L.ptr(self.grad_norm) if i == 0 else None, b.numel(), self.lr, self.betas[0], self.betas[1],
+                   self.eps, self.weight_decay, float(max_norm or 0.0), float(max_value or 0.0), st)
+        L.call("mivae_scalar_add", L.ptr(self.step_count), 1.0, st)
+        return self.grad_norm
+
+    def zero_grad(self, set_to_none: bool = False) -> None:
+        self.reducer.zero_grad()
+
+    def state_dict(self):
+        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
+                "lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay}
+
+    def load_state_dict(self, sd) -> None:
+        self.step_count.copy_(sd["step"])
+        for dst, src in zip(self.exp_avg, sd["exp_avg"]):
+            dst.copy_(src)
+        for dst, src in zip(self.exp_avg_sq, sd["exp_avg_sq"]):
+            dst.copy_(src)
 
 
 class PackedScalars:

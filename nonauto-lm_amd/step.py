@@ -42,6 +42,9 @@ class TrainStep:
         return {k: info[k] for k in ("batch-loss", "batch-kl", "batch-nll")}
 
     def _update(self):
+        if isinstance(self.opt, dp.FusedAdam):      # clip + Adam + zero_grad in one pass over the flat buckets
+            self.opt.step(self.max_norm, self.max_value)
+            return
         self.reducer.clip_(self.max_norm, self.max_value)
         self.opt.step()
         self.reducer.zero_grad()

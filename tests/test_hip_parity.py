@@ -648,3 +648,43 @@ def test_train_step_graph_replay(M):
         losses[graph] = seq
     # same seed, same data, different RNG streams for eps: the two modes land in the same loss range
     assert abs(losses[True][-1] - losses[False][-1]) < 0.25 * abs(losses[False][0])
+
+
+@pytest.mark.parametrize("max_norm,max_value,wd", [(5.0, 2.0, 0.0), (0.05, None, 0.0), (None, 0.01, 0.01), (None, None, 0.0)])
+def test_fused_adam_matches_torch(M, max_norm, max_value, wd):
+    """dp.FusedAdam (clip_grad_norm_ + clip_grad_value_ + Adam + zero_grad in one pass over the flat buckets) vs
+    torch.nn.utils.clip_grad_* + torch.optim.Adam on the same gradients for 5 steps (trainer.py:286-289, 359-367)."""
+    from torch.nn.utils import clip_grad_norm_, clip_grad_value_
+    from nonauto_lm_amd import dp
+
+    def net():
+        torch.manual_seed(5)
+        return torch.nn.Sequential(torch.nn.Linear(37, 53), torch.nn.Tanh(), torch.nn.Linear(53, 11),
+                                   torch.nn.LayerNorm(11)).to(DEV)
+    ref, fused = net(), net()
+    opt_ref = torch.optim.Adam(ref.parameters(), lr=3e-3, weight_decay=wd)
+    reducer = dp.GradReducer(fused.parameters(), bucket_bytes=8 << 10, flatten_params=True)   # several buckets
+    assert len(reducer.buckets) > 1
+    opt = dp.FusedAdam(reducer, lr=3e-3, weight_decay=wd)
+    gen = torch.Generator().manual_seed(1)
+    for it in range(5):
+        x = dev(torch.randn(64, 37, generator=gen) * (1 + 3 * it))
+        (ref(x).pow(2).sum() * 0.1).backward()
+        # identical gradients on both sides: Adam's m / sqrt(v) turns ulp-level differences of near-zero
+        # gradients into full-size steps, so letting the two nets drift would test chaos, not the kernel
+        for a, b in zip(ref.parameters(), fused.parameters()):
+            b.grad.copy_(a.grad)
+        norm_ref = torch.linalg.vector_norm(torch.stack([p.grad.norm() for p in ref.parameters()]))
+        if max_norm is not None:
+            clip_grad_norm_(ref.parameters(), max_norm)
+        if max_value is not None:
+            clip_grad_value_(ref.parameters(), max_value)
+        opt_ref.step()
+        opt_ref.zero_grad()
+        reducer.finish()
+        norm = opt.step(max_norm, max_value)
+        assert rel_err(norm, norm_ref) < 1e-6
+        assert all(float(b.abs().max()) == 0.0 for b in reducer.buckets)
+        for (k, a), b in zip(ref.named_parameters(), fused.parameters()):
+            assert rel_err(b, a) < 2e-6, (it, k)
+    assert list(fused.state_dict()) == list(ref.state_dict())
