@@ -156,6 +156,11 @@ int mivae_actnorm_bwd(const void* dout, const void* z, const float* log_scale, c
 int mivae_actnorm_stats(const void* z, float* mean, float* std, float* workspace, int64_t rows,
                         int64_t D, int dtype, void* stream);
 
+/* out[c] = sum_rows x[row, c], fp32, fixed order: the bias gradient of a Linear over `rows` tokens (autograd of
+ * the posterior heads' torch.nn.Linear, posterior.py:19-27).  workspace: mivae_col_workspace_floats(rows, D). */
+int mivae_colsum(const void* x, float* out, float* workspace, int64_t rows, int64_t D, int dtype,
+                 void* stream);
+
 /* ---- KL / ELBO tail -------------------------------------------------------------------------------- */
 /* kl = clamp(logq - logp, min = free_bits) (clamp only if use_fb).  Replaces DefaultKLLoss.forward
  * nn/kl_loss.py:38-49 and _free_bits_kl :14-21. */

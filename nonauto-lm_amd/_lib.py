@@ -35,6 +35,7 @@ SIGNATURES = {
     "mivae_col_workspace_floats": [I64, I64, I32],
     "mivae_actnorm_bwd": [P, P, P, P, P, P, P, I64, I64, I64, I64, I32, P],
     "mivae_actnorm_stats": [P, P, P, P, I64, I64, I32, P],
+    "mivae_colsum": [P, P, P, I64, I64, I32, P],
     "mivae_kl_fwd": [P, P, P, I64, I32, F32, P],
     "mivae_kl_bwd": [P, P, P, P, P, I64, I32, F32, P],
     "mivae_elbo_fwd": [P, P, P, I64, I64, F32, F32, I32, P],

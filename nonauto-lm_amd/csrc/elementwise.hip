@@ -463,14 +463,25 @@ __global__ void k_col_partial(const T* __restrict__ x, const T* __restrict__ dou
   }
 }
 
-// out[v][c] = scale * sum_blocks partial[blk][v][c]; MODE_FIN 1: std = sqrt(sum / (rows - 1))
-__global__ void k_col_finish(const float* __restrict__ partial, float* __restrict__ out, int nblk,
-                             int nv, int D, float scale, int take_sqrt) {
-  int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= nv * D) return;
-  int v = idx / D, c = idx % D;
+// out[v][c] = scale * sum_blocks partial[blk][v][c]; take_sqrt: std = sqrt(sum / (rows - 1)).
+// A block of 4 waves owns 64 consecutive (v, c) outputs; wave g sums blocks g, g+4, ... (independent loads,
+// 16 in flight) and the four partial sums are combined through LDS in wave order (fixed order).
+__global__ void __launch_bounds__(256) k_col_finish(const float* __restrict__ partial, float* __restrict__ out,
+                                                    int nblk, int nv, int D, float scale, int take_sqrt) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + lane;
+  const int total = nv * D;
   float sum = 0.f;
-  for (int b = 0; b < nblk; ++b) sum += partial[((int64_t)b * nv + v) * D + c];
+  if (idx < total) {
+    const float* p = partial + idx;                 // partial[(b * nv + v) * D + c] = partial[b * total + idx]
+#pragma unroll 16
+    for (int b = grp; b < nblk; b += 4) sum += p[(int64_t)b * total];
+  }
+  red[grp][lane] = sum;
+  __syncthreads();
+  if (grp != 0 || idx >= total) return;
+  sum = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
   sum *= scale;
   out[idx] = take_sqrt ? sqrtf(sum) : sum;
 }
@@ -695,7 +706,7 @@ static ColCfg col_cfg(int64_t rows, int64_t D, int dtype, bool aligned) {
   int vmax = dtype == MIVAE_BF16 ? 8 : 4;
   c.vec = (aligned && D % vmax == 0) ? vmax : 1;
   c.L = lanes_per_row(D, c.vec);
-  int64_t nblk = (rows + 255) / 256;      // >= 256 rows per block
+  int64_t nblk = (rows + 63) / 64;        // >= 64 rows per block: 256 blocks at 16k tokens
   if (nblk > 1024) nblk = 1024;
   if (nblk < 1) nblk = 1;
   c.rows_per_block = (int)((rows + nblk - 1) / nblk);
@@ -884,7 +895,7 @@ extern "C" int mivae_actnorm_bwd(const void* dout, const void* z, const float* l
   DISPATCH_COL(dtype, c.vec, 2, z, dout, log_scale, mask, dz, workspace, rows, c.rows_per_block,
                c.nblk, (int)mask_div, (int)S, (int)D, c.L, S_(stream));
   MIVAE_CHECK_LAUNCH("actnorm_bwd");
-  unsigned grid = (unsigned)((2 * D + kBlock - 1) / kBlock);
+  unsigned grid = (unsigned)((2 * D + 63) / 64);
   k_col_finish<<<grid, kBlock, 0, S_(stream)>>>(workspace, dparams, c.nblk, 2, (int)D, 1.f, 0);
   MIVAE_CHECK_LAUNCH("actnorm_bwd_finish");
   return MIVAE_OK;
@@ -897,7 +908,7 @@ extern "C" int mivae_actnorm_stats(const void* z, float* mean, float* std, float
   MIVAE_REQUIRE(dtype == MIVAE_F32 || dtype == MIVAE_BF16, "actnorm_stats: bad dtype");
   MIVAE_REQUIRE(z && mean && std && workspace, "actnorm_stats: null pointer");
   ColCfg c = col_cfg(rows, D, dtype, aligned16(z));
-  unsigned grid = (unsigned)((D + kBlock - 1) / kBlock);
+  unsigned grid = (unsigned)((D + 63) / 64);
   DISPATCH_COL(dtype, c.vec, 0, z, nullptr, nullptr, nullptr, nullptr, workspace, rows,
                c.rows_per_block, c.nblk, 1, 1, (int)D, c.L, S_(stream));
   MIVAE_CHECK_LAUNCH("actnorm_stats_mean");
@@ -908,6 +919,23 @@ extern "C" int mivae_actnorm_stats(const void* z, float* mean, float* std, float
   k_col_finish<<<grid, kBlock, 0, S_(stream)>>>(workspace, std, c.nblk, 1, (int)D,
                                               1.f / (float)(rows - 1), 1);
   MIVAE_CHECK_LAUNCH("actnorm_stats_finish");
+  return MIVAE_OK;
+}
+
+// out[c] = sum over rows of x[row, c] (fp32 accumulation, fixed order): the bias gradient of a Linear layer
+// over many tokens (posterior heads a3, bracket projections).  workspace: mivae_col_workspace_floats.
+extern "C" int mivae_colsum(const void* x, float* out, float* workspace, int64_t rows, int64_t D, int dtype,
+                            void* stream) {
+  MIVAE_REQUIRE(rows >= 1 && D > 0 && D < (1ll << 31), "colsum: bad shape");
+  MIVAE_REQUIRE(dtype == MIVAE_F32 || dtype == MIVAE_BF16, "colsum: bad dtype");
+  MIVAE_REQUIRE(x && out && workspace, "colsum: null pointer");
+  ColCfg c = col_cfg(rows, D, dtype, aligned16(x));
+  DISPATCH_COL(dtype, c.vec, 0, x, nullptr, nullptr, nullptr, nullptr, workspace, rows, c.rows_per_block,
+               c.nblk, 1, 1, (int)D, c.L, S_(stream));
+  MIVAE_CHECK_LAUNCH("colsum_partial");
+  unsigned grid = (unsigned)((D + 63) / 64);
+  k_col_finish<<<grid, kBlock, 0, S_(stream)>>>(workspace, out, c.nblk, 1, (int)D, 1.f, 0);
+  MIVAE_CHECK_LAUNCH("colsum_finish");
   return MIVAE_OK;
 }
 

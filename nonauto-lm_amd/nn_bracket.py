@@ -50,7 +50,10 @@ class _SplitKLinearFn(torch.autograd.Function):
                 gw = g2.t().matmul(x2).float()
             gw = gw.to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = g2.sum(0, dtype=torch.float32).to(weight.dtype)
+            if g2.is_cuda and g2.dtype in (torch.float32, torch.bfloat16) and n >= 1024 and g2.size(1) <= 1024:
+                gb = ops.colsum(g2).to(weight.dtype)
+            else:
+                gb = g2.sum(0, dtype=torch.float32).to(weight.dtype)
         return gx, gw, gb
 
 

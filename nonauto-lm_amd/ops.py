@@ -304,6 +304,18 @@ def actnorm_stats(z) -> Tuple[torch.Tensor, torch.Tensor]:
     return mean, std
 
 
+def colsum(x: torch.Tensor) -> torch.Tensor:
+    """fp32 column sums of a (rows, D) fp32/bf16 matrix, fixed summation order (bias gradient of a Linear)."""
+    L.require_gpu(x)
+    x = x.contiguous()
+    rows, D = x.shape
+    code = L.dtype_code(x.dtype)
+    out = torch.empty(D, dtype=torch.float32, device=x.device)
+    ws = torch.empty(L.query("mivae_col_workspace_floats", rows, D, code), dtype=torch.float32, device=x.device)
+    L.call("mivae_colsum", L.ptr(x), L.ptr(out), L.ptr(ws), rows, D, code, L.stream())
+    return out
+
+
 # ----------------------------------------------------------------------------------- KL / ELBO
 class _KL(torch.autograd.Function):
     @staticmethod

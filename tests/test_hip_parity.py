@@ -688,3 +688,14 @@ def test_fused_adam_matches_torch(M, max_norm, max_value, wd):
         for (k, a), b in zip(ref.named_parameters(), fused.parameters()):
             assert rel_err(b, a) < 2e-6, (it, k)
     assert list(fused.state_dict()) == list(ref.state_dict())
+
+
+@pytest.mark.parametrize("rows,D,dtype", [(16384, 64, torch.bfloat16), (4096, 128, torch.float32), (1000, 37, torch.float32),
+                                          (3, 8, torch.bfloat16), (2048, 1000, torch.bfloat16)])
+def test_colsum(M, rows, D, dtype):
+    """mivae_colsum (bias gradient of a Linear over many tokens) vs a float64 column sum."""
+    x = (torch.randn(rows, D, generator=torch.Generator().manual_seed(rows + D)) * 3).to(dtype)
+    got = M.ops.colsum(dev(x))
+    ref = x.double().sum(0)
+    assert got.dtype == torch.float32
+    assert float((got.cpu().double() - ref).abs().max()) <= 1e-5 * float(x.double().abs().sum(0).max())
