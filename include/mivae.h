@@ -193,6 +193,20 @@ int mivae_nll_bwd(const void* logits, const int64_t* target, const float* lse, c
                   const float* dper_seq, void* dlogits, int64_t Bn, int64_t S, int64_t V,
                   float smoothing, int dtype, void* stream);
 
+/* ---- LayerNorm (pre-norm sublayers of the attention coupling / transformer bracket) ------------------ */
+/* y = (x - mean) * rstd * gamma + beta over the last axis (torch.nn.LayerNorm inside SublayerConnection,
+ * nn/transformer.py:147-162; used by AttentionCoupling, couplings.py:54-81).  x (rows, D) in in_dtype, y in
+ * out_dtype (bf16 output from the fp32 residual stream saves the cast before the next projection); mean, rstd
+ * (rows) fp32 are kept for the backward.  D <= 1024 (multiple of 4, aligned) or <= 256 otherwise. */
+int mivae_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                        float* rstd, int64_t rows, int64_t D, float eps, int in_dtype, int out_dtype,
+                        void* stream);
+int64_t mivae_layernorm_workspace_floats(int64_t rows, int64_t D);
+/* dx (in_dtype) and dgamma_dbeta = [dgamma (D) | dbeta (D)] from dy (out_dtype); fixed-order reductions. */
+int mivae_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                        const float* rstd, void* dx, float* dgamma_dbeta, float* workspace, int64_t rows,
+                        int64_t D, int in_dtype, int out_dtype, void* stream);
+
 /* ---- step-harness tail on flat buffers ---------------------------------------------------------- */
 /* Gradient clipping + Adam + zero_grad of DefaultTrainer._train_batch (training/trainers/trainer.py:286-289
  * clip_grad_norm_ / clip_grad_value_, :359-367 optimizer.step() / zero_grad(), optimizer = torch.optim.Adam

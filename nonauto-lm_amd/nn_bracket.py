@@ -193,12 +193,29 @@ class PositionwiseFeedForward(torch.nn.Module):
         return self._w_2(self._dropout(torch.relu(self._w_1(x))))
 
 
+class LayerNorm(torch.nn.LayerNorm):
+    """torch.nn.LayerNorm (same parameters / state-dict keys) on the libmivae row kernels when the input is a
+    GPU fp32/bf16 tensor; under bf16 autocast the output is written as bf16 directly (the next op is always a
+    projection), otherwise in the input's dtype.  Anything else falls through to the stock op."""
+
+    def forward(self, x):
+        D = x.size(-1)
+        if (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and self.elementwise_affine
+                and self.bias is not None and len(self.normalized_shape) == 1 and D % 4 == 0
+                and D <= ops.LAYERNORM_MAX_D and self.weight.dtype == torch.float32 and x.numel() > 0):
+            out_dtype = x.dtype
+            if torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+                out_dtype = torch.bfloat16
+            return ops.layer_norm(x, self.weight, self.bias, self.eps, out_dtype)
+        return super().forward(x)
+
+
 class SublayerConnection(torch.nn.Module):
     """Pre-norm residual (nn/transformer.py:147-162)."""
 
     def __init__(self, input_size, dropout=0.1):
         super().__init__()
-        self._norm = torch.nn.LayerNorm(input_size)
+        self._norm = LayerNorm(input_size)
         self._dropout = _maybe_dropout(dropout)
 
     def forward(self, x, sublayer):

@@ -304,6 +304,43 @@ def actnorm_stats(z) -> Tuple[torch.Tensor, torch.Tensor]:
     return mean, std
 
 
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_dtype):
+        D = x.size(-1)
+        x2 = x.contiguous().view(-1, D)
+        rows = x2.size(0)
+        y = torch.empty(rows, D, dtype=out_dtype, device=x.device)
+        stats = torch.empty(2, rows, dtype=torch.float32, device=x.device)
+        L.call("mivae_layernorm_fwd", L.ptr(x2), L.ptr(weight), L.ptr(bias), L.ptr(y), L.ptr(stats[0]), L.ptr(stats[1]),
+               rows, D, float(eps), L.dtype_code(x2.dtype), L.dtype_code(out_dtype), L.stream())
+        ctx.save_for_backward(x2, weight, stats)
+        ctx.shape = x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, stats = ctx.saved_tensors
+        rows, D = x2.shape
+        dy2 = dy.contiguous().view(rows, D)
+        dx = torch.empty_like(x2)
+        dgb = torch.empty(2, D, dtype=torch.float32, device=x2.device)
+        ws = torch.empty(L.query("mivae_layernorm_workspace_floats", rows, D), dtype=torch.float32, device=x2.device)
+        L.call("mivae_layernorm_bwd", L.ptr(dy2), L.ptr(x2), L.ptr(weight), L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(dx),
+               L.ptr(dgb), L.ptr(ws), rows, D, L.dtype_code(x2.dtype), L.dtype_code(dy2.dtype), L.stream())
+        return dx.view(ctx.shape), dgb[0], dgb[1], None, None
+
+
+LAYERNORM_MAX_D = 1024
+
+
+def layer_norm(x, weight, bias, eps: float = 1e-5, out_dtype=None):
+    """torch.nn.functional.layer_norm over the last axis (fp32 affine parameters); `out_dtype` lets the fp32
+    residual stream be normalised straight into bf16 for the projection that follows."""
+    L.require_gpu(x, weight, bias)
+    return _LayerNorm.apply(x, weight, bias, eps, out_dtype or x.dtype)
+
+
 def colsum(x: torch.Tensor) -> torch.Tensor:
     """fp32 column sums of a (rows, D) fp32/bf16 matrix, fixed summation order (bias gradient of a Linear)."""
     L.require_gpu(x)

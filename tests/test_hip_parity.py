@@ -699,3 +699,28 @@ def test_colsum(M, rows, D, dtype):
     ref = x.double().sum(0)
     assert got.dtype == torch.float32
     assert float((got.cpu().double() - ref).abs().max()) <= 1e-5 * float(x.double().abs().sum(0).max())
+
+
+@pytest.mark.parametrize("shape,in_dt,out_dt", [((256, 64, 64), torch.float32, torch.float32), ((37, 5, 64), torch.float32, torch.bfloat16),
+                                                ((19, 256), torch.bfloat16, torch.bfloat16), ((7, 3, 512), torch.float32, torch.float32),
+                                                ((5, 1024), torch.float32, torch.bfloat16), ((300, 8), torch.float32, torch.float32),
+                                                ((1, 1, 4), torch.bfloat16, torch.float32)])
+def test_layer_norm_vs_torch(M, shape, in_dt, out_dt):
+    """libmivae LayerNorm (nn/transformer.py:147-162 pre-norm) vs torch.nn.functional.layer_norm in float64."""
+    gen = torch.Generator().manual_seed(sum(shape))
+    D = shape[-1]
+    x = (torch.randn(*shape, generator=gen) * 2 + 0.5).to(in_dt)
+    w, b = torch.randn(D, generator=gen), torch.randn(D, generator=gen)
+    cot = torch.randn(*shape, generator=gen).to(out_dt)
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (D,), wr, br, 1e-5)
+    (ref * cot.double()).sum().backward()
+    xg, wg, bg = dev(x).requires_grad_(True), dev(w).requires_grad_(True), dev(b).requires_grad_(True)
+    got = M.ops.layer_norm(xg, wg, bg, 1e-5, out_dt)
+    (got.float() * dev(cot).float()).sum().backward()
+    assert got.dtype == out_dt and xg.grad.dtype == in_dt
+    tol_o = TOL if out_dt == torch.float32 else 4e-3
+    tol_i = TOL if in_dt == torch.float32 else 4e-3
+    assert rel_err(got.float(), ref) < tol_o
+    assert rel_err(xg.grad.float(), xr.grad) < max(tol_i, 2e-5)
+    assert rel_err(wg.grad, wr.grad) < 2e-5 and rel_err(bg.grad, br.grad) < 2e-5
