@@ -215,11 +215,12 @@ int mivae_layernorm_bwd(const void* dy, const void* x, const float* gamma, const
  * buckets are laid out back to back.  mivae_adam_clip_step folds ALL npartial partials into the global norm
  * (same order in every block), scales by min(1, max_norm / (norm + 1e-6)) (max_norm <= 0: off), clamps to
  * +-max_value (<= 0: off), applies Adam (torch formula, L2 weight_decay) with step count *step + 1, writes
- * p, m, v and zeroes g.  *step is advanced separately with mivae_scalar_add(step, 1) after all buckets.
+ * p, m, v (and, when p_bf16 is not NULL, a bf16 copy of the new p: the shadow the bf16 forward reads, so no
+ * per-layer weight casts are needed) and zeroes g.  *step is advanced separately with mivae_scalar_add(step, 1) after all buckets.
  * n must be a multiple of 4 floats, buffers 16-byte aligned.  norm_out may be NULL. */
 int64_t mivae_sumsq_blocks(int64_t n);
 int mivae_sumsq_partial(const float* g, float* partial, int64_t n, void* stream);
-int mivae_adam_clip_step(float* p, float* g, float* m, float* v, const float* partial, int64_t npartial,
+int mivae_adam_clip_step(float* p, void* p_bf16, float* g, float* m, float* v, const float* partial, int64_t npartial,
                          const float* step, float* norm_out, int64_t n, double lr, double beta1,
                          double beta2, float eps, float weight_decay, float max_norm, float max_value,
                          void* stream);

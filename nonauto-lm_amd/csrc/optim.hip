@@ -50,6 +50,7 @@ __global__ __launch_bounds__(kBlock) void k_sumsq_partial(const float* __restric
 
 struct AdamArgs {
   float *p, *g, *m, *v;
+  unsigned short* p16;    // optional bf16 shadow of p (the copy the bf16 forward reads), or null
   const float* partial;   // sums of squares over ALL buckets
   const float* step;      // device scalar: number of steps taken so far
   float* norm_out;        // optional: total gradient norm (written by block 0)
@@ -93,6 +94,10 @@ __global__ __launch_bounds__(kBlock) void k_adam_clip(AdamArgs a) {
     }
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     *reinterpret_cast<f32x4*>(a.p + i) = p;
+    if (a.p16) {
+      u16x4 q = {f32_to_bf16(p[0]), f32_to_bf16(p[1]), f32_to_bf16(p[2]), f32_to_bf16(p[3])};
+      *reinterpret_cast<u16x4*>(a.p16 + i) = q;
+    }
     *reinterpret_cast<f32x4*>(a.m + i) = m;
     *reinterpret_cast<f32x4*>(a.v + i) = v;
     *reinterpret_cast<f32x4*>(a.g + i) = zero;                               // optimizer.zero_grad()
@@ -123,7 +128,7 @@ extern "C" int mivae_sumsq_partial(const float* g, float* partial, int64_t n, vo
   return MIVAE_OK;
 }
 
-extern "C" int mivae_adam_clip_step(float* p, float* g, float* m, float* v, const float* partial,
+extern "C" int mivae_adam_clip_step(float* p, void* p_bf16, float* g, float* m, float* v, const float* partial,
                                     int64_t npartial, const float* step, float* norm_out, int64_t n, double lr,
                                     double beta1, double beta2, float eps, float weight_decay, float max_norm,
                                     float max_value, void* stream) {
@@ -134,7 +139,7 @@ extern "C" int mivae_adam_clip_step(float* p, float* g, float* m, float* v, cons
                 "adam_clip_step: buffers must be 16-byte aligned and padded to a multiple of 4 floats");
   MIVAE_REQUIRE(lr >= 0. && beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1. && eps >= 0.f,
                 "adam_clip_step: bad hyper-parameters");
-  AdamArgs a = {p, g, m, v, partial, step, norm_out, n, (int)npartial, lr, beta1, beta2, eps, weight_decay,
+  AdamArgs a = {p, g, m, v, static_cast<unsigned short*>(p_bf16), partial, step, norm_out, n, (int)npartial, lr, beta1, beta2, eps, weight_decay,
                 max_norm, max_value};
   int64_t blocks = (n / 4 + kBlock - 1) / kBlock;
   if (blocks > 2048) blocks = 2048;

@@ -159,7 +159,7 @@ class FusedAdam:
     inside a HIP graph.  Needs GradReducer(..., flatten_params=True) and fp32 parameters."""
 
     def __init__(self, reducer: "GradReducer", lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 0.0, amsgrad: bool = False):
+                 weight_decay: float = 0.0, amsgrad: bool = False, bf16_shadow: bool = False):
         from . import _lib as L
         if amsgrad:
             raise NotImplementedError("FusedAdam: amsgrad is not supported")
@@ -178,6 +178,23 @@ class FusedAdam:
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self._nblk = [L.query("mivae_sumsq_blocks", b.numel()) for b in reducer.buckets]
         self._partial = torch.zeros(max(sum(self._nblk), 1), dtype=torch.float32, device=dev)
+        # bf16_shadow: the update kernel also writes a bf16 copy of every parameter; each parameter gets a
+        # `_mivae_lp` view into it, which nn_bracket.Linear uses as its compute copy under bf16 autocast
+        # (no per-layer weight casts).  After loading weights by any other route call refresh_shadow().
+        self.shadow = None
+        if bf16_shadow:
+            self.shadow = [torch.empty(b.numel(), dtype=torch.bfloat16, device=dev) for b in reducer.buckets]
+            for p in reducer.params:
+                bi = reducer._bucket_of[id(p)]
+                off = (p.data_ptr() - reducer.flat_params[bi].data_ptr()) // 4
+                p._mivae_lp = self.shadow[bi][off:off + p.numel()].view_as(p)
+            self.refresh_shadow()
+
+    def refresh_shadow(self) -> None:
+        if self.shadow is not None:
+            with torch.no_grad():
+                for sh, fp in zip(self.shadow, self.reducer.flat_params):
+                    sh.copy_(fp)
 
     def step(self, max_norm: Optional[float] = None, max_value: Optional[float] = None) -> torch.Tensor:
         """Clip (global L2 norm, then value), Adam update, zero the gradient buckets.  Returns the pre-clip
@@ -189,7 +206,8 @@ class FusedAdam:
             L.call("mivae_sumsq_partial", L.ptr(b), self._partial.data_ptr() + 4 * off, b.numel(), st)
             off += nb
         for i, b in enumerate(self.reducer.buckets):
-            L.call("mivae_adam_clip_step", L.ptr(self.reducer.flat_params[i]), L.ptr(b), L.ptr(self.exp_avg[i]),
+            L.call("mivae_adam_clip_step", L.ptr(self.reducer.flat_params[i]),
+                   None if self.shadow is None else L.ptr(self.shadow[i]), L.ptr(b), L.ptr(self.exp_avg[i]),
                    L.ptr(self.exp_avg_sq[i]), L.ptr(self._partial), off, L.ptr(self.step_count),
                    L.ptr(self.grad_norm) if i == 0 else None, b.numel(), self.lr, self.betas[0], self.betas[1],
                    self.eps, self.weight_decay, float(max_norm or 0.0), float(max_value or 0.0), st)

@@ -24,10 +24,16 @@ class _SplitKLinearFn(torch.autograd.Function):
     Same arithmetic, different (fixed) summation order."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
+    def forward(ctx, x, weight, bias, w_lp, b_lp):
+        # w_lp / b_lp: low-precision compute copies of the fp32 parameters (bf16 autocast), or None.  The
+        # gradients go straight to the fp32 parameters in fp32 (no cast nodes, no bf16 rounding of dW).
+        w = weight if w_lp is None else w_lp
+        b = bias if b_lp is None else b_lp
+        ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
-        return F.linear(x, weight, bias)
+        ctx.param_dtype = weight.dtype
+        with torch.autocast("cuda", enabled=False):
+            return F.linear(x, w, b)
 
     @staticmethod
     def backward(ctx, gy):
@@ -48,13 +54,13 @@ class _SplitKLinearFn(torch.autograd.Function):
                 gw = torch.bmm(g2.view(G, n // G, -1).transpose(1, 2), x2.view(G, n // G, -1)).sum(0, dtype=torch.float32)
             else:
                 gw = g2.t().matmul(x2).float()
-            gw = gw.to(weight.dtype)
+            gw = gw.to(ctx.param_dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             if g2.is_cuda and g2.dtype in (torch.float32, torch.bfloat16) and n >= 1024 and g2.size(1) <= 1024:
-                gb = ops.colsum(g2).to(weight.dtype)
+                gb = ops.colsum(g2).to(ctx.param_dtype)
             else:
-                gb = g2.sum(0, dtype=torch.float32).to(weight.dtype)
-        return gx, gw, gb
+                gb = g2.sum(0, dtype=torch.float32).to(ctx.param_dtype)
+        return gx, gw, gb, None, None
 
 
 class Linear(torch.nn.Linear):
@@ -64,9 +70,17 @@ class Linear(torch.nn.Linear):
     def forward(self, x):
         if x.is_cuda and torch.is_grad_enabled() and x.numel() // x.size(-1) >= 4096 and self.out_features <= 512:
             if torch.is_autocast_enabled():
-                dt = torch.get_autocast_gpu_dtype()
-                return _SplitKLinearFn.apply(x.to(dt), self.weight.to(dt), None if self.bias is None else self.bias.to(dt))
-            return _SplitKLinearFn.apply(x, self.weight, self.bias)
+                dt = torch.get_autocast_dtype("cuda")
+                w_lp = getattr(self.weight, "_mivae_lp", None)        # bf16 shadow kept by dp.FusedAdam
+                if w_lp is None or w_lp.dtype != dt:
+                    w_lp = self.weight.detach().to(dt)
+                b_lp = None
+                if self.bias is not None:
+                    b_lp = getattr(self.bias, "_mivae_lp", None)
+                    if b_lp is None or b_lp.dtype != dt:
+                        b_lp = self.bias.detach().to(dt)
+                return _SplitKLinearFn.apply(x.to(dt), self.weight, self.bias, w_lp, b_lp)
+            return _SplitKLinearFn.apply(x, self.weight, self.bias, None, None)
         return super().forward(x)
 
 

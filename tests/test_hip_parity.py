@@ -665,7 +665,7 @@ def test_fused_adam_matches_torch(M, max_norm, max_value, wd):
     opt_ref = torch.optim.Adam(ref.parameters(), lr=3e-3, weight_decay=wd)
     reducer = dp.GradReducer(fused.parameters(), bucket_bytes=8 << 10, flatten_params=True)   # several buckets
     assert len(reducer.buckets) > 1
-    opt = dp.FusedAdam(reducer, lr=3e-3, weight_decay=wd)
+    opt = dp.FusedAdam(reducer, lr=3e-3, weight_decay=wd, bf16_shadow=True)
     gen = torch.Generator().manual_seed(1)
     for it in range(5):
         x = dev(torch.randn(64, 37, generator=gen) * (1 + 3 * it))
@@ -687,6 +687,7 @@ def test_fused_adam_matches_torch(M, max_norm, max_value, wd):
         assert all(float(b.abs().max()) == 0.0 for b in reducer.buckets)
         for (k, a), b in zip(ref.named_parameters(), fused.parameters()):
             assert rel_err(b, a) < 2e-6, (it, k)
+            assert torch.equal(b._mivae_lp, b.detach().to(torch.bfloat16)), k     # bf16 shadow written by the kernel
     assert list(fused.state_dict()) == list(ref.state_dict())
 
 
