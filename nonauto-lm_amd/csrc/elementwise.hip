@@ -486,6 +486,28 @@ __global__ void __launch_bounds__(256) k_col_finish(const float* __restrict__ pa
   out[idx] = take_sqrt ? sqrtf(sum) : sum;
 }
 
+// Column sums of a short, wide matrix (rows <= a few hundred, e.g. the G split-K partials of a weight
+// gradient): 4 waves split the rows of 64 consecutive columns, combined through LDS in wave order.
+template <typename T>
+__global__ void __launch_bounds__(256) k_colsum_short(const T* __restrict__ x, float* __restrict__ out, int rows,
+                                                      int64_t D) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + lane;
+  float sum = 0.f;
+  if (c < D) {
+#pragma unroll 16
+    for (int r = grp; r < rows; r += 4) {
+      float v[1];
+      RowIO<T, 1>::load(x + (int64_t)r * D + c, v);
+      sum += v[0];
+    }
+  }
+  red[grp][lane] = sum;
+  __syncthreads();
+  if (grp == 0 && c < D) out[c] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+}
+
 // ------------------------------------------------------------------------------------------------
 // a16: DefaultKLLoss (kl_loss.py:38-49): kl = clamp(logq - logp, min=free_bits)
 __global__ void k_kl_fwd(const float* __restrict__ logq, const float* __restrict__ logp,
@@ -929,6 +951,13 @@ extern "C" int mivae_colsum(const void* x, float* out, float* workspace, int64_t
   MIVAE_REQUIRE(rows >= 1 && D > 0 && D < (1ll << 31), "colsum: bad shape");
   MIVAE_REQUIRE(dtype == MIVAE_F32 || dtype == MIVAE_BF16, "colsum: bad dtype");
   MIVAE_REQUIRE(x && out && workspace, "colsum: null pointer");
+  if (rows <= 512) {   // short and wide: one pass, no workspace traffic
+    unsigned g = (unsigned)((D + 63) / 64);
+    if (dtype == MIVAE_BF16) k_colsum_short<unsigned short><<<g, kBlock, 0, S_(stream)>>>((const unsigned short*)x, out, (int)rows, D);
+    else k_colsum_short<float><<<g, kBlock, 0, S_(stream)>>>((const float*)x, out, (int)rows, D);
+    MIVAE_CHECK_LAUNCH("colsum_short");
+    return MIVAE_OK;
+  }
   ColCfg c = col_cfg(rows, D, dtype, aligned16(x));
   DISPATCH_COL(dtype, c.vec, 0, x, nullptr, nullptr, nullptr, nullptr, workspace, rows, c.rows_per_block,
                c.nblk, 1, 1, (int)D, c.L, S_(stream));

@@ -51,7 +51,11 @@ class _SplitKLinearFn(torch.autograd.Function):
             while G < 128 and n % (2 * G) == 0 and n // (2 * G) >= 128:
                 G *= 2
             if G > 1:
-                gw = torch.bmm(g2.view(G, n // G, -1).transpose(1, 2), x2.view(G, n // G, -1)).sum(0, dtype=torch.float32)
+                part = torch.bmm(g2.view(G, n // G, -1).transpose(1, 2), x2.view(G, n // G, -1))
+                if part.is_cuda and part.dtype in (torch.float32, torch.bfloat16):
+                    gw = ops.colsum(part.view(G, -1)).view(part.shape[1:])      # fp32 G-way sum, fixed order
+                else:
+                    gw = part.sum(0, dtype=torch.float32)
             else:
                 gw = g2.t().matmul(x2).float()
             gw = gw.to(ctx.param_dtype)

@@ -692,7 +692,8 @@ def test_fused_adam_matches_torch(M, max_norm, max_value, wd):
 
 
 @pytest.mark.parametrize("rows,D,dtype", [(16384, 64, torch.bfloat16), (4096, 128, torch.float32), (1000, 37, torch.float32),
-                                          (3, 8, torch.bfloat16), (2048, 1000, torch.bfloat16)])
+                                          (3, 8, torch.bfloat16), (2048, 1000, torch.bfloat16),
+                                          (128, 4096, torch.bfloat16), (500, 70, torch.float32)])
 def test_colsum(M, rows, D, dtype):
     """mivae_colsum (bias gradient of a Linear over many tokens) vs a float64 column sum."""
     x = (torch.randn(rows, D, generator=torch.Generator().manual_seed(rows + D)) * 3).to(dtype)
