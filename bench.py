@@ -303,7 +303,7 @@ def main():
                        "global_batch": world * B, "seq_len": S, "latent_dim": D, "flow_steps": K,
                        "parallelism": f"dp{world}"},
             "roofline": roofline, "kernels": kern, "kernel_timing": kernel_timing,
-            "step_mode": "eager" if args.eager else "hipgraph-replay", "cpu_baseline": cpu, "final_loss": round(loss, 4),
+            "step_mode": "hipgraph-replay" if train_step.graph_a is not None else "eager", "cpu_baseline": cpu, "final_loss": round(loss, 4),
         }
         print(json.dumps(line), flush=True)
     if world > 1:

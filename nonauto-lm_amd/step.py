@@ -66,12 +66,22 @@ class TrainStep:
                 self._update()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.graph_a = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_a):
-            self.info = self._fwd_bwd()
-        self.graph_b = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
-            self._update()
+        # thread_local: RCCL's watchdog thread may query events while this thread captures
+        try:
+            graph_a = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph_a, capture_error_mode="thread_local"):
+                self.info = self._fwd_bwd()
+            graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph_b, pool=graph_a.pool(), capture_error_mode="thread_local"):
+                self._update()
+            self.graph_a, self.graph_b = graph_a, graph_b
+        except RuntimeError as err:                 # keep training: same step, launched eagerly
+            import sys
+            print(f"[TrainStep] HIP-graph capture failed ({err}); falling back to eager launches", file=sys.stderr)
+            torch.cuda.synchronize()
+            self.graph_a = self.graph_b = None
+            self.reducer.overlap = True
+            self.reducer.zero_grad()
 
     # ---- one step -------------------------------------------------------------------------------
     def __call__(self) -> Dict[str, torch.Tensor]:
