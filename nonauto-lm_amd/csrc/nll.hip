@@ -215,3 +215,312 @@ extern "C" int mivae_nll_bwd(const void* logits, const int64_t* target, const fl
   MIVAE_CHECK_LAUNCH("nll_bwd");
   return MIVAE_OK;
 }
+
+// =====================================================================================================
+// Fused vocabulary projection + NLL ("lce"): logits = h W^T + b are produced tile by tile on the
+// matrix cores and consumed in registers -- the (N, V) logits are never written to HBM.
+//   NonAutoModel.decode: logits = self._vocab_projection(decoded)      (nonauto_lm/model.py:105-112)
+//   LabelSmoothingNLL.forward on those logits                           (models/base/losses.py:128-169)
+// bf16 operands, fp32 accumulation (v_mfma_f32_32x32x16_bf16): products of bf16 values are exact in fp32, so the
+// logits equal an fp32 GEMM of the same rounded operands up to summation order.
+//   forward : a wave owns 32 tokens x a slice of the vocabulary; per 32-row vocabulary chunk one accumulator
+//             tile (rows = vocabulary in registers, columns = tokens on lanes), online max / sum-exp per lane,
+//             target logit picked by row compare; partial (max, sum, sum x, x_t) per token and slice, combined
+//             by k_lce_combine.  VALU (v_exp_f32) bound: N V exponentials.
+//   backward: recomputes the tile, forms coef (softmax - q) and writes d logits (bf16) through a per-wave LDS
+//             transpose as 128-byte row segments; the two dense products with d logits (d h, d W) stay library
+//             GEMMs.  HBM: N V e written, nothing of that size read.
+namespace {
+
+typedef __bf16 lce_bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ int lce_row(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
+
+// accumulator tile initialised with the bias of vocabulary rows 32 c .. 32 c + 31
+__device__ __forceinline__ f32x16 lce_bias_tile(const float* __restrict__ bias, int c, int hh) {
+  f32x16 a;
+  if (bias) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(bias + 32 * c + 8 * q + 4 * hh);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[4 * q + i] = v[i];
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = 0.f;
+  }
+  return a;
+}
+
+template <int NKS>
+__device__ __forceinline__ void lce_load_w(const unsigned short* __restrict__ W, int c, int r32, int hh,
+                                           lce_bf16x8 (&f)[NKS]) {
+  const unsigned short* p = W + (int64_t)(32 * c + r32) * (16 * NKS) + 8 * hh;
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) f[ks] = *reinterpret_cast<const lce_bf16x8*>(p + 16 * ks);
+}
+
+template <int NKS>
+__device__ __forceinline__ f32x16 lce_tile(const lce_bf16x8 (&wf)[NKS], const lce_bf16x8 (&hf)[NKS], f32x16 acc) {
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], hf[ks], acc, 0, 0, 0);
+  return acc;
+}
+
+struct LceArgs {
+  const unsigned short* h;      // (N, E) bf16
+  const unsigned short* W;      // (V, E) bf16
+  const float* bias;            // (V) or null
+  const int64_t* target;        // (N)
+  const float* weights;         // (N)           [fwd]
+  f32x4* partial;               // (VS, N) {max2, sum, sum x, x_t}   [fwd]
+  const float* lse;             // (N)           [bwd]
+  const float* tokscale;        // (N)           [bwd]
+  const float* dper;            // (Bn)          [bwd]
+  unsigned short* dlogits;      // (N, V) bf16   [bwd]
+  int64_t N;
+  int S, V, per;                // per: chunks (fwd) or chunk pairs (bwd) per vocabulary slice
+  float smoothing;
+};
+
+template <int NKS>
+__global__ __launch_bounds__(256) void k_lce_fwd(LceArgs a) {
+  const int lane = threadIdx.x & 63, r32 = lane & 31, hh = lane >> 5;
+  const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t tok = tile * 32 + r32;
+  const bool valid = tok < a.N;
+  const float w = valid ? a.weights[tok] : 0.f;
+  f32x4* out = a.partial + (int64_t)blockIdx.y * a.N + tok;
+  if (!__any(w != 0.f)) {                     // tile of padding tokens: nothing is read (wave-uniform)
+    if (valid && hh == 0) { const f32x4 z = {-INFINITY, 0.f, 0.f, 0.f}; *out = z; }
+    return;
+  }
+  lce_bf16x8 hf[NKS];
+  {
+    const unsigned short* hp = a.h + (valid ? tok : 0) * (16 * NKS) + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) hf[ks] = *reinterpret_cast<const lce_bf16x8*>(hp + 16 * ks);
+  }
+  const int t = valid ? (int)a.target[tok] : -1;
+  const int nch = a.V >> 5;
+  const int c0 = blockIdx.y * a.per;
+  int c1 = c0 + a.per;
+  if (c1 > nch) c1 = nch;
+  float m = -INFINITY, s = 0.f, sx = 0.f, xt = 0.f;
+  lce_bf16x8 wf[NKS], wn[NKS];
+  if (c0 < c1) lce_load_w<NKS>(a.W, c0, r32, hh, wf);
+  for (int c = c0; c < c1; ++c) {
+    if (c + 1 < c1) lce_load_w<NKS>(a.W, c + 1, r32, hh, wn);      // next chunk in flight under this one's math
+    const f32x16 x = lce_tile<NKS>(wf, hf, lce_bias_tile(a.bias, c, hh));
+    float cm = x[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) cm = fmaxf(cm, x[r]);
+    const float mn = fmaxf(m, cm * kLog2e);
+    float acc = 0.f;
+    const int rel = t - 32 * c - 4 * hh;      // row of the target inside this lane's 16 rows, if any
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc += ex2(fmaf(x[r], kLog2e, -mn));
+      sx += x[r];
+      xt += (rel == (r & 3) + 8 * (r >> 2)) ? x[r] : 0.f;
+    }
+    s = fmaf(s, ex2(m - mn), acc);
+    m = mn;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) wf[ks] = wn[ks];
+  }
+  // the two half-waves hold the two row halves of the same token column
+  const float mo = __shfl_xor(m, 32, 64), so = __shfl_xor(s, 32, 64);
+  const float M = fmaxf(m, mo);
+  s = (m == -INFINITY ? 0.f : s * ex2(m - M)) + (mo == -INFINITY ? 0.f : so * ex2(mo - M));
+  sx += __shfl_xor(sx, 32, 64);
+  xt += __shfl_xor(xt, 32, 64);
+  if (valid && hh == 0) { const f32x4 o = {M, s, sx, xt}; *out = o; }
+}
+
+// tok_nll[r] = w_r * nll_r and lse[r] from the per-slice partials (slices folded in slice order)
+__global__ __launch_bounds__(256) void k_lce_combine(const f32x4* __restrict__ partial, const float* __restrict__ weights,
+                                                      float* __restrict__ tok_nll, float* __restrict__ lse_out,
+                                                      int64_t N, int VS, int V, float smoothing) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= N) return;
+  const float w = weights[r];
+  if (w == 0.f) { tok_nll[r] = 0.f; lse_out[r] = 0.f; return; }
+  float M = -INFINITY, s = 0.f, sx = 0.f, xt = 0.f;
+  for (int v = 0; v < VS; ++v) {
+    const f32x4 p = partial[(int64_t)v * N + r];
+    const float Mn = fmaxf(M, p[0]);
+    s = (M == -INFINITY ? 0.f : s * ex2(M - Mn)) + (p[0] == -INFINITY ? 0.f : p[1] * ex2(p[0] - Mn));
+    M = Mn;
+    sx += p[2];
+    xt += p[3];
+  }
+  const float lse = (M + __builtin_amdgcn_logf(s)) * kLn2;
+  float nll = lse - xt;
+  if (smoothing > 0.f) nll = (1.f - smoothing) * nll + smoothing * lse - (smoothing / (float)V) * sx;
+  tok_nll[r] = nll * w;
+  lse_out[r] = lse;
+}
+
+constexpr int kLceStride = 72;   // bf16 per staged token row (64 + pad): 144 B keeps 16-byte alignment
+
+template <int NKS>
+__global__ __launch_bounds__(256) void k_lce_bwd(LceArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned short stage_all[4][32 * kLceStride];
+  const int lane = threadIdx.x & 63, r32 = lane & 31, hh = lane >> 5;
+  const int wave = threadIdx.x >> 6;
+  unsigned short* stage = stage_all[wave];
+  const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t tok0 = tile * 32, tok = tok0 + r32;
+  if (tok0 >= a.N) return;                                   // wave-uniform
+  const bool valid = tok < a.N;
+  const float coef = valid ? a.dper[tok / a.S] * a.tokscale[tok] : 0.f;
+  const int npair = a.V >> 6;
+  const int p0 = blockIdx.y * a.per;
+  int p1 = p0 + a.per;
+  if (p1 > npair) p1 = npair;
+  // copy-out geometry: lane -> (row = lane >> 3 (+ 8 i), 16-byte column lane & 7)
+  const int orow = lane >> 3, ocol = (lane & 7) * 8;
+  if (!__any(coef != 0.f)) {                                 // padding tile: zero gradient rows, nothing read
+    const u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int p = p0; p < p1; ++p)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t row = tok0 + orow + 8 * i;
+        if (row < a.N) *reinterpret_cast<u16x8*>(a.dlogits + row * a.V + 64 * p + ocol) = z;
+      }
+    return;
+  }
+  lce_bf16x8 hf[NKS];
+  {
+    const unsigned short* hp = a.h + (valid ? tok : 0) * (16 * NKS) + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) hf[ks] = *reinterpret_cast<const lce_bf16x8*>(hp + 16 * ks);
+  }
+  const int t = valid ? (int)a.target[tok] : -1;
+  const float l2 = valid ? a.lse[tok] * kLog2e : 0.f;
+  const float uni = coef * (a.smoothing > 0.f ? a.smoothing / (float)a.V : 0.f);
+  const float hot = coef * (a.smoothing > 0.f ? 1.f - a.smoothing : 1.f);
+  lce_bf16x8 wf[2][NKS];
+  for (int p = p0; p < p1; ++p) {
+    lce_load_w<NKS>(a.W, 2 * p, r32, hh, wf[0]);
+    lce_load_w<NKS>(a.W, 2 * p + 1, r32, hh, wf[1]);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int c = 2 * p + u;
+      const f32x16 x = lce_tile<NKS>(wf[u], hf, lce_bias_tile(a.bias, c, hh));
+      const int rel = t - 32 * c - 4 * hh;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        u16x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float g = fmaf(coef, ex2(fmaf(x[4 * q + i], kLog2e, -l2)), -uni);
+          if (rel == i + 8 * q) g -= hot;
+          o[i] = f32_to_bf16(g);
+        }
+        *reinterpret_cast<u16x4*>(stage + r32 * kLceStride + 32 * u + 8 * q + 4 * hh) = o;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = orow + 8 * i;
+      const u16x8 v = *reinterpret_cast<const u16x8*>(stage + row * kLceStride + ocol);
+      if (tok0 + row < a.N) *reinterpret_cast<u16x8*>(a.dlogits + (tok0 + row) * a.V + 64 * p + ocol) = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+int lce_check(const char* name, int64_t Bn, int64_t S, int64_t E, int64_t V, float smoothing) {
+  MIVAE_REQUIRE(Bn >= 0 && S > 0 && S < (1ll << 31) && Bn * S < (1ll << 31), "%s: bad shape Bn=%lld S=%lld", name,
+                (long long)Bn, (long long)S);
+  MIVAE_REQUIRE(E == 32 || E == 64 || E == 128 || E == 256, "%s: E must be 32, 64, 128 or 256 (got %lld)", name, (long long)E);
+  MIVAE_REQUIRE(V >= 64 && V % 64 == 0 && V < (1ll << 31), "%s: V must be a multiple of 64 (got %lld)", name, (long long)V);
+  MIVAE_REQUIRE(smoothing >= 0.f && smoothing < 1.f, "%s: smoothing must be in [0, 1)", name);
+  return MIVAE_OK;
+}
+
+// vocabulary slices so that at least ~2048 waves are in flight (2 per SIMD), at most 16
+int lce_slices(int64_t N, int64_t units) {
+  const int64_t tiles = (N + 31) / 32;
+  int64_t vs = (2048 + tiles - 1) / tiles;
+  if (vs > 16) vs = 16;
+  if (vs > units) vs = units;
+  if (vs < 1) vs = 1;
+  return (int)vs;
+}
+
+}  // namespace
+
+extern "C" int64_t mivae_lce_workspace_floats(int64_t N, int64_t V) {
+  if (N <= 0 || V <= 0) return 0;
+  return (int64_t)lce_slices(N, V / 32) * N * 4 + N;
+}
+
+// per_seq (Bn), lse (N), tokscale (N) as mivae_nll_fwd; h (N, E) and W (V, E) bf16, bias (V) fp32 or NULL.
+extern "C" int mivae_lce_fwd(const void* h, const void* W, const float* bias, const int64_t* target,
+                             const float* weights, float* per_seq, float* lse, float* tokscale, float* workspace,
+                             int64_t Bn, int64_t S, int64_t E, int64_t V, float smoothing, void* stream) {
+  int rc = lce_check("lce_fwd", Bn, S, E, V, smoothing);
+  if (rc) return rc;
+  if (Bn == 0) return MIVAE_OK;
+  MIVAE_REQUIRE(h && W && target && weights && per_seq && lse && tokscale && workspace, "lce_fwd: null pointer");
+  MIVAE_REQUIRE(aligned16(h) && aligned16(W) && aligned16(workspace) && (!bias || aligned16(bias)),
+                "lce_fwd: operands must be 16-byte aligned");
+  const int64_t N = Bn * S;
+  LceArgs a = {};
+  a.h = (const unsigned short*)h; a.W = (const unsigned short*)W; a.bias = bias; a.target = target; a.weights = weights;
+  a.partial = reinterpret_cast<f32x4*>(workspace);
+  a.N = N; a.S = (int)S; a.V = (int)V; a.smoothing = smoothing;
+  const int VS = lce_slices(N, V / 32);
+  a.per = (int)((V / 32 + VS - 1) / VS);
+  float* tok_nll = workspace + (int64_t)VS * N * 4;
+  dim3 grid((unsigned)(((N + 31) / 32 + 3) / 4), (unsigned)VS);
+  hipStream_t st = S_(stream);
+  switch (E) {
+    case 32: k_lce_fwd<2><<<grid, 256, 0, st>>>(a); break;
+    case 64: k_lce_fwd<4><<<grid, 256, 0, st>>>(a); break;
+    case 128: k_lce_fwd<8><<<grid, 256, 0, st>>>(a); break;
+    default: k_lce_fwd<16><<<grid, 256, 0, st>>>(a); break;
+  }
+  MIVAE_CHECK_LAUNCH("lce_fwd");
+  k_lce_combine<<<(unsigned)((N + 255) / 256), 256, 0, st>>>(a.partial, weights, tok_nll, lse, N, VS, (int)V, smoothing);
+  MIVAE_CHECK_LAUNCH("lce_combine");
+  k_nll_seq<<<(unsigned)((Bn + 3) / 4), kBlock, 0, st>>>(tok_nll, weights, per_seq, tokscale, Bn, (int)S);
+  MIVAE_CHECK_LAUNCH("lce_seq");
+  return MIVAE_OK;
+}
+
+// dlogits (N, V) bf16 = dper_seq[b] * tokscale * (softmax(h W^T + b) - q); the caller forms d h, d W, d b from it.
+extern "C" int mivae_lce_bwd(const void* h, const void* W, const float* bias, const int64_t* target, const float* lse,
+                             const float* tokscale, const float* dper_seq, void* dlogits, int64_t Bn, int64_t S,
+                             int64_t E, int64_t V, float smoothing, void* stream) {
+  int rc = lce_check("lce_bwd", Bn, S, E, V, smoothing);
+  if (rc) return rc;
+  if (Bn == 0) return MIVAE_OK;
+  MIVAE_REQUIRE(h && W && target && lse && tokscale && dper_seq && dlogits, "lce_bwd: null pointer");
+  MIVAE_REQUIRE(aligned16(h) && aligned16(W) && aligned16(dlogits) && (!bias || aligned16(bias)),
+                "lce_bwd: operands must be 16-byte aligned");
+  const int64_t N = Bn * S;
+  LceArgs a = {};
+  a.h = (const unsigned short*)h; a.W = (const unsigned short*)W; a.bias = bias; a.target = target;
+  a.lse = lse; a.tokscale = tokscale; a.dper = dper_seq; a.dlogits = (unsigned short*)dlogits;
+  a.N = N; a.S = (int)S; a.V = (int)V; a.smoothing = smoothing;
+  const int VS = lce_slices(N, V / 64);
+  a.per = (int)((V / 64 + VS - 1) / VS);
+  dim3 grid((unsigned)(((N + 31) / 32 + 3) / 4), (unsigned)VS);
+  hipStream_t st = S_(stream);
+  switch (E) {
+    case 32: k_lce_bwd<2><<<grid, 256, 0, st>>>(a); break;
+    case 64: k_lce_bwd<4><<<grid, 256, 0, st>>>(a); break;
+    case 128: k_lce_bwd<8><<<grid, 256, 0, st>>>(a); break;
+    default: k_lce_bwd<16><<<grid, 256, 0, st>>>(a); break;
+  }
+  MIVAE_CHECK_LAUNCH("lce_bwd");
+  return MIVAE_OK;
+}

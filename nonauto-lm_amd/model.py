@@ -177,7 +177,18 @@ class NonAutoModel(VAELmModel):
         return self._encoder(self._embedder(tokens), ops.tokens_mask(tokens))
 
     def decode(self, z, mask, target=None):
-        logits = self._vocab_projection(self._decoder(z, mask))
+        decoded = self._decoder(z, mask)
+        if (self.training_outputs_only and target is not None and torch.is_autocast_enabled()
+                and torch.get_autocast_dtype("cuda") == torch.bfloat16
+                and ops.linear_nll_supported(decoded, self._vocab_projection.weight)):
+            # training step under bf16 autocast: projection + NLL fused, the (N, V) logits are never written
+            # (SURVEY 8f-1); `logits` / `probs` / `preds` are not produced in this mode
+            proj = self._vocab_projection
+            weights = ops.tokens_mask(target).float()
+            smoothing = self._loss._smoothing if (self._loss._smoothing and self.training) else 0.0
+            return {"loss": ops.linear_nll(decoded, proj.weight, proj.bias, target, weights, smoothing,
+                                           getattr(proj.weight, "_mivae_lp", None))}
+        logits = self._vocab_projection(decoded)
         out = {"logits": logits}
         if not (self.training_outputs_only and target is not None):
             out["probs"] = torch.softmax(logits, dim=-1)

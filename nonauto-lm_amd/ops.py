@@ -450,6 +450,66 @@ def label_smoothing_nll(logits, target, weights, smoothing: float = 0.0):
     return _NLL.apply(logits, target, weights, smoothing or 0.0)
 
 
+class _LinearNLL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, weight, bias, w_lp, target, weights, smoothing):
+        Bn, E = h.size(0), h.size(-1)
+        V = weight.size(0)
+        S = target.numel() // max(Bn, 1)
+        N = Bn * S
+        h2 = h.contiguous().view(N, E)
+        if h2.dtype != torch.bfloat16:
+            h2 = h2.to(torch.bfloat16)
+        w16 = w_lp if (w_lp is not None and w_lp.dtype == torch.bfloat16) else weight.detach().to(torch.bfloat16)
+        w16 = w16.contiguous()
+        b32 = None if bias is None else bias.detach().float().contiguous()
+        tgt = target.reshape(Bn, S).contiguous().long()
+        w = weights.reshape(Bn, S).contiguous().float()
+        dev = h.device
+        per_seq = torch.empty(Bn, dtype=torch.float32, device=dev)
+        aux = torch.empty(2, N, dtype=torch.float32, device=dev)            # lse, tokscale
+        ws = torch.empty(L.query("mivae_lce_workspace_floats", N, V), dtype=torch.float32, device=dev)
+        with _timed("lce_fwd"):
+            L.call("mivae_lce_fwd", L.ptr(h2), L.ptr(w16), L.ptr(b32), L.ptr(tgt), L.ptr(w), L.ptr(per_seq), L.ptr(aux[0]),
+                   L.ptr(aux[1]), L.ptr(ws), Bn, S, E, V, float(smoothing), L.stream())
+        ctx.save_for_backward(h2, w16, b32, tgt, aux)
+        ctx.meta = (Bn, S, E, V, float(smoothing), h.shape, h.dtype, weight.dtype, bias is not None)
+        return per_seq
+
+    @staticmethod
+    def backward(ctx, dper):
+        h2, w16, b32, tgt, aux = ctx.saved_tensors
+        Bn, S, E, V, smoothing, hshape, hdtype, wdtype, has_bias = ctx.meta
+        dl = torch.empty(Bn * S, V, dtype=torch.bfloat16, device=h2.device)
+        with _timed("lce_bwd"):
+            L.call("mivae_lce_bwd", L.ptr(h2), L.ptr(w16), L.ptr(b32), L.ptr(tgt), L.ptr(aux[0]), L.ptr(aux[1]),
+                   L.ptr(dper.contiguous().float()), L.ptr(dl), Bn, S, E, V, smoothing, L.stream())
+        dh = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dh = dl.matmul(w16).view(hshape).to(hdtype)
+        if ctx.needs_input_grad[1]:
+            dw = dl.t().matmul(h2).to(wdtype)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = dl.sum(0, dtype=torch.float32).to(wdtype)
+        return dh, dw, db, None, None, None, None
+
+
+LCE_FEATURES = (32, 64, 128, 256)
+
+
+def linear_nll_supported(h, weight) -> bool:
+    return bool(h.is_cuda and h.size(-1) in LCE_FEATURES and weight.size(0) % 64 == 0 and weight.size(0) >= 64
+                and weight.size(1) == h.size(-1))
+
+
+def linear_nll(h, weight, bias, target, weights, smoothing: float = 0.0, w_lp=None):
+    """8f-1: LabelSmoothingNLL(size_average=False) of logits = h W^T + b without materialising the logits
+    (nonauto_lm/model.py:105-112 + models/base/losses.py:128-164).  bf16 operands, fp32 accumulation.
+    h (Bn, ..., E); weight (V, E) fp32 parameter (`w_lp`: its bf16 shadow, if one is kept); bias (V) or None."""
+    L.require_gpu(h, weight, target, weights)
+    return _LinearNLL.apply(h, weight, bias, w_lp, target, weights, smoothing or 0.0)
+
+
 # ----------------------------------------------------------------------------------- fused NICE stack
 _PTR_CACHE = {}
 

@@ -726,3 +726,59 @@ def test_layer_norm_vs_torch(M, shape, in_dt, out_dt):
     assert rel_err(got.float(), ref) < tol_o
     assert rel_err(xg.grad.float(), xr.grad) < max(tol_i, 2e-5)
     assert rel_err(wg.grad, wr.grad) < 2e-5 and rel_err(bg.grad, br.grad) < 2e-5
+
+
+@pytest.mark.parametrize("Bn,S,E,V,sm,bias", [(6, 9, 64, 128, 0.0, True), (4, 33, 32, 1024, 0.1, True), (3, 70, 128, 8192, 0.0, False),
+                                              (5, 7, 256, 512, 0.2, True), (256, 64, 64, 8192, 0.0, True), (1, 1, 64, 64, 0.0, True)])
+def test_linear_nll_fused_vs_oracle(M, Bn, S, E, V, sm, bias):
+    """8f-1: fused vocabulary projection + label-smoothing NLL (logits never written) vs the oracle's
+    label_smoothing_nll on logits = h W^T + b computed in fp64 from the same bf16-rounded h and W."""
+    gen = torch.Generator().manual_seed(Bn * 7 + V + E)
+    h = (torch.randn(Bn, S, E, generator=gen)).to(torch.bfloat16)
+    W = (torch.randn(V, E, generator=gen) * 0.3)
+    b = torch.randn(V, generator=gen) if bias else None
+    target = torch.randint(1, V, (Bn, S), generator=gen)
+    lengths = torch.randint(0, S + 1, (Bn,), generator=gen)
+    lengths[0] = S
+    target[torch.arange(S)[None, :] >= lengths[:, None]] = 0
+    w = O.tokens_mask(target).float()
+    gout = torch.randn(Bn, generator=gen)
+    W16 = W.to(torch.bfloat16)
+    hr = h.double().requires_grad_(True)
+    Wr = W16.double().requires_grad_(True)
+    br = None if b is None else b.double().requires_grad_(True)
+    logits = hr @ Wr.t() + (0 if br is None else br)
+    ref = O.label_smoothing_nll(logits, target, w.double(), sm, training=True)
+    (ref * gout.double()).sum().backward()
+    hg = dev(h).requires_grad_(True)
+    Wg = dev(W).requires_grad_(True)
+    bg = None if b is None else dev(b).requires_grad_(True)
+    got = M.ops.linear_nll(hg, Wg, bg, dev(target), dev(w), sm)
+    (got * dev(gout)).sum().backward()
+    assert got.dtype == torch.float32 and rel_err(got, ref) < 2e-5
+    # d logits is rounded to bf16 once before the two dense products (library GEMMs, fp32 accumulation)
+    assert rel_err(hg.grad.float(), hr.grad) < 8e-3
+    assert rel_err(Wg.grad, Wr.grad) < 8e-3
+    if bias:
+        assert rel_err(bg.grad, br.grad) < 8e-3
+    pad = dev(w) == 0
+    assert torch.equal(hg.grad[pad], torch.zeros_like(hg.grad[pad]))
+
+
+def test_fused_decode_matches_unfused(M):
+    """NonAutoModel.decode: fused projection + NLL path (training_outputs_only, bf16 autocast) vs the unfused
+    projection -> LabelSmoothingNLL path on the same weights and latents."""
+    import bench
+    torch.manual_seed(3)
+    model = M.VAELmModel.from_params(vocab=M.SimpleVocab(512), **bench.model_config(64, 64, 2)).to(DEV).train()
+    tokens = bench.synthetic_tokens(8, 20, True, 5)
+    tokens = torch.where(tokens > 0, tokens % 500 + 4, tokens).to(DEV)
+    mask = M.ops.tokens_mask(tokens)
+    z = torch.randn(8, 20, 64, device=DEV) * mask.unsqueeze(-1)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        model.training_outputs_only = False
+        ref = model.decode(z, mask, tokens)["loss"]
+        model.training_outputs_only = True
+        out = model.decode(z, mask, tokens)
+    assert "logits" not in out
+    assert rel_err(out["loss"], ref) < 5e-3           # the unfused path rounds the logits to bf16
