@@ -196,16 +196,21 @@ int mivae_nll_bwd(const void* logits, const int64_t* target, const float* lse, c
 /* ---- fused vocabulary projection + NLL (the logits never reach HBM) --------------------------------- */
 /* Same outputs as mivae_nll_fwd for logits = h W^T + bias, computed tile by tile on the matrix cores:
  * `self._vocab_projection(...)` of NonAutoModel.decode (nonauto_lm/model.py:105-112) followed by
- * LabelSmoothingNLL.forward (models/base/losses.py:128-169).  h (Bn*S, E) and W (V, E) bf16, bias (V) fp32 or
- * NULL; E in {32, 64, 128, 256}; V a multiple of 64.  workspace: mivae_lce_workspace_floats(Bn*S, V) floats. */
+ * LabelSmoothingNLL.forward (models/base/losses.py:128-169).  h (Bn*S, E) bf16; `W` is the packed weight + bias
+ * image from mivae_lce_pack; E in {32, 64, 128, 256}; V a multiple of 64.  workspace: mivae_lce_workspace_floats(Bn*S, V) floats. */
 int64_t mivae_lce_workspace_floats(int64_t N, int64_t V);
-int mivae_lce_fwd(const void* h, const void* W, const float* bias, const int64_t* target,
+/* W (V, E) bf16 row-major + bias (V) fp32 or NULL -> Wp (mivae_lce_pack_elems(V, E) = V * (E + 16) bf16): the
+ * MFMA-fragment-ordered image the two kernels below read as `W` (every wave load is one contiguous 1 KiB); the
+ * bias rides along as an extra k-step (bf16 hi + lo halves against a [1, 1, 0, ...] column of h). */
+int64_t mivae_lce_pack_elems(int64_t V, int64_t E);
+int mivae_lce_pack(const void* W, const float* bias, void* Wp, int64_t V, int64_t E, void* stream);
+int mivae_lce_fwd(const void* h, const void* W, const int64_t* target,
                   const float* weights, float* per_seq, float* lse, float* tokscale, float* workspace,
                   int64_t Bn, int64_t S, int64_t E, int64_t V, float smoothing, void* stream);
 /* dlogits (Bn*S, V) bf16 = dper_seq[b] * tokscale * (softmax(h W^T + bias) - q), recomputed from h and W (autograd
  * of the chain above w.r.t. the logits); d h = dlogits W, d W = dlogits^T h, d bias = colsum(dlogits) are the
  * caller's dense products. */
-int mivae_lce_bwd(const void* h, const void* W, const float* bias, const int64_t* target, const float* lse,
+int mivae_lce_bwd(const void* h, const void* W, const int64_t* target, const float* lse,
                   const float* tokscale, const float* dper_seq, void* dlogits, int64_t Bn, int64_t S,
                   int64_t E, int64_t V, float smoothing, void* stream);
 

@@ -43,8 +43,10 @@ SIGNATURES = {
     "mivae_nll_fwd": [P, P, P, P, P, P, P, I64, I64, I64, F32, I32, P],
     "mivae_nll_bwd": [P, P, P, P, P, P, I64, I64, I64, F32, I32, P],
     "mivae_lce_workspace_floats": [I64, I64],
-    "mivae_lce_fwd": [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P],
-    "mivae_lce_bwd": [P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P],
+    "mivae_lce_pack_elems": [I64, I64],
+    "mivae_lce_pack": [P, P, P, I64, I64, P],
+    "mivae_lce_fwd": [P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P],
+    "mivae_lce_bwd": [P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P],
     "mivae_layernorm_fwd": [P, P, P, P, P, P, I64, I64, F32, I32, I32, P],
     "mivae_layernorm_workspace_floats": [I64, I64],
     "mivae_layernorm_bwd": [P, P, P, P, P, P, P, P, I64, I64, I32, I32, P],
@@ -66,6 +68,7 @@ _RET = {
     "mivae_nice_pack_bytes": I64,
     "mivae_sumsq_blocks": I64,
     "mivae_lce_workspace_floats": I64,
+    "mivae_lce_pack_elems": I64,
     "mivae_layernorm_workspace_floats": I64,
     "mivae_nice_stack_npad": I64,
     "mivae_nice_dw_workspace_floats": I64,

@@ -11,6 +11,7 @@
 // gradient row is written as zeros).  Reductions are fixed-order (lane-local, then xor butterfly,
 // then one wave per sentence walking its tokens in order): bit-reproducible run to run.
 #include "common.hpp"
+#include <stdlib.h>
 
 using namespace mivae;
 
@@ -236,42 +237,41 @@ typedef __bf16 lce_bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ int lce_row(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
 
-// accumulator tile initialised with the bias of vocabulary rows 32 c .. 32 c + 31
-__device__ __forceinline__ f32x16 lce_bias_tile(const float* __restrict__ bias, int c, int hh) {
-  f32x16 a;
-  if (bias) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(bias + 32 * c + 8 * q + 4 * hh);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[4 * q + i] = v[i];
-    }
-  } else {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) a[r] = 0.f;
-  }
-  return a;
-}
-
-template <int NKS>
+// NF = E / 16 + 1 fragments per chunk: the last k-step carries the bias (hi + lo bf16 halves) against a
+// [1, 1, 0, ...] column of h, so the bias add rides on the matrix pipe and the accumulator starts from zero.
+template <int NF>
 __device__ __forceinline__ void lce_load_w(const unsigned short* __restrict__ W, int c, int r32, int hh,
-                                           lce_bf16x8 (&f)[NKS]) {
-  const unsigned short* p = W + (int64_t)(32 * c + r32) * (16 * NKS) + 8 * hh;
+                                           lce_bf16x8 (&f)[NF]) {
+  // W is packed in fragment order [chunk][k-step][lane][8]: one contiguous 1 KiB per wave load
+  const unsigned short* p = W + ((int64_t)c * NF * 64 + (hh * 32 + r32)) * 8;
 #pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) f[ks] = *reinterpret_cast<const lce_bf16x8*>(p + 16 * ks);
+  for (int ks = 0; ks < NF; ++ks) f[ks] = *reinterpret_cast<const lce_bf16x8*>(p + ks * 512);
 }
 
-template <int NKS>
-__device__ __forceinline__ f32x16 lce_tile(const lce_bf16x8 (&wf)[NKS], const lce_bf16x8 (&hf)[NKS], f32x16 acc) {
+template <int NF>
+__device__ __forceinline__ f32x16 lce_tile(const lce_bf16x8 (&wf)[NF], const lce_bf16x8 (&hf)[NF]) {
+  f32x16 acc;
 #pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], hf[ks], acc, 0, 0, 0);
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < NF; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], hf[ks], acc, 0, 0, 0);
   return acc;
+}
+
+// h fragments of one 32-token tile (+ the [1, 1, 0, ...] bias column)
+template <int NF>
+__device__ __forceinline__ void lce_load_h(const unsigned short* __restrict__ h, int64_t tok, bool valid, int hh,
+                                           lce_bf16x8 (&hf)[NF]) {
+  const unsigned short* hp = h + (valid ? tok : 0) * (16 * (NF - 1)) + 8 * hh;
+#pragma unroll
+  for (int ks = 0; ks < NF - 1; ++ks) hf[ks] = *reinterpret_cast<const lce_bf16x8*>(hp + 16 * ks);
+  const u16x8 one = {0x3F80, 0x3F80, 0, 0, 0, 0, 0, 0}, zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  hf[NF - 1] = __builtin_bit_cast(lce_bf16x8, hh == 0 ? one : zero);
 }
 
 struct LceArgs {
   const unsigned short* h;      // (N, E) bf16
-  const unsigned short* W;      // (V, E) bf16
-  const float* bias;            // (V) or null
+  const unsigned short* W;      // (V, E + 16) bf16 in fragment order incl. the bias k-step (k_lce_pack)
   const int64_t* target;        // (N)
   const float* weights;         // (N)           [fwd]
   f32x4* partial;               // (VS, N) {max2, sum, sum x, x_t}   [fwd]
@@ -284,8 +284,34 @@ struct LceArgs {
   float smoothing;
 };
 
-template <int NKS>
+// Wp[chunk c][k-step ks][lane (hh, r32)][j] = W[32 c + r32][16 ks + 8 hh + j] for ks < E / 16 (the A fragments of
+// the logits tiles); the extra k-step ks = E / 16 holds {bf16 hi, bf16 lo} of bias[32 c + r32] in slots 0, 1 of the
+// hh = 0 lanes (hi + lo carries the fp32 bias to ~2^-17 relative) and zeros elsewhere.
+__global__ __launch_bounds__(256) void k_lce_pack(const unsigned short* __restrict__ W, const float* __restrict__ bias,
+                                                   unsigned short* __restrict__ Wp, int64_t V, int E) {
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;       // one 16-byte group per thread
+  const int nf = (E >> 4) + 1;
+  if (g >= (V >> 5) * nf * 64) return;
+  const int lane = (int)(g & 63);
+  const int64_t q = g >> 6;
+  const int ks = (int)(q % nf);
+  const int64_t c = q / nf;
+  const int r32 = lane & 31, hh = lane >> 5;
+  u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (ks < nf - 1) {
+    v = *reinterpret_cast<const u16x8*>(W + (32 * c + r32) * E + 16 * ks + 8 * hh);
+  } else if (hh == 0 && bias) {
+    const float b = bias[32 * c + r32];
+    const unsigned short hi = f32_to_bf16(b);
+    v[0] = hi;
+    v[1] = f32_to_bf16(b - bf16_to_f32(hi));
+  }
+  *reinterpret_cast<u16x8*>(Wp + g * 8) = v;
+}
+
+template <int NKS, bool SMOOTH>
 __global__ __launch_bounds__(256) void k_lce_fwd(LceArgs a) {
+  constexpr int NF = NKS + 1;
   const int lane = threadIdx.x & 63, r32 = lane & 31, hh = lane >> 5;
   const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t tok = tile * 32 + r32;
@@ -296,39 +322,38 @@ __global__ __launch_bounds__(256) void k_lce_fwd(LceArgs a) {
     if (valid && hh == 0) { const f32x4 z = {-INFINITY, 0.f, 0.f, 0.f}; *out = z; }
     return;
   }
-  lce_bf16x8 hf[NKS];
-  {
-    const unsigned short* hp = a.h + (valid ? tok : 0) * (16 * NKS) + 8 * hh;
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) hf[ks] = *reinterpret_cast<const lce_bf16x8*>(hp + 16 * ks);
-  }
+  lce_bf16x8 hf[NF];
+  lce_load_h<NF>(a.h, tok, valid, hh, hf);
   const int t = valid ? (int)a.target[tok] : -1;
   const int nch = a.V >> 5;
   const int c0 = blockIdx.y * a.per;
   int c1 = c0 + a.per;
   if (c1 > nch) c1 = nch;
   float m = -INFINITY, s = 0.f, sx = 0.f, xt = 0.f;
-  lce_bf16x8 wf[NKS], wn[NKS];
-  if (c0 < c1) lce_load_w<NKS>(a.W, c0, r32, hh, wf);
+  lce_bf16x8 wf[NF], wn[NF];
+  if (c0 < c1) lce_load_w<NF>(a.W, c0, r32, hh, wf);
   for (int c = c0; c < c1; ++c) {
-    if (c + 1 < c1) lce_load_w<NKS>(a.W, c + 1, r32, hh, wn);      // next chunk in flight under this one's math
-    const f32x16 x = lce_tile<NKS>(wf, hf, lce_bias_tile(a.bias, c, hh));
+    if (c + 1 < c1) lce_load_w<NF>(a.W, c + 1, r32, hh, wn);      // next chunk in flight under this one's math
+    const f32x16 x = lce_tile<NF>(wf, hf);
     float cm = x[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) cm = fmaxf(cm, x[r]);
     const float mn = fmaxf(m, cm * kLog2e);
     float acc = 0.f;
-    const int rel = t - 32 * c - 4 * hh;      // row of the target inside this lane's 16 rows, if any
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       acc += ex2(fmaf(x[r], kLog2e, -mn));
-      sx += x[r];
-      xt += (rel == (r & 3) + 8 * (r >> 2)) ? x[r] : 0.f;
+      if (SMOOTH) sx += x[r];
     }
     s = fmaf(s, ex2(m - mn), acc);
     m = mn;
+    if (__any((t >> 5) == c)) {               // some token of this tile has its target in this chunk (wave-uniform)
+      const int rel = t - 32 * c - 4 * hh;    // row of the target inside this lane's 16 rows, if any
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) wf[ks] = wn[ks];
+      for (int r = 0; r < 16; ++r) xt += (rel == (r & 3) + 8 * (r >> 2)) ? x[r] : 0.f;
+    }
+#pragma unroll
+    for (int ks = 0; ks < NF; ++ks) wf[ks] = wn[ks];
   }
   // the two half-waves hold the two row halves of the same token column
   const float mo = __shfl_xor(m, 32, 64), so = __shfl_xor(s, 32, 64);
@@ -367,6 +392,7 @@ constexpr int kLceStride = 72;   // bf16 per staged token row (64 + pad): 144 B 
 
 template <int NKS>
 __global__ __launch_bounds__(256) void k_lce_bwd(LceArgs a) {
+  constexpr int NF = NKS + 1;
   __shared__ __attribute__((aligned(16))) unsigned short stage_all[4][32 * kLceStride];
   const int lane = threadIdx.x & 63, r32 = lane & 31, hh = lane >> 5;
   const int wave = threadIdx.x >> 6;
@@ -392,32 +418,29 @@ __global__ __launch_bounds__(256) void k_lce_bwd(LceArgs a) {
       }
     return;
   }
-  lce_bf16x8 hf[NKS];
-  {
-    const unsigned short* hp = a.h + (valid ? tok : 0) * (16 * NKS) + 8 * hh;
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) hf[ks] = *reinterpret_cast<const lce_bf16x8*>(hp + 16 * ks);
-  }
+  lce_bf16x8 hf[NF];
+  lce_load_h<NF>(a.h, tok, valid, hh, hf);
   const int t = valid ? (int)a.target[tok] : -1;
   const float l2 = valid ? a.lse[tok] * kLog2e : 0.f;
   const float uni = coef * (a.smoothing > 0.f ? a.smoothing / (float)a.V : 0.f);
   const float hot = coef * (a.smoothing > 0.f ? 1.f - a.smoothing : 1.f);
-  lce_bf16x8 wf[2][NKS];
+  lce_bf16x8 wf[2][NF];
   for (int p = p0; p < p1; ++p) {
-    lce_load_w<NKS>(a.W, 2 * p, r32, hh, wf[0]);
-    lce_load_w<NKS>(a.W, 2 * p + 1, r32, hh, wf[1]);
+    lce_load_w<NF>(a.W, 2 * p, r32, hh, wf[0]);
+    lce_load_w<NF>(a.W, 2 * p + 1, r32, hh, wf[1]);
+    const bool anyt = __any((t >> 6) == p) != 0;   // a target of this tile falls into this pair of chunks
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int c = 2 * p + u;
-      const f32x16 x = lce_tile<NKS>(wf[u], hf, lce_bias_tile(a.bias, c, hh));
-      const int rel = t - 32 * c - 4 * hh;
+      const f32x16 x = lce_tile<NF>(wf[u], hf);
+      const int rel = anyt ? t - 32 * c - 4 * hh : -1;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         u16x4 o;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           float g = fmaf(coef, ex2(fmaf(x[4 * q + i], kLog2e, -l2)), -uni);
-          if (rel == i + 8 * q) g -= hot;
+          if (anyt && rel == i + 8 * q) g -= hot;
           o[i] = f32_to_bf16(g);
         }
         *reinterpret_cast<u16x4*>(stage + r32 * kLceStride + 32 * u + 8 * q + 4 * hh) = o;
@@ -445,11 +468,12 @@ int lce_check(const char* name, int64_t Bn, int64_t S, int64_t E, int64_t V, flo
   return MIVAE_OK;
 }
 
-// vocabulary slices so that at least ~2048 waves are in flight (2 per SIMD), at most 16
+// vocabulary slices so that ~8192 waves are in flight (8 per SIMD: exp latency and the MFMA chain overlap), at most 64
 int lce_slices(int64_t N, int64_t units) {
   const int64_t tiles = (N + 31) / 32;
-  int64_t vs = (2048 + tiles - 1) / tiles;
-  if (vs > 16) vs = 16;
+  static const int64_t target = getenv("MIVAE_LCE_WAVES") ? atoll(getenv("MIVAE_LCE_WAVES")) : 8192;
+  int64_t vs = (target + tiles - 1) / tiles;
+  if (vs > 64) vs = 64;
   if (vs > units) vs = units;
   if (vs < 1) vs = 1;
   return (int)vs;
@@ -462,19 +486,32 @@ extern "C" int64_t mivae_lce_workspace_floats(int64_t N, int64_t V) {
   return (int64_t)lce_slices(N, V / 32) * N * 4 + N;
 }
 
-// per_seq (Bn), lse (N), tokscale (N) as mivae_nll_fwd; h (N, E) and W (V, E) bf16, bias (V) fp32 or NULL.
-extern "C" int mivae_lce_fwd(const void* h, const void* W, const float* bias, const int64_t* target,
+// W (V, E) bf16 row-major + bias (V) fp32 (or NULL) -> Wp (V * (E + 16) bf16): what mivae_lce_fwd / _bwd read
+extern "C" int64_t mivae_lce_pack_elems(int64_t V, int64_t E) { return V > 0 && E > 0 ? V * (E + 16) : 0; }
+
+extern "C" int mivae_lce_pack(const void* W, const float* bias, void* Wp, int64_t V, int64_t E, void* stream) {
+  MIVAE_REQUIRE(W && Wp, "lce_pack: null pointer");
+  MIVAE_REQUIRE((E == 32 || E == 64 || E == 128 || E == 256) && V >= 32 && V % 32 == 0 && V < (1ll << 31),
+                "lce_pack: bad shape V=%lld E=%lld", (long long)V, (long long)E);
+  MIVAE_REQUIRE(aligned16(W) && aligned16(Wp), "lce_pack: operands must be 16-byte aligned");
+  const int64_t groups = (V / 32) * (E / 16 + 1) * 64;
+  k_lce_pack<<<(unsigned)((groups + 255) / 256), 256, 0, S_(stream)>>>((const unsigned short*)W, bias, (unsigned short*)Wp, V, (int)E);
+  MIVAE_CHECK_LAUNCH("lce_pack");
+  return MIVAE_OK;
+}
+
+// per_seq (Bn), lse (N), tokscale (N) as mivae_nll_fwd; h (N, E) bf16, W = packed weight + bias (mivae_lce_pack).
+extern "C" int mivae_lce_fwd(const void* h, const void* W, const int64_t* target,
                              const float* weights, float* per_seq, float* lse, float* tokscale, float* workspace,
                              int64_t Bn, int64_t S, int64_t E, int64_t V, float smoothing, void* stream) {
   int rc = lce_check("lce_fwd", Bn, S, E, V, smoothing);
   if (rc) return rc;
   if (Bn == 0) return MIVAE_OK;
   MIVAE_REQUIRE(h && W && target && weights && per_seq && lse && tokscale && workspace, "lce_fwd: null pointer");
-  MIVAE_REQUIRE(aligned16(h) && aligned16(W) && aligned16(workspace) && (!bias || aligned16(bias)),
-                "lce_fwd: operands must be 16-byte aligned");
+  MIVAE_REQUIRE(aligned16(h) && aligned16(W) && aligned16(workspace), "lce_fwd: operands must be 16-byte aligned");
   const int64_t N = Bn * S;
   LceArgs a = {};
-  a.h = (const unsigned short*)h; a.W = (const unsigned short*)W; a.bias = bias; a.target = target; a.weights = weights;
+  a.h = (const unsigned short*)h; a.W = (const unsigned short*)W; a.target = target; a.weights = weights;
   a.partial = reinterpret_cast<f32x4*>(workspace);
   a.N = N; a.S = (int)S; a.V = (int)V; a.smoothing = smoothing;
   const int VS = lce_slices(N, V / 32);
@@ -482,12 +519,18 @@ extern "C" int mivae_lce_fwd(const void* h, const void* W, const float* bias, co
   float* tok_nll = workspace + (int64_t)VS * N * 4;
   dim3 grid((unsigned)(((N + 31) / 32 + 3) / 4), (unsigned)VS);
   hipStream_t st = S_(stream);
+#define LCE_FWD(NKS)                                                         \
+  do {                                                                       \
+    if (smoothing > 0.f) k_lce_fwd<NKS, true><<<grid, 256, 0, st>>>(a);      \
+    else k_lce_fwd<NKS, false><<<grid, 256, 0, st>>>(a);                     \
+  } while (0)
   switch (E) {
-    case 32: k_lce_fwd<2><<<grid, 256, 0, st>>>(a); break;
-    case 64: k_lce_fwd<4><<<grid, 256, 0, st>>>(a); break;
-    case 128: k_lce_fwd<8><<<grid, 256, 0, st>>>(a); break;
-    default: k_lce_fwd<16><<<grid, 256, 0, st>>>(a); break;
+    case 32: LCE_FWD(2); break;
+    case 64: LCE_FWD(4); break;
+    case 128: LCE_FWD(8); break;
+    default: LCE_FWD(16); break;
   }
+#undef LCE_FWD
   MIVAE_CHECK_LAUNCH("lce_fwd");
   k_lce_combine<<<(unsigned)((N + 255) / 256), 256, 0, st>>>(a.partial, weights, tok_nll, lse, N, VS, (int)V, smoothing);
   MIVAE_CHECK_LAUNCH("lce_combine");
@@ -497,18 +540,17 @@ extern "C" int mivae_lce_fwd(const void* h, const void* W, const float* bias, co
 }
 
 // dlogits (N, V) bf16 = dper_seq[b] * tokscale * (softmax(h W^T + b) - q); the caller forms d h, d W, d b from it.
-extern "C" int mivae_lce_bwd(const void* h, const void* W, const float* bias, const int64_t* target, const float* lse,
+extern "C" int mivae_lce_bwd(const void* h, const void* W, const int64_t* target, const float* lse,
                              const float* tokscale, const float* dper_seq, void* dlogits, int64_t Bn, int64_t S,
                              int64_t E, int64_t V, float smoothing, void* stream) {
   int rc = lce_check("lce_bwd", Bn, S, E, V, smoothing);
   if (rc) return rc;
   if (Bn == 0) return MIVAE_OK;
   MIVAE_REQUIRE(h && W && target && lse && tokscale && dper_seq && dlogits, "lce_bwd: null pointer");
-  MIVAE_REQUIRE(aligned16(h) && aligned16(W) && aligned16(dlogits) && (!bias || aligned16(bias)),
-                "lce_bwd: operands must be 16-byte aligned");
+  MIVAE_REQUIRE(aligned16(h) && aligned16(W) && aligned16(dlogits), "lce_bwd: operands must be 16-byte aligned");
   const int64_t N = Bn * S;
   LceArgs a = {};
-  a.h = (const unsigned short*)h; a.W = (const unsigned short*)W; a.bias = bias; a.target = target;
+  a.h = (const unsigned short*)h; a.W = (const unsigned short*)W; a.target = target;
   a.lse = lse; a.tokscale = tokscale; a.dper = dper_seq; a.dlogits = (unsigned short*)dlogits;
   a.N = N; a.S = (int)S; a.V = (int)V; a.smoothing = smoothing;
   const int VS = lce_slices(N, V / 64);

@@ -463,6 +463,9 @@ class _LinearNLL(torch.autograd.Function):
         w16 = w_lp if (w_lp is not None and w_lp.dtype == torch.bfloat16) else weight.detach().to(torch.bfloat16)
         w16 = w16.contiguous()
         b32 = None if bias is None else bias.detach().float().contiguous()
+        # fragment-ordered weight + bias image for the two kernels
+        wp = torch.empty(L.query("mivae_lce_pack_elems", V, E), dtype=torch.bfloat16, device=h.device)
+        L.call("mivae_lce_pack", L.ptr(w16), L.ptr(b32), L.ptr(wp), V, E, L.stream())
         tgt = target.reshape(Bn, S).contiguous().long()
         w = weights.reshape(Bn, S).contiguous().float()
         dev = h.device
@@ -470,26 +473,32 @@ class _LinearNLL(torch.autograd.Function):
         aux = torch.empty(2, N, dtype=torch.float32, device=dev)            # lse, tokscale
         ws = torch.empty(L.query("mivae_lce_workspace_floats", N, V), dtype=torch.float32, device=dev)
         with _timed("lce_fwd"):
-            L.call("mivae_lce_fwd", L.ptr(h2), L.ptr(w16), L.ptr(b32), L.ptr(tgt), L.ptr(w), L.ptr(per_seq), L.ptr(aux[0]),
+            L.call("mivae_lce_fwd", L.ptr(h2), L.ptr(wp), L.ptr(tgt), L.ptr(w), L.ptr(per_seq), L.ptr(aux[0]),
                    L.ptr(aux[1]), L.ptr(ws), Bn, S, E, V, float(smoothing), L.stream())
-        ctx.save_for_backward(h2, w16, b32, tgt, aux)
+        ctx.save_for_backward(h2, w16, wp, tgt, aux)
         ctx.meta = (Bn, S, E, V, float(smoothing), h.shape, h.dtype, weight.dtype, bias is not None)
         return per_seq
 
     @staticmethod
     def backward(ctx, dper):
-        h2, w16, b32, tgt, aux = ctx.saved_tensors
+        h2, w16, wp, tgt, aux = ctx.saved_tensors
         Bn, S, E, V, smoothing, hshape, hdtype, wdtype, has_bias = ctx.meta
         dl = torch.empty(Bn * S, V, dtype=torch.bfloat16, device=h2.device)
         with _timed("lce_bwd"):
-            L.call("mivae_lce_bwd", L.ptr(h2), L.ptr(w16), L.ptr(b32), L.ptr(tgt), L.ptr(aux[0]), L.ptr(aux[1]),
+            L.call("mivae_lce_bwd", L.ptr(h2), L.ptr(wp), L.ptr(tgt), L.ptr(aux[0]), L.ptr(aux[1]),
                    L.ptr(dper.contiguous().float()), L.ptr(dl), Bn, S, E, V, smoothing, L.stream())
         dh = dw = db = None
         if ctx.needs_input_grad[0]:
             dh = dl.matmul(w16).view(hshape).to(hdtype)
-        if ctx.needs_input_grad[1]:
+        want_db = has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] and want_db:
+            # one dense product for both: d W = dl^T h and d b = dl^T 1 (a ones block appended to h)
+            h_aug = torch.cat([h2, torch.ones(h2.size(0), 8, dtype=h2.dtype, device=h2.device)], dim=1)
+            dwa = dl.t().matmul(h_aug)
+            dw, db = dwa[:, :E].to(wdtype), dwa[:, E].to(wdtype)
+        elif ctx.needs_input_grad[1]:
             dw = dl.t().matmul(h2).to(wdtype)
-        if has_bias and ctx.needs_input_grad[2]:
+        elif want_db:
             db = dl.sum(0, dtype=torch.float32).to(wdtype)
         return dh, dw, db, None, None, None, None
 
