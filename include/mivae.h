@@ -214,6 +214,21 @@ int mivae_lce_bwd(const void* h, const void* W, const int64_t* target, const flo
                   const float* tokscale, const float* dper_seq, void* dlogits, int64_t Bn, int64_t S,
                   int64_t E, int64_t V, float smoothing, void* stream);
 
+/* ---- token-parallel small Linear layers ---------------------------------------------------------------- */
+/* torch.nn.Linear over many tokens and few features, bf16 operands, fp32 accumulation on the matrix cores: the
+ * posterior heads (posterior.py:19-27, row a3) and the q/k/v/out/FFN projections of the attention coupling /
+ * transformer layers (nn/transformer.py:41-48, 129-130).  x (N, Fi), w (Fo, Fi) row-major (nn.Linear layout),
+ * bias (Fo) or NULL, y (N, Fo); Fi, Fo in {32, 64, 128, 256}. */
+int mivae_linear_fwd(const void* x, const void* w, const void* bias, void* y, int64_t N, int64_t Fi, int64_t Fo,
+                     void* stream);
+/* dx (N, Fi) = dy (N, Fo) w  (autograd of the above w.r.t. x). */
+int mivae_linear_dgrad(const void* dy, const void* w, void* dx, int64_t N, int64_t Fi, int64_t Fo, void* stream);
+/* partial (mivae_linear_wgrad_rows(N), Fo*Fi + Fo) fp32: per-wave [dy^T x | colsum dy]; its column sums
+ * (mivae_colsum) are [dW (Fo, Fi) | db (Fo)] (autograd w.r.t. weight and bias).  Fi, Fo in {32, 64, 128}. */
+int64_t mivae_linear_wgrad_rows(int64_t N);
+int mivae_linear_wgrad(const void* x, const void* dy, float* partial, int64_t N, int64_t Fi, int64_t Fo,
+                       void* stream);
+
 /* ---- LayerNorm (pre-norm sublayers of the attention coupling / transformer bracket) ------------------ */
 /* y = (x - mean) * rstd * gamma + beta over the last axis (torch.nn.LayerNorm inside SublayerConnection,
  * nn/transformer.py:147-162; used by AttentionCoupling, couplings.py:54-81).  x (rows, D) in in_dtype, y in

@@ -47,6 +47,10 @@ SIGNATURES = {
     "mivae_lce_pack": [P, P, P, I64, I64, P],
     "mivae_lce_fwd": [P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P],
     "mivae_lce_bwd": [P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P],
+    "mivae_linear_fwd": [P, P, P, P, I64, I64, I64, P],
+    "mivae_linear_dgrad": [P, P, P, I64, I64, I64, P],
+    "mivae_linear_wgrad_rows": [I64],
+    "mivae_linear_wgrad": [P, P, P, I64, I64, I64, P],
     "mivae_layernorm_fwd": [P, P, P, P, P, P, I64, I64, F32, I32, I32, P],
     "mivae_layernorm_workspace_floats": [I64, I64],
     "mivae_layernorm_bwd": [P, P, P, P, P, P, P, P, I64, I64, I32, I32, P],
@@ -69,6 +73,7 @@ _RET = {
     "mivae_sumsq_blocks": I64,
     "mivae_lce_workspace_floats": I64,
     "mivae_lce_pack_elems": I64,
+    "mivae_linear_wgrad_rows": I64,
     "mivae_layernorm_workspace_floats": I64,
     "mivae_nice_stack_npad": I64,
     "mivae_nice_dw_workspace_floats": I64,

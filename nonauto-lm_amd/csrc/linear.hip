@@ -1,0 +1,289 @@
+// Token-parallel small Linear layers on the matrix cores: y = x W^T + b, dx = dy W, (dW, db) = (dy^T x, colsum dy)
+// for many tokens (N >= 4096) and few features (32 .. 256, multiples of 32): the posterior heads
+// (posterior.py:19-27: mu = Linear(E -> D), sigma = ...(Linear(E -> D))) and the q/k/v/out/FFN
+// projections of the attention coupling / transformer bracket (nn/transformer.py:41-48, 129-130).
+// hipBLASLt dispatches these (16384 x 64 x 64) products to a 256-workgroup 64x64 tiling at ~9 us per call; they
+// are 4 MB of HBM traffic.  Here a wave owns 32 tokens, keeps their features as MFMA B fragments in registers and
+// walks the output features in chunks of 32 (v_mfma_f32_32x32x16_bf16, fp32 accumulation, bf16 operands exactly
+// like the library path): one read of x, one write of y.  The weight gradient contracts over tokens: both operand
+// tiles are transposed through wave-private LDS ([feature][token]) so the fragments are 16-byte reads; every wave
+// dumps its partial (dW | db) and mivae_colsum folds the partials in fixed order (no atomics).
+#include "common.hpp"
+
+using namespace mivae;
+
+namespace {
+
+typedef __bf16 lin_bf16x8 __attribute__((ext_vector_type(8)));
+
+static inline hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
+__device__ __forceinline__ int lin_row(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
+
+struct LinArgs {
+  const unsigned short* x;     // (N, K) bf16: activations (fwd) or dy (dgrad)
+  const unsigned short* w;     // (Fo, Fi) bf16 row-major (torch.nn.Linear layout)
+  const unsigned short* bias;  // (Fo) bf16 or null (fwd only)
+  unsigned short* y;           // (N, M) bf16
+  int64_t N;
+  int Fo, Fi;
+};
+
+// fwd  (TRANS = false): K = Fi, M = Fo, A fragments straight from W (rows = outputs, k = inputs)
+// dgrad (TRANS = true): K = Fo, M = Fi, A[i][k] = W[k][i]: W is transposed into LDS once per block
+template <int NK, bool TRANS>
+__global__ __launch_bounds__(256) void k_lin(LinArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short wt[];   // TRANS: [M][K + 8]
+  constexpr int K = 16 * NK;
+  const int M = TRANS ? a.Fi : a.Fo;
+  const int lane = threadIdx.x & 63, r32 = lane & 31, hh = lane >> 5;
+  if (TRANS) {
+    // W (Fo = K rows, Fi = M cols) -> wt[m][k]; each thread moves 8 consecutive m of one k per step
+    const int groups = K * (M >> 3);
+    for (int g = threadIdx.x; g < groups; g += 256) {
+      const int k = g / (M >> 3), m8 = (g % (M >> 3)) * 8;
+      const u16x8 v = *reinterpret_cast<const u16x8*>(a.w + (int64_t)k * M + m8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wt[(m8 + e) * (K + 8) + k] = v[e];
+    }
+    __syncthreads();
+  }
+  // one (32-token tile, 32-output chunk) unit per wave: 2-8 x more waves than tiles, the chip needs them
+  const int nch = M >> 5;
+  const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t tile = unit / nch;
+  const int c = (int)(unit - tile * nch);
+  const int64_t tok = tile * 32 + r32;
+  if (tile * 32 >= a.N) return;                       // wave-uniform, after the only barrier
+  const bool valid = tok < a.N;
+  lin_bf16x8 xf[NK];
+  {
+    const unsigned short* xp = a.x + (valid ? tok : 0) * K + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) xf[ks] = *reinterpret_cast<const lin_bf16x8*>(xp + 16 * ks);
+  }
+  {
+    lin_bf16x8 wf[NK];
+    if (TRANS) {
+      const unsigned short* p = wt + (32 * c + r32) * (K + 8) + 8 * hh;
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks) wf[ks] = *reinterpret_cast<const lin_bf16x8*>(p + 16 * ks);
+    } else {
+      const unsigned short* p = a.w + (int64_t)(32 * c + r32) * K + 8 * hh;
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks) wf[ks] = *reinterpret_cast<const lin_bf16x8*>(p + 16 * ks);
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = (!TRANS && a.bias) ? bf16_to_f32(a.bias[32 * c + lin_row(r, hh)]) : 0.f;
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xf[ks], acc, 0, 0, 0);
+    if (valid) {
+      unsigned short* yp = a.y + tok * M + 32 * c + 4 * hh;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        u16x4 o = {f32_to_bf16(acc[4 * q]), f32_to_bf16(acc[4 * q + 1]), f32_to_bf16(acc[4 * q + 2]), f32_to_bf16(acc[4 * q + 3])};
+        *reinterpret_cast<u16x4*>(yp + 8 * q) = o;
+      }
+    }
+  }
+}
+
+struct WgArgs {
+  const unsigned short* x;    // (N, Fi) bf16
+  const unsigned short* dy;   // (N, Fo) bf16
+  float* partial;             // (P, Fo * Fi + Fo): per wave [dW row-major | db]
+  int64_t N;
+  int Fo, Fi, tiles_per_wave;
+};
+
+constexpr int kTokPad = 40;   // staged row = 32 tokens + 8 pad (80 B: 16-byte aligned fragment reads)
+
+// MO = Fo / 32, NI = Fi / 32 accumulator tiles per wave
+template <int MO, int NI>
+__global__ __launch_bounds__(256) void k_lin_wgrad(WgArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];   // per wave: [Fo + Fi][kTokPad]
+  const int lane = threadIdx.x & 63, r32 = lane & 31, hh = lane >> 5;
+  const int wave = threadIdx.x >> 6;
+  constexpr int Fo = 32 * MO, Fi = 32 * NI;
+  unsigned short* gt = lds + wave * (Fo + Fi) * kTokPad;   // dy^T tile [Fo][kTokPad]
+  unsigned short* xt = gt + Fo * kTokPad;                  // x^T  tile [Fi][kTokPad]
+  const int64_t t0 = ((int64_t)blockIdx.x * 4 + wave) * a.tiles_per_wave;
+  f32x16 acc[MO][NI], accb[MO];
+#pragma unroll
+  for (int m = 0; m < MO; ++m) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[m][r] = 0.f;
+#pragma unroll
+    for (int n = 0; n < NI; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+  }
+  const u16x8 ones_raw = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  const lin_bf16x8 ones = __builtin_bit_cast(lin_bf16x8, ones_raw);
+  const int64_t ntiles = (a.N + 31) / 32;
+  for (int i = 0; i < a.tiles_per_wave; ++i) {
+    const int64_t tile = t0 + i;
+    if (tile >= ntiles) break;                             // wave-uniform; no block barrier inside this loop
+    const int64_t tokb = tile * 32;
+    // stage both tiles transposed: each lane moves 16 B (8 features of one token) per step
+#pragma unroll 2
+    for (int g = lane; g < 32 * (Fo >> 3); g += 64) {
+      const int tk = g / (Fo >> 3), f8 = (g % (Fo >> 3)) * 8;
+      u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (tokb + tk < a.N) v = *reinterpret_cast<const u16x8*>(a.dy + (tokb + tk) * Fo + f8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gt[(f8 + e) * kTokPad + tk] = v[e];
+    }
+#pragma unroll 2
+    for (int g = lane; g < 32 * (Fi >> 3); g += 64) {
+      const int tk = g / (Fi >> 3), f8 = (g % (Fi >> 3)) * 8;
+      u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (tokb + tk < a.N) v = *reinterpret_cast<const u16x8*>(a.x + (tokb + tk) * Fi + f8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xt[(f8 + e) * kTokPad + tk] = v[e];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {                          // 2 k-steps of 16 tokens
+      lin_bf16x8 af[MO], bf[NI];
+#pragma unroll
+      for (int m = 0; m < MO; ++m) af[m] = *reinterpret_cast<const lin_bf16x8*>(gt + (32 * m + r32) * kTokPad + 16 * s + 8 * hh);
+#pragma unroll
+      for (int n = 0; n < NI; ++n) bf[n] = *reinterpret_cast<const lin_bf16x8*>(xt + (32 * n + r32) * kTokPad + 16 * s + 8 * hh);
+#pragma unroll
+      for (int m = 0; m < MO; ++m) {
+        accb[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], ones, accb[m], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NI; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bf[n], acc[m][n], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+  // fold the block's 4 waves in wave order through LDS (the staging area is free now), then one coalesced dump:
+  // partial[block][row * Fi + col] (row = output feature, col = input feature), db at [Fo * Fi + row]
+  float* red = reinterpret_cast<float*>(lds);
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave != w) continue;
+#pragma unroll
+    for (int m = 0; m < MO; ++m) {
+#pragma unroll
+      for (int n = 0; n < NI; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float* q = red + (32 * m + lin_row(r, hh)) * Fi + 32 * n + r32;
+          *q = (w == 0 ? 0.f : *q) + acc[m][n][r];
+        }
+      if (r32 == 0) {                                      // every column of accb holds the row sums
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float* q = red + Fo * Fi + 32 * m + lin_row(r, hh);
+          *q = (w == 0 ? 0.f : *q) + accb[m][r];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float* out = a.partial + (int64_t)blockIdx.x * ((int64_t)Fo * Fi + Fo);
+  for (int i = threadIdx.x; i < Fo * Fi + Fo; i += 256) out[i] = red[i];
+}
+
+bool lin_dim_ok(int64_t f) { return f == 32 || f == 64 || f == 128 || f == 256; }
+
+template <bool TRANS>
+int lin_launch(const LinArgs& a, int K, int M, hipStream_t st) {
+  const unsigned grid = (unsigned)((((a.N + 31) / 32) * (M / 32) + 3) / 4);
+  const size_t lds = TRANS ? (size_t)M * (K + 8) * 2 : 0;
+  auto big = [&](const void* fn) {
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  };
+  switch (K) {
+    case 32: big((const void*)k_lin<2, TRANS>); k_lin<2, TRANS><<<grid, 256, lds, st>>>(a); return 0;
+    case 64: big((const void*)k_lin<4, TRANS>); k_lin<4, TRANS><<<grid, 256, lds, st>>>(a); return 0;
+    case 128: big((const void*)k_lin<8, TRANS>); k_lin<8, TRANS><<<grid, 256, lds, st>>>(a); return 0;
+    case 256: big((const void*)k_lin<16, TRANS>); k_lin<16, TRANS><<<grid, 256, lds, st>>>(a); return 0;
+  }
+  return -1;
+}
+
+// waves (= partial rows) for the weight gradient: ~1024 waves, each a whole number of 32-token tiles
+void wgrad_geom(int64_t N, int& tiles_per_wave, int64_t& P) {
+  const int64_t ntiles = (N + 31) / 32;
+  int64_t tpw = (ntiles + 1023) / 1024;
+  if (tpw < 1) tpw = 1;
+  tiles_per_wave = (int)tpw;
+  P = ((ntiles + tpw - 1) / tpw + 3) / 4;         // blocks of 4 waves = partial rows
+}
+
+}  // namespace
+
+// y (N, Fo) = x (N, Fi) W^T + bias; all bf16 (bias may be NULL), fp32 accumulation.  Fi, Fo in {32, 64, 128, 256}.
+extern "C" int mivae_linear_fwd(const void* x, const void* w, const void* bias, void* y, int64_t N, int64_t Fi,
+                                int64_t Fo, void* stream) {
+  MIVAE_REQUIRE(N >= 0 && N < (1ll << 31), "linear_fwd: bad N");
+  MIVAE_REQUIRE(lin_dim_ok(Fi) && lin_dim_ok(Fo), "linear_fwd: features must be 32, 64, 128 or 256 (Fi=%lld Fo=%lld)",
+                (long long)Fi, (long long)Fo);
+  if (N == 0) return MIVAE_OK;
+  MIVAE_REQUIRE(x && w && y, "linear_fwd: null pointer");
+  MIVAE_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y), "linear_fwd: operands must be 16-byte aligned");
+  LinArgs a = {(const unsigned short*)x, (const unsigned short*)w, (const unsigned short*)bias, (unsigned short*)y, N,
+               (int)Fo, (int)Fi};
+  MIVAE_REQUIRE(lin_launch<false>(a, (int)Fi, (int)Fo, S_(stream)) == 0, "linear_fwd: no kernel instance");
+  MIVAE_CHECK_LAUNCH("linear_fwd");
+  return MIVAE_OK;
+}
+
+// dx (N, Fi) = dy (N, Fo) W, W (Fo, Fi) row-major.
+extern "C" int mivae_linear_dgrad(const void* dy, const void* w, void* dx, int64_t N, int64_t Fi, int64_t Fo,
+                                  void* stream) {
+  MIVAE_REQUIRE(N >= 0 && N < (1ll << 31), "linear_dgrad: bad N");
+  MIVAE_REQUIRE(lin_dim_ok(Fi) && lin_dim_ok(Fo), "linear_dgrad: features must be 32, 64, 128 or 256 (Fi=%lld Fo=%lld)",
+                (long long)Fi, (long long)Fo);
+  if (N == 0) return MIVAE_OK;
+  MIVAE_REQUIRE(dy && w && dx, "linear_dgrad: null pointer");
+  MIVAE_REQUIRE(aligned16(dy) && aligned16(w) && aligned16(dx), "linear_dgrad: operands must be 16-byte aligned");
+  LinArgs a = {(const unsigned short*)dy, (const unsigned short*)w, nullptr, (unsigned short*)dx, N, (int)Fo, (int)Fi};
+  MIVAE_REQUIRE(lin_launch<true>(a, (int)Fo, (int)Fi, S_(stream)) == 0, "linear_dgrad: no kernel instance");
+  MIVAE_CHECK_LAUNCH("linear_dgrad");
+  return MIVAE_OK;
+}
+
+// rows of the partial matrix mivae_linear_wgrad writes; each row is Fo * Fi + Fo floats
+extern "C" int64_t mivae_linear_wgrad_rows(int64_t N) {
+  if (N <= 0) return 0;
+  int tpw; int64_t P;
+  wgrad_geom(N, tpw, P);
+  return P;
+}
+
+// partial (rows, Fo * Fi + Fo) fp32: per-block [dy^T x | colsum dy] over its token tiles; the column sums of this
+// matrix (mivae_colsum) are [dW (Fo, Fi) row-major | db (Fo)].  Fi, Fo in {32, 64, 128}.
+extern "C" int mivae_linear_wgrad(const void* x, const void* dy, float* partial, int64_t N, int64_t Fi, int64_t Fo,
+                                  void* stream) {
+  MIVAE_REQUIRE(N >= 1 && N < (1ll << 31), "linear_wgrad: bad N");
+  MIVAE_REQUIRE((Fi == 32 || Fi == 64 || Fi == 128) && (Fo == 32 || Fo == 64 || Fo == 128),
+                "linear_wgrad: features must be 32, 64 or 128 (Fi=%lld Fo=%lld)", (long long)Fi, (long long)Fo);
+  MIVAE_REQUIRE(x && dy && partial, "linear_wgrad: null pointer");
+  MIVAE_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(partial), "linear_wgrad: operands must be 16-byte aligned");
+  WgArgs a = {(const unsigned short*)x, (const unsigned short*)dy, partial, N, (int)Fo, (int)Fi, 0};
+  int64_t P;
+  wgrad_geom(N, a.tiles_per_wave, P);
+  const unsigned grid = (unsigned)P;
+  const size_t lds = (size_t)4 * (Fo + Fi) * kTokPad * 2;   // >= (Fo * Fi + Fo) floats for every supported shape
+  hipStream_t st = S_(stream);
+#define WG(MO, NI)                                                                                         \
+  do {                                                                                                     \
+    if (lds > 64 * 1024)                                                                                   \
+      (void)hipFuncSetAttribute((const void*)k_lin_wgrad<MO, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    k_lin_wgrad<MO, NI><<<grid, 256, lds, st>>>(a);                                                        \
+  } while (0)
+  const int mo = (int)Fo / 32, ni = (int)Fi / 32;
+  if (mo == 1 && ni == 1) WG(1, 1); else if (mo == 1 && ni == 2) WG(1, 2); else if (mo == 1 && ni == 4) WG(1, 4);
+  else if (mo == 2 && ni == 1) WG(2, 1); else if (mo == 2 && ni == 2) WG(2, 2); else if (mo == 2 && ni == 4) WG(2, 4);
+  else if (mo == 4 && ni == 1) WG(4, 1); else if (mo == 4 && ni == 2) WG(4, 2); else WG(4, 4);
+#undef WG
+  MIVAE_CHECK_LAUNCH("linear_wgrad");
+  return MIVAE_OK;
+}

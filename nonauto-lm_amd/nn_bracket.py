@@ -29,9 +29,15 @@ class _SplitKLinearFn(torch.autograd.Function):
         # gradients go straight to the fp32 parameters in fp32 (no cast nodes, no bf16 rounding of dW).
         w = weight if w_lp is None else w_lp
         b = bias if b_lp is None else b_lp
-        ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         ctx.param_dtype = weight.dtype
+        ctx.small = ops.linear_small_supported(x, w) and (b is None or b.dtype == torch.bfloat16)
+        if ctx.small:                               # libmivae MFMA kernels: one read of x, one write of y
+            x2 = x.contiguous().view(-1, x.size(-1))
+            ctx.save_for_backward(x2, w)
+            ctx.xshape = x.shape
+            return ops.linear_fwd(x2, w, b).view(*x.shape[:-1], w.size(0))
+        ctx.save_for_backward(x, w)
         with torch.autocast("cuda", enabled=False):
             return F.linear(x, w, b)
 
@@ -39,7 +45,18 @@ class _SplitKLinearFn(torch.autograd.Function):
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
         gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
+        if ctx.small and gy.dtype == torch.bfloat16:
+            g2 = gy.contiguous().view(-1, gy.size(-1))
+            if ctx.needs_input_grad[0]:
+                gx = ops.linear_dgrad(g2, weight).view(ctx.xshape)
+            if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+                if weight.size(0) <= 128 and weight.size(1) <= 128:
+                    gw, gb = ops.linear_wgrad(x, g2)
+                    gw, gb = gw.to(ctx.param_dtype), (gb.to(ctx.param_dtype) if ctx.has_bias else None)
+                    return gx, gw, gb, None, None
+            else:
+                return gx, None, None, None, None
+        if ctx.needs_input_grad[0] and gx is None:
             gx = gy.matmul(weight.to(gy.dtype))
         x2 = x.reshape(-1, x.size(-1))
         g2 = gy.reshape(-1, gy.size(-1))

@@ -341,6 +341,44 @@ def layer_norm(x, weight, bias, eps: float = 1e-5, out_dtype=None):
     return _LayerNorm.apply(x, weight, bias, eps, out_dtype or x.dtype)
 
 
+LINEAR_DIMS = (32, 64, 128, 256)
+
+
+def linear_small_supported(x, weight) -> bool:
+    """bf16 GPU tensors, many tokens, feature counts the MFMA Linear kernels are instantiated for."""
+    return bool(x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
+                and weight.size(0) in LINEAR_DIMS and weight.size(1) in LINEAR_DIMS and weight.is_contiguous()
+                and weight.data_ptr() % 16 == 0)
+
+
+def linear_fwd(x2, w16, b16):
+    """y = x2 w16^T + b16 for x2 (N, Fi) bf16 contiguous (a3 posterior heads, bracket projections)."""
+    N, Fi = x2.shape
+    Fo = w16.size(0)
+    y = torch.empty(N, Fo, dtype=torch.bfloat16, device=x2.device)
+    L.call("mivae_linear_fwd", L.ptr(x2), L.ptr(w16), L.ptr(b16), L.ptr(y), N, Fi, Fo, L.stream())
+    return y
+
+
+def linear_dgrad(g2, w16):
+    N, Fo = g2.shape
+    Fi = w16.size(1)
+    dx = torch.empty(N, Fi, dtype=torch.bfloat16, device=g2.device)
+    L.call("mivae_linear_dgrad", L.ptr(g2), L.ptr(w16), L.ptr(dx), N, Fi, Fo, L.stream())
+    return dx
+
+
+def linear_wgrad(x2, g2):
+    """(dW (Fo, Fi), db (Fo)) fp32 from x2 (N, Fi), g2 (N, Fo) bf16; Fi, Fo <= 128."""
+    N, Fi = x2.shape
+    Fo = g2.size(1)
+    rows = L.query("mivae_linear_wgrad_rows", N)
+    part = torch.empty(rows, Fo * Fi + Fo, dtype=torch.float32, device=x2.device)
+    L.call("mivae_linear_wgrad", L.ptr(x2), L.ptr(g2), L.ptr(part), N, Fi, Fo, L.stream())
+    sums = colsum(part)
+    return sums[:Fo * Fi].view(Fo, Fi), sums[Fo * Fi:]
+
+
 def colsum(x: torch.Tensor) -> torch.Tensor:
     """fp32 column sums of a (rows, D) fp32/bf16 matrix, fixed summation order (bias gradient of a Linear)."""
     L.require_gpu(x)

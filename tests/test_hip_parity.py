@@ -782,3 +782,45 @@ def test_fused_decode_matches_unfused(M):
         out = model.decode(z, mask, tokens)
     assert "logits" not in out
     assert rel_err(out["loss"], ref) < 5e-3           # the unfused path rounds the logits to bf16
+
+
+@pytest.mark.parametrize("N,Fi,Fo,bias", [(16384, 64, 64, True), (8192, 64, 128, True), (4100, 128, 64, False), (4096, 32, 256, True),
+                                          (5000, 256, 256, True), (4096, 128, 128, True)])
+def test_small_linear_kernels_vs_fp64(M, N, Fi, Fo, bias):
+    """libmivae token-parallel Linear (fwd / dgrad / wgrad+bias on MFMA, bf16 operands, fp32 accumulation) vs
+    float64 products of the same bf16-rounded operands (a3 posterior heads, bracket projections)."""
+    gen = torch.Generator().manual_seed(N + Fi + Fo)
+    x = torch.randn(N, Fi, generator=gen).to(torch.bfloat16)
+    w = (torch.randn(Fo, Fi, generator=gen) * 0.2).to(torch.bfloat16)
+    b = torch.randn(Fo, generator=gen).to(torch.bfloat16) if bias else None
+    gy = torch.randn(N, Fo, generator=gen).to(torch.bfloat16)
+    y = M.ops.linear_fwd(dev(x), dev(w), None if b is None else dev(b))
+    ref = x.double() @ w.double().t() + (0 if b is None else b.double())
+    assert y.dtype == torch.bfloat16 and rel_err(y.float(), ref) < 4e-3          # one bf16 rounding on store
+    dx = M.ops.linear_dgrad(dev(gy), dev(w))
+    assert rel_err(dx.float(), gy.double() @ w.double()) < 4e-3
+    if Fi <= 128 and Fo <= 128:
+        dw, db = M.ops.linear_wgrad(dev(x), dev(gy))
+        assert dw.dtype == torch.float32
+        assert rel_err(dw, gy.double().t() @ x.double()) < 1e-5              # exact products, fp32 accumulation
+        assert rel_err(db, gy.double().sum(0)) < 1e-5
+
+
+def test_linear_module_autocast_small_path(M):
+    """nn_bracket.Linear under bf16 autocast (MFMA kernels) vs torch.nn.Linear under the same autocast."""
+    from nonauto_lm_amd.nn_bracket import Linear
+    torch.manual_seed(4)
+    ref = torch.nn.Linear(64, 128).to(DEV)
+    lin = Linear(64, 128).to(DEV)
+    lin.load_state_dict(ref.state_dict())
+    x = torch.randn(64, 128, 64, device=DEV)
+    cot = torch.randn(64, 128, 128, device=DEV)
+    xr, xl = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        yr, yl = ref(xr), lin(xl)
+    (yr.float() * cot).sum().backward()
+    (yl.float() * cot).sum().backward()
+    assert yl.dtype == torch.bfloat16 and rel_err(yl.float(), yr.float()) < 8e-3
+    assert rel_err(xl.grad, xr.grad) < 8e-3
+    assert rel_err(lin.weight.grad, ref.weight.grad) < 8e-3 and rel_err(lin.bias.grad, ref.bias.grad) < 8e-3
+    assert lin.weight.grad.dtype == torch.float32
