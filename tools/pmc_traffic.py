@@ -14,7 +14,8 @@ import sys
 from collections import defaultdict
 
 NAMES = {"k_nll_fwd": "nll_fwd", "k_nll_bwd": "nll_bwd", "k_stack_fwd": "nice_stack_fwd", "k_stack_bwd": "nice_stack_bwd",
-         "k_dw_partial": "nice_dw", "k_dw_reduce": "nice_dw", "k_nll_seq": "nll_fwd"}
+         "k_dw_partial": "nice_dw", "k_dw_reduce": "nice_dw", "k_lce_fwd": "lce_fwd", "k_lce_combine": "lce_fwd",
+         "k_lce_bwd": "lce_bwd"}
 
 
 def collect(directory, counter):
