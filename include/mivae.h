@@ -138,6 +138,12 @@ int mivae_nice_dw(const void* Gt, const void* Ht, const void* dSt, const void* x
                   float* dW1, float* db1, float* dW2, float* db2, int64_t N, int64_t h, int64_t H,
                   int64_t K, int dtype, void* stream);
 
+/* As mivae_nice_dw, but the gradients are ADDED into the parameters' own fp32 gradient buffers: grad_ptrs is a
+ * device int64[K][8] table of addresses in mivae_nice_pack's order (32 per-parameter add kernels less per step). */
+int mivae_nice_dw_sink(const void* Gt, const void* Ht, const void* dSt, const void* x0t, float* workspace,
+                       const int64_t* grad_ptrs, int64_t N, int64_t h, int64_t H, int64_t K, int dtype,
+                       void* stream);
+
 /* ---- ActNorm ------------------------------------------------------------------------------------- */
 /* out = (z exp(log_scale) + bias) * mask  (inverse: ((z - bias) * mask) / (exp(log_scale) + 1e-13));
  * logdet[i] = +-sum(log_scale) * (count_weighted ? token count of row i : 1), i < n_logdet.
@@ -160,6 +166,12 @@ int mivae_actnorm_stats(const void* z, float* mean, float* std, float* workspace
  * the posterior heads' torch.nn.Linear, posterior.py:19-27).  workspace: mivae_col_workspace_floats(rows, D). */
 int mivae_colsum(const void* x, float* out, float* workspace, int64_t rows, int64_t D, int dtype,
                  void* stream);
+
+/* As mivae_colsum, but ADDS columns [0, split) into out0 and [split, D) into out1: a finished [dW | db] row goes
+ * straight into the parameters' gradient buffers (the accumulation autograd's AccumulateGrad would do with one
+ * extra kernel per parameter). */
+int mivae_colsum_sink(const void* x, float* out0, float* out1, int64_t split, float* workspace, int64_t rows,
+                      int64_t D, int dtype, void* stream);
 
 /* ---- KL / ELBO tail -------------------------------------------------------------------------------- */
 /* kl = clamp(logq - logp, min = free_bits) (clamp only if use_fb).  Replaces DefaultKLLoss.forward
@@ -242,6 +254,11 @@ int64_t mivae_layernorm_workspace_floats(int64_t rows, int64_t D);
 int mivae_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                         const float* rstd, void* dx, float* dgamma_dbeta, float* workspace, int64_t rows,
                         int64_t D, int in_dtype, int out_dtype, void* stream);
+
+/* As mivae_layernorm_bwd with d gamma ADDED into dgamma (D) and d beta ADDED into dbeta (D). */
+int mivae_layernorm_bwd_sink(const void* dy, const void* x, const float* gamma, const float* mean,
+                             const float* rstd, void* dx, float* dgamma, float* dbeta, float* workspace,
+                             int64_t rows, int64_t D, int in_dtype, int out_dtype, void* stream);
 
 /* ---- step-harness tail on flat buffers ---------------------------------------------------------- */
 /* Gradient clipping + Adam + zero_grad of DefaultTrainer._train_batch (training/trainers/trainer.py:286-289

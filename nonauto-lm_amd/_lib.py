@@ -36,6 +36,7 @@ SIGNATURES = {
     "mivae_actnorm_bwd": [P, P, P, P, P, P, P, I64, I64, I64, I64, I32, P],
     "mivae_actnorm_stats": [P, P, P, P, I64, I64, I32, P],
     "mivae_colsum": [P, P, P, I64, I64, I32, P],
+    "mivae_colsum_sink": [P, P, P, I64, P, I64, I64, I32, P],
     "mivae_kl_fwd": [P, P, P, I64, I32, F32, P],
     "mivae_kl_bwd": [P, P, P, P, P, I64, I32, F32, P],
     "mivae_elbo_fwd": [P, P, P, I64, I64, F32, F32, I32, P],
@@ -53,6 +54,8 @@ SIGNATURES = {
     "mivae_linear_wgrad": [P, P, P, I64, I64, I64, P],
     "mivae_layernorm_fwd": [P, P, P, P, P, P, I64, I64, F32, I32, I32, P],
     "mivae_layernorm_workspace_floats": [I64, I64],
+    "mivae_layernorm_bwd_sink": [P, P, P, P, P, P, P, P, P, I64, I64, I32, I32, P],
+    "mivae_nice_dw_sink": [P, P, P, P, P, P, I64, I64, I64, I64, I32, P],
     "mivae_layernorm_bwd": [P, P, P, P, P, P, P, P, I64, I64, I32, I32, P],
     "mivae_sumsq_blocks": [I64],
     "mivae_sumsq_partial": [P, P, I64, P],

@@ -467,7 +467,8 @@ __global__ void k_col_partial(const T* __restrict__ x, const T* __restrict__ dou
 // A block of 4 waves owns 64 consecutive (v, c) outputs; wave g sums blocks g, g+4, ... (independent loads,
 // 16 in flight) and the four partial sums are combined through LDS in wave order (fixed order).
 __global__ void __launch_bounds__(256) k_col_finish(const float* __restrict__ partial, float* __restrict__ out,
-                                                    int nblk, int nv, int D, float scale, int take_sqrt) {
+                                                    int nblk, int nv, int D, float scale, int take_sqrt,
+                                                    float* __restrict__ out1 = nullptr, int split = 0, int accumulate = 0) {
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int idx = blockIdx.x * 64 + lane;
@@ -483,14 +484,17 @@ __global__ void __launch_bounds__(256) k_col_finish(const float* __restrict__ pa
   if (grp != 0 || idx >= total) return;
   sum = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
   sum *= scale;
-  out[idx] = take_sqrt ? sqrtf(sum) : sum;
+  sum = take_sqrt ? sqrtf(sum) : sum;
+  float* dst = (out1 && idx >= split) ? out1 + (idx - split) : out + idx;   // two destinations: [0, split) | [split, ..)
+  *dst = accumulate ? *dst + sum : sum;
 }
 
 // Column sums of a short, wide matrix (rows <= a few hundred, e.g. the G split-K partials of a weight
 // gradient): 4 waves split the rows of 64 consecutive columns, combined through LDS in wave order.
 template <typename T>
 __global__ void __launch_bounds__(256) k_colsum_short(const T* __restrict__ x, float* __restrict__ out, int rows,
-                                                      int64_t D) {
+                                                      int64_t D, float* __restrict__ out1 = nullptr, int64_t split = 0,
+                                                      int accumulate = 0) {
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int64_t c = (int64_t)blockIdx.x * 64 + lane;
@@ -505,7 +509,11 @@ __global__ void __launch_bounds__(256) k_colsum_short(const T* __restrict__ x, f
   }
   red[grp][lane] = sum;
   __syncthreads();
-  if (grp == 0 && c < D) out[c] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+  if (grp == 0 && c < D) {
+    const float v = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    float* dst = (out1 && c >= split) ? out1 + (c - split) : out + c;
+    *dst = accumulate ? *dst + v : v;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -946,15 +954,18 @@ extern "C" int mivae_actnorm_stats(const void* z, float* mean, float* std, float
 
 // out[c] = sum over rows of x[row, c] (fp32 accumulation, fixed order): the bias gradient of a Linear layer
 // over many tokens (posterior heads a3, bracket projections).  workspace: mivae_col_workspace_floats.
-extern "C" int mivae_colsum(const void* x, float* out, float* workspace, int64_t rows, int64_t D, int dtype,
-                            void* stream) {
+static int colsum_impl(const void* x, float* out, float* out1, int64_t split, int accumulate, float* workspace,
+                       int64_t rows, int64_t D, int dtype, void* stream) {
   MIVAE_REQUIRE(rows >= 1 && D > 0 && D < (1ll << 31), "colsum: bad shape");
   MIVAE_REQUIRE(dtype == MIVAE_F32 || dtype == MIVAE_BF16, "colsum: bad dtype");
   MIVAE_REQUIRE(x && out && workspace, "colsum: null pointer");
+  MIVAE_REQUIRE(!out1 || (split >= 0 && split <= D), "colsum: bad split");
   if (rows <= 512) {   // short and wide: one pass, no workspace traffic
     unsigned g = (unsigned)((D + 63) / 64);
-    if (dtype == MIVAE_BF16) k_colsum_short<unsigned short><<<g, kBlock, 0, S_(stream)>>>((const unsigned short*)x, out, (int)rows, D);
-    else k_colsum_short<float><<<g, kBlock, 0, S_(stream)>>>((const float*)x, out, (int)rows, D);
+    if (dtype == MIVAE_BF16)
+      k_colsum_short<unsigned short><<<g, kBlock, 0, S_(stream)>>>((const unsigned short*)x, out, (int)rows, D, out1, split, accumulate);
+    else
+      k_colsum_short<float><<<g, kBlock, 0, S_(stream)>>>((const float*)x, out, (int)rows, D, out1, split, accumulate);
     MIVAE_CHECK_LAUNCH("colsum_short");
     return MIVAE_OK;
   }
@@ -963,9 +974,24 @@ extern "C" int mivae_colsum(const void* x, float* out, float* workspace, int64_t
                c.nblk, 1, 1, (int)D, c.L, S_(stream));
   MIVAE_CHECK_LAUNCH("colsum_partial");
   unsigned grid = (unsigned)((D + 63) / 64);
-  k_col_finish<<<grid, kBlock, 0, S_(stream)>>>(workspace, out, c.nblk, 1, (int)D, 1.f, 0);
+  k_col_finish<<<grid, kBlock, 0, S_(stream)>>>(workspace, out, c.nblk, 1, (int)D, 1.f, 0, out1, (int)split, accumulate);
   MIVAE_CHECK_LAUNCH("colsum_finish");
   return MIVAE_OK;
+}
+
+// out[c] = sum over rows of x[row, c] (fp32 accumulation, fixed order): the bias gradient of a Linear layer
+// over many tokens (posterior heads a3, bracket projections).  workspace: mivae_col_workspace_floats.
+extern "C" int mivae_colsum(const void* x, float* out, float* workspace, int64_t rows, int64_t D, int dtype,
+                            void* stream) {
+  return colsum_impl(x, out, nullptr, 0, 0, workspace, rows, D, dtype, stream);
+}
+
+// The same sums ADDED into two destinations: columns [0, split) += into out0, columns [split, D) += into out1
+// (e.g. the [dW | db] row of mivae_linear_wgrad straight into weight.grad and bias.grad).
+extern "C" int mivae_colsum_sink(const void* x, float* out0, float* out1, int64_t split, float* workspace,
+                                 int64_t rows, int64_t D, int dtype, void* stream) {
+  MIVAE_REQUIRE(out1, "colsum_sink: null pointer");
+  return colsum_impl(x, out0, out1, split, 1, workspace, rows, D, dtype, stream);
 }
 
 extern "C" int mivae_kl_fwd(const float* logq, const float* logp, float* kl, int64_t n, int use_fb,

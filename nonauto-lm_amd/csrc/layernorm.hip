@@ -145,7 +145,8 @@ __global__ __launch_bounds__(kBlock) void k_ln_bwd(const TO* __restrict__ dy, co
 
 // out[idx] = sum_b partial[b][idx], idx < total: 4 waves split the blocks, combined in wave order
 __global__ void __launch_bounds__(256) k_ln_finish(const float* __restrict__ partial, float* __restrict__ out,
-                                                   int nblk, int total) {
+                                                   int nblk, int total, float* __restrict__ out1, int split,
+                                                   int accumulate) {
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int idx = blockIdx.x * 64 + lane;
@@ -156,7 +157,11 @@ __global__ void __launch_bounds__(256) k_ln_finish(const float* __restrict__ par
   }
   red[grp][lane] = sum;
   __syncthreads();
-  if (grp == 0 && idx < total) out[idx] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+  if (grp == 0 && idx < total) {
+    const float v = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    float* dst = (out1 && idx >= split) ? out1 + (idx - split) : out + idx;
+    *dst = accumulate ? *dst + v : v;
+  }
 }
 
 struct LnCfg { int vec, L, nblk, rows_per_block; };
@@ -226,9 +231,9 @@ extern "C" int mivae_layernorm_fwd(const void* x, const float* gamma, const floa
   return MIVAE_OK;
 }
 
-extern "C" int mivae_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
-                                   const float* rstd, void* dx, float* dgamma_dbeta, float* workspace, int64_t rows,
-                                   int64_t D, int in_dtype, int out_dtype, void* stream) {
+static int layernorm_bwd_impl(const void* dy, const void* x, const float* gamma, const float* mean,
+                              const float* rstd, void* dx, float* dgamma_dbeta, float* dbeta_sink, float* workspace,
+                              int64_t rows, int64_t D, int in_dtype, int out_dtype, void* stream) {
   MIVAE_REQUIRE(rows >= 1 && D >= 1, "layernorm_bwd: bad shape");
   MIVAE_REQUIRE((in_dtype == MIVAE_F32 || in_dtype == MIVAE_BF16) && (out_dtype == MIVAE_F32 || out_dtype == MIVAE_BF16),
                 "layernorm_bwd: dtype must be 0 (f32) or 1 (bf16)");
@@ -243,7 +248,22 @@ extern "C" int mivae_layernorm_bwd(const void* dy, const void* x, const float* g
   else launch_bwd<unsigned short, unsigned short>(c, dy, x, gamma, mean, rstd, dx, workspace, rows, (int)D, st);
   MIVAE_CHECK_LAUNCH("layernorm_bwd");
   const int total = 2 * (int)D;
-  k_ln_finish<<<(unsigned)((total + 63) / 64), 256, 0, st>>>(workspace, dgamma_dbeta, c.nblk, total);
+  k_ln_finish<<<(unsigned)((total + 63) / 64), 256, 0, st>>>(workspace, dgamma_dbeta, c.nblk, total, dbeta_sink, (int)D,
+                                                              dbeta_sink ? 1 : 0);
   MIVAE_CHECK_LAUNCH("layernorm_bwd_finish");
   return MIVAE_OK;
+}
+
+extern "C" int mivae_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                                   const float* rstd, void* dx, float* dgamma_dbeta, float* workspace, int64_t rows,
+                                   int64_t D, int in_dtype, int out_dtype, void* stream) {
+  return layernorm_bwd_impl(dy, x, gamma, mean, rstd, dx, dgamma_dbeta, nullptr, workspace, rows, D, in_dtype, out_dtype, stream);
+}
+
+// Same, with d gamma ADDED into dgamma (D) and d beta ADDED into dbeta (D): the parameters' gradient buffers.
+extern "C" int mivae_layernorm_bwd_sink(const void* dy, const void* x, const float* gamma, const float* mean,
+                                        const float* rstd, void* dx, float* dgamma, float* dbeta, float* workspace,
+                                        int64_t rows, int64_t D, int in_dtype, int out_dtype, void* stream) {
+  MIVAE_REQUIRE(dbeta, "layernorm_bwd_sink: null pointer");
+  return layernorm_bwd_impl(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, D, in_dtype, out_dtype, stream);
 }

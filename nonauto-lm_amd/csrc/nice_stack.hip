@@ -957,6 +957,7 @@ struct DwArgs {
   float* partb1;  // [items][32]        (type 0 items only are meaningful)
   float* partb2;  // [K*2][nslab][hp]
   float *dW1, *db1, *dW2, *db2;
+  const int64_t* sink;   // optional device table [K*2][4] of fp32 gradient addresses {W1, b1, W2, b2}: accumulate there
   int64_t Npad;
   int K, h, H, hp, Hp, HT, HC, nslab, slab_len;
   int64_t nitems;
@@ -1072,6 +1073,11 @@ __global__ void __launch_bounds__(256) k_dw_reduce(DwArgs a) {
     const int r = e & 15, cl = e >> 4, cc = cl & 31, hh = cl >> 5;
     const int row = 32 * mt + (r & 3) + 4 * hh + 8 * (r >> 2), col = 32 * t + cc;
     if (row >= a.H || col >= a.h) return;
+    if (a.sink) {          // straight into the parameters' gradient buffers (+=): no per-parameter add kernels
+      if (type == 0) reinterpret_cast<float*>(a.sink[kn * 4 + 0])[row * a.h + col] += s;
+      else reinterpret_cast<float*>(a.sink[kn * 4 + 2])[col * a.H + row] += s;
+      return;
+    }
     if (type == 0) a.dW1[((int64_t)kn * a.H + row) * a.h + col] = s;
     else a.dW2[((int64_t)kn * a.h + col) * a.H + row] = s;
     return;
@@ -1082,13 +1088,15 @@ __global__ void __launch_bounds__(256) k_dw_reduce(DwArgs a) {
     const int64_t item0 = (((int64_t)kn * 2 + 0) * a.HC + row / 32) * a.nslab;
     float s = 0.f;
     for (int sl = 0; sl < a.nslab; ++sl) s += a.partb1[(item0 + sl) * 32 + row % 32];
-    a.db1[idx] = s;
+    if (a.sink) reinterpret_cast<float*>(a.sink[kn * 4 + 1])[row] += s;
+    else a.db1[idx] = s;
   } else if (idx < nb1 + nb2) {
     idx -= nb1;
     const int out = (int)(idx % a.h); const int kn = (int)(idx / a.h);
     float s = 0.f;
     for (int sl = 0; sl < a.nslab; ++sl) s += a.partb2[((int64_t)kn * a.nslab + sl) * a.hp + out];
-    a.db2[idx] = s;
+    if (a.sink) reinterpret_cast<float*>(a.sink[kn * 4 + 3])[out] += s;
+    else a.db2[idx] = s;
   }
 }
 
@@ -1278,10 +1286,10 @@ extern "C" int64_t mivae_nice_dw_workspace_floats(int64_t N, int64_t h, int64_t 
   return nitems * ((int64_t)g.HT * 1024 + 32) + (int64_t)K * 2 * nslab * g.hp;
 }
 
-extern "C" int mivae_nice_dw(const void* Gt, const void* Ht, const void* dSt, const void* x0t,
-                             float* workspace, float* dW1, float* db1, float* dW2, float* db2,
-                             int64_t N, int64_t h, int64_t H, int64_t K, int dtype, void* stream) {
-  MIVAE_REQUIRE(Gt && Ht && dSt && x0t && workspace && dW1 && db1 && dW2 && db2, "nice_dw: null pointer");
+static int nice_dw_impl(const void* Gt, const void* Ht, const void* dSt, const void* x0t,
+                        float* workspace, float* dW1, float* db1, float* dW2, float* db2, const int64_t* sink,
+                        int64_t N, int64_t h, int64_t H, int64_t K, int dtype, void* stream) {
+  MIVAE_REQUIRE(Gt && Ht && dSt && x0t && workspace && (sink || (dW1 && db1 && dW2 && db2)), "nice_dw: null pointer");
   MIVAE_REQUIRE(N >= 1 && h >= 1 && H >= 1 && K >= 1 && K <= 4096, "nice_dw: bad shape");
   MIVAE_REQUIRE(dtype == MIVAE_F32 || dtype == MIVAE_BF16, "nice_dw: bad dtype %d", dtype);
   Geom g = make_geom((int)h, (int)H, (int)K, dtype == MIVAE_BF16);
@@ -1296,7 +1304,7 @@ extern "C" int mivae_nice_dw(const void* Gt, const void* Ht, const void* dSt, co
   a.part = workspace;
   a.partb1 = workspace + a.nitems * (int64_t)g.HT * 1024;
   a.partb2 = a.partb1 + a.nitems * 32;
-  a.dW1 = dW1; a.db1 = db1; a.dW2 = dW2; a.db2 = db2;
+  a.dW1 = dW1; a.db1 = db1; a.dW2 = dW2; a.db2 = db2; a.sink = sink;
   int rc = dtype == MIVAE_BF16 ? launch_dw<MmaBF16, unsigned short>(g.HT, a, (hipStream_t)stream)
                                : launch_dw<MmaF32, float>(g.HT, a, (hipStream_t)stream);
   MIVAE_REQUIRE(rc == 0, "nice_dw: no kernel instance");
@@ -1305,4 +1313,19 @@ extern "C" int mivae_nice_dw(const void* Gt, const void* Ht, const void* dSt, co
   k_dw_reduce<<<(unsigned)nblk, 256, 0, (hipStream_t)stream>>>(a);
   MIVAE_CHECK_LAUNCH("nice_dw_reduce");
   return MIVAE_OK;
+}
+
+extern "C" int mivae_nice_dw(const void* Gt, const void* Ht, const void* dSt, const void* x0t,
+                             float* workspace, float* dW1, float* db1, float* dW2, float* db2,
+                             int64_t N, int64_t h, int64_t H, int64_t K, int dtype, void* stream) {
+  return nice_dw_impl(Gt, Ht, dSt, x0t, workspace, dW1, db1, dW2, db2, nullptr, N, h, H, K, dtype, stream);
+}
+
+// Same products, ADDED into the parameters' own fp32 gradient buffers: grad_ptrs is a device int64[K][8] table
+// of addresses in mivae_nice_pack's order {W1s,b1s,W2s,b2s,W1t,b1t,W2t,b2t} (each element written by one thread).
+extern "C" int mivae_nice_dw_sink(const void* Gt, const void* Ht, const void* dSt, const void* x0t,
+                                  float* workspace, const int64_t* grad_ptrs, int64_t N, int64_t h, int64_t H,
+                                  int64_t K, int dtype, void* stream) {
+  MIVAE_REQUIRE(grad_ptrs, "nice_dw_sink: null pointer table");
+  return nice_dw_impl(Gt, Ht, dSt, x0t, workspace, nullptr, nullptr, nullptr, nullptr, grad_ptrs, N, h, H, K, dtype, stream);
 }

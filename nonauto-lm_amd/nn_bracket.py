@@ -31,6 +31,7 @@ class _SplitKLinearFn(torch.autograd.Function):
         b = bias if b_lp is None else b_lp
         ctx.has_bias = bias is not None
         ctx.param_dtype = weight.dtype
+        ctx.params = (weight, bias)
         ctx.small = ops.linear_small_supported(x, w) and (b is None or b.dtype == torch.bfloat16)
         if ctx.small:                               # libmivae MFMA kernels: one read of x, one write of y
             x2 = x.contiguous().view(-1, x.size(-1))
@@ -51,6 +52,9 @@ class _SplitKLinearFn(torch.autograd.Function):
                 gx = ops.linear_dgrad(g2, weight).view(ctx.xshape)
             if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
                 if weight.size(0) <= 128 and weight.size(1) <= 128:
+                    if ctx.has_bias and all(ctx.needs_input_grad[1:3]) and ops.grad_sink_ok(*ctx.params):
+                        ops.linear_wgrad(x, g2, sink=(ctx.params[0].grad, ctx.params[1].grad))
+                        return gx, None, None, None, None
                     gw, gb = ops.linear_wgrad(x, g2)
                     gw, gb = gw.to(ctx.param_dtype), (gb.to(ctx.param_dtype) if ctx.has_bias else None)
                     return gx, gw, gb, None, None

@@ -316,6 +316,7 @@ class _LayerNorm(torch.autograd.Function):
                rows, D, float(eps), L.dtype_code(x2.dtype), L.dtype_code(out_dtype), L.stream())
         ctx.save_for_backward(x2, weight, stats)
         ctx.shape = x.shape
+        ctx.params = (weight, bias)
         return y.view(x.shape)
 
     @staticmethod
@@ -324,8 +325,14 @@ class _LayerNorm(torch.autograd.Function):
         rows, D = x2.shape
         dy2 = dy.contiguous().view(rows, D)
         dx = torch.empty_like(x2)
-        dgb = torch.empty(2, D, dtype=torch.float32, device=x2.device)
         ws = torch.empty(L.query("mivae_layernorm_workspace_floats", rows, D), dtype=torch.float32, device=x2.device)
+        if grad_sink_ok(*ctx.params):
+            gw, gb = ctx.params[0].grad, ctx.params[1].grad
+            L.call("mivae_layernorm_bwd_sink", L.ptr(dy2), L.ptr(x2), L.ptr(weight), L.ptr(stats[0]), L.ptr(stats[1]),
+                   L.ptr(dx), L.ptr(gw), L.ptr(gb), L.ptr(ws), rows, D, L.dtype_code(x2.dtype), L.dtype_code(dy2.dtype),
+                   L.stream())
+            return dx.view(ctx.shape), None, None, None, None
+        dgb = torch.empty(2, D, dtype=torch.float32, device=x2.device)
         L.call("mivae_layernorm_bwd", L.ptr(dy2), L.ptr(x2), L.ptr(weight), L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(dx),
                L.ptr(dgb), L.ptr(ws), rows, D, L.dtype_code(x2.dtype), L.dtype_code(dy2.dtype), L.stream())
         return dx.view(ctx.shape), dgb[0], dgb[1], None, None
@@ -339,6 +346,23 @@ def layer_norm(x, weight, bias, eps: float = 1e-5, out_dtype=None):
     residual stream be normalised straight into bf16 for the projection that follows."""
     L.require_gpu(x, weight, bias)
     return _LayerNorm.apply(x, weight, bias, eps, out_dtype or x.dtype)
+
+
+# Gradient sinks: when enabled (step.TrainStep turns it on), the weight-gradient kernels of the custom Functions add
+# their results straight into `param.grad` (the reducer's flat-bucket views) and return None for those inputs, so
+# autograd launches no per-parameter accumulation kernel.  Post-accumulate hooks do not fire for such parameters
+# (GradReducer.finish() flushes every bucket anyway).
+GRAD_SINK = False
+
+
+def grad_sink_ok(*params) -> bool:
+    if not GRAD_SINK:
+        return False
+    for p in params:
+        g = getattr(p, "grad", None)
+        if g is None or g.dtype != torch.float32 or not g.is_cuda or not g.is_contiguous():
+            return False
+    return True
 
 
 LINEAR_DIMS = (32, 64, 128, 256)
@@ -368,13 +392,19 @@ def linear_dgrad(g2, w16):
     return dx
 
 
-def linear_wgrad(x2, g2):
-    """(dW (Fo, Fi), db (Fo)) fp32 from x2 (N, Fi), g2 (N, Fo) bf16; Fi, Fo <= 128."""
+def linear_wgrad(x2, g2, sink=None):
+    """(dW (Fo, Fi), db (Fo)) fp32 from x2 (N, Fi), g2 (N, Fo) bf16; Fi, Fo <= 128.  `sink` = (weight.grad,
+    bias.grad): the sums are added there instead and None is returned."""
     N, Fi = x2.shape
     Fo = g2.size(1)
     rows = L.query("mivae_linear_wgrad_rows", N)
     part = torch.empty(rows, Fo * Fi + Fo, dtype=torch.float32, device=x2.device)
     L.call("mivae_linear_wgrad", L.ptr(x2), L.ptr(g2), L.ptr(part), N, Fi, Fo, L.stream())
+    if sink is not None:
+        D = Fo * Fi + Fo
+        ws = torch.empty(L.query("mivae_col_workspace_floats", rows, D, 0), dtype=torch.float32, device=x2.device)
+        L.call("mivae_colsum_sink", L.ptr(part), L.ptr(sink[0]), L.ptr(sink[1]), Fo * Fi, L.ptr(ws), rows, D, 0, L.stream())
+        return None
     sums = colsum(part)
     return sums[:Fo * Fi].view(Fo, Fi), sums[Fo * Fi:]
 
@@ -607,6 +637,7 @@ class _NiceStack(torch.autograd.Function):
                    L.stream())
         ctx.meta = (Bn, S, D, H, K, act, int(base), float(mu), float(std), code)
         ctx.shapes = [tuple(p.shape) for p in params]
+        ctx.params = params
         if need_grad:
             ctx.save_for_backward(z, z_out, hist, mask, packed)
         return z_out, tok
@@ -635,6 +666,12 @@ class _NiceStack(torch.autograd.Function):
         # Weight gradients: split-K NT MFMA products over the token axis on the emitted
         # [feature][token] tensors, reduced in fixed order (k_dw_partial / k_dw_reduce).
         ws = torch.empty(L.query("mivae_nice_dw_workspace_floats", N, h, H, K), dtype=torch.float32, device=z.device)
+        if grad_sink_ok(*ctx.params) and all(ctx.needs_input_grad[8:]):
+            table = _ptr_table([p.grad for p in ctx.params], z.device)
+            with _timed("nice_dw"):
+                L.call("mivae_nice_dw_sink", L.ptr(Gt), L.ptr(Ht), L.ptr(dSt), L.ptr(x0t), L.ptr(ws), L.ptr(table),
+                       N, h, H, K, code, L.stream())
+            return (dz_in, None, None, None, None, None, None, None, *([None] * len(ctx.params)))
         dW1 = torch.empty(K, 2, H, h, dtype=torch.float32, device=z.device)
         db1 = torch.empty(K, 2, H, dtype=torch.float32, device=z.device)
         dW2 = torch.empty(K, 2, h, H, dtype=torch.float32, device=z.device)

@@ -30,11 +30,20 @@ class TrainStep:
         self.world = dp.world_size()
         self.info: Optional[Dict[str, torch.Tensor]] = None
         self.graph_a = self.graph_b = None
+        self.grad_sink = True
         if graph:
             self._capture(warmup)
 
     # ---- pieces ---------------------------------------------------------------------------------
     def _fwd_bwd(self):
+        from . import ops
+        ops.GRAD_SINK = self.grad_sink       # weight-gradient kernels add straight into the flat buckets
+        try:
+            return self._fwd_bwd_inner()
+        finally:
+            ops.GRAD_SINK = False
+
+    def _fwd_bwd_inner(self):
         with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
             out = self.model(self.tokens, self.tokens)
         info = out["loss_info"]

@@ -824,3 +824,31 @@ def test_linear_module_autocast_small_path(M):
     assert rel_err(xl.grad, xr.grad) < 8e-3
     assert rel_err(lin.weight.grad, ref.weight.grad) < 8e-3 and rel_err(lin.bias.grad, ref.bias.grad) < 8e-3
     assert lin.weight.grad.dtype == torch.float32
+
+
+def test_grad_sink_matches_autograd_accumulation(M):
+    """ops.GRAD_SINK (weight-gradient kernels add straight into param.grad = the reducer's bucket views) gives the
+    same gradients as autograd's own accumulation, for the whole model under bf16 autocast."""
+    import bench
+    from nonauto_lm_amd import dp
+    torch.manual_seed(11)
+    model = M.VAELmModel.from_params(vocab=M.SimpleVocab(512), **bench.model_config(64, 64, 2)).to(DEV).train()
+    model.training_outputs_only = True
+    reducer = dp.GradReducer(model.parameters(), flatten_params=True)
+    tokens = bench.synthetic_tokens(64, 64, True, 3)                     # 4096 tokens: the MFMA Linear path is taken
+    tokens = torch.where(tokens > 0, tokens % 500 + 4, tokens).to(DEV)
+    eps = torch.randn(64, 1, 64, 64, device=DEV)
+    grads = {}
+    for sink in (False, True):
+        reducer.zero_grad()
+        M.ops.GRAD_SINK = sink
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = model(tokens, tokens, eps=eps)
+            out["loss_info"]["batch-loss"].backward()
+        finally:
+            M.ops.GRAD_SINK = False
+        grads[sink] = [b.clone() for b in reducer.buckets]
+    assert any(float(b.abs().max()) > 0 for b in grads[True])
+    for a, b in zip(grads[False], grads[True]):
+        assert torch.equal(a, b)
