@@ -421,29 +421,45 @@ __global__ __launch_bounds__(256) void k_lce_bwd(LceArgs a) {
   lce_bf16x8 hf[NF];
   lce_load_h<NF>(a.h, tok, valid, hh, hf);
   const int t = valid ? (int)a.target[tok] : -1;
-  const float l2 = valid ? a.lse[tok] * kLog2e : 0.f;
+  // coef * softmax = sign(coef) * 2^(x log2e - lse log2e + log2|coef|): one fma + one v_exp_f32 per element, the sign
+  // goes on with an integer xor (coef = 0 -> 2^-inf = 0: padding tokens inside a live tile get exact zeros)
+  const float c0 = valid ? __builtin_amdgcn_logf(fabsf(coef)) - a.lse[tok] * kLog2e : -INFINITY;
+  const unsigned sgn = __float_as_uint(coef) & 0x80000000u;
   const float uni = coef * (a.smoothing > 0.f ? a.smoothing / (float)a.V : 0.f);
   const float hot = coef * (a.smoothing > 0.f ? 1.f - a.smoothing : 1.f);
+  const bool smooth = a.smoothing > 0.f;
   lce_bf16x8 wf[2][NF];
   for (int p = p0; p < p1; ++p) {
     lce_load_w<NF>(a.W, 2 * p, r32, hh, wf[0]);
     lce_load_w<NF>(a.W, 2 * p + 1, r32, hh, wf[1]);
-    const bool anyt = __any((t >> 6) == p) != 0;   // a target of this tile falls into this pair of chunks
+    // a target of this tile falls into this pair of chunks, or label smoothing: the slow element path (wave-uniform)
+    const bool slow = smooth || (__any((t >> 6) == p) != 0);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int c = 2 * p + u;
       const f32x16 x = lce_tile<NF>(wf[u], hf);
-      const int rel = anyt ? t - 32 * c - 4 * hh : -1;
+      if (!slow) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        u16x4 o;
+        for (int q = 0; q < 4; ++q) {
+          u16x4 o;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float g = fmaf(coef, ex2(fmaf(x[4 * q + i], kLog2e, -l2)), -uni);
-          if (anyt && rel == i + 8 * q) g -= hot;
-          o[i] = f32_to_bf16(g);
+          for (int i = 0; i < 4; ++i)
+            o[i] = f32_to_bf16(__uint_as_float(__float_as_uint(ex2(fmaf(x[4 * q + i], kLog2e, c0))) ^ sgn));
+          *reinterpret_cast<u16x4*>(stage + r32 * kLceStride + 32 * u + 8 * q + 4 * hh) = o;
         }
-        *reinterpret_cast<u16x4*>(stage + r32 * kLceStride + 32 * u + 8 * q + 4 * hh) = o;
+      } else {
+        const int rel = t - 32 * c - 4 * hh;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          u16x4 o;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float g = __uint_as_float(__float_as_uint(ex2(fmaf(x[4 * q + i], kLog2e, c0))) ^ sgn) - uni;
+            if (rel == i + 8 * q) g -= hot;
+            o[i] = f32_to_bf16(g);
+          }
+          *reinterpret_cast<u16x4*>(stage + r32 * kLceStride + 32 * u + 8 * q + 4 * hh) = o;
+        }
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
