@@ -208,6 +208,16 @@ class MultiHeadAttention(torch.nn.Module):
         k = self._split(self._projections["key"](key))
         v = self._split(self._projections["value"](value))
         S = q.size(2)
+        if (q.is_cuda and q.dtype == torch.bfloat16 and torch.is_autocast_enabled()
+                and not (self.training and isinstance(self._dropout, torch.nn.Dropout) and self._dropout.p > 0)):
+            # bf16 training bracket: the library's fused attention (same key-padding x causal mask, -inf instead of
+            # -1e13 fill: identical for every row that has a valid key, i.e. always with prefix masks)
+            keep = None if mask is None else mask.ne(0)[:, None, None, :]
+            if self._mask_tril:
+                tril = torch.ones(S, S, dtype=torch.bool, device=q.device).tril()[None, None]
+                keep = tril if keep is None else keep & tril
+            out = F.scaled_dot_product_attention(q, k, v, attn_mask=keep)
+            return self._output(out.transpose(1, 2).reshape(q.size(0), S, -1))
         scores = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(self._attn_size)
         if mask is None:
             keep = torch.ones(q.size(0), 1, 1, S, dtype=torch.bool, device=q.device)
