@@ -220,6 +220,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bucket-mb", type=int, default=32)
     ap.add_argument("--torch-adam", action="store_true", help="stock torch.optim.Adam + separate clip passes")
+    ap.add_argument("--no-sdpa", action="store_true", help="explicit masked-softmax attention in the bracket")
     ap.add_argument("--eager", action="store_true", help="no HIP-graph replay of the step (hook-overlapped all-reduce)")
     args = ap.parse_args()
 
@@ -237,6 +238,8 @@ def main():
     from nonauto_lm_amd import dp, ops
     from nonauto_lm_amd.step import TrainStep
     M._lib.lib()                                   # the HIP extension is mandatory
+    if args.no_sdpa:
+        M.nn_bracket.USE_FUSED_ATTENTION = False
 
     B, S, D, H, K, dtype_name, ragged = CONFIGS[args.config]
     amp_dtype = torch.bfloat16 if dtype_name == "bf16" else None

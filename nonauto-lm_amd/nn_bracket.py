@@ -4,6 +4,7 @@ label-smoothing NLL.  They run on PyTorch-ROCm library ops (rocBLAS / MIOpen); n
 Parameter names follow the reference so its checkpoints load (state-dict keys).
 """
 import math
+import os
 from typing import Callable, Dict, List, NamedTuple, Union
 
 import torch
@@ -180,6 +181,12 @@ def _maybe_dropout(p):
     return torch.nn.Dropout(p) if p and p > 0 else torch.nn.Identity()
 
 
+# bf16 training bracket: use the library's fused attention kernel (set MIVAE_NO_SDPA=1 or this flag to False to keep
+# the explicit masked-softmax path, e.g. to profile a HIP-graph replayed step with rocprofv3, which aborts on the
+# graph-captured library attention kernel on ROCm 7.2)
+USE_FUSED_ATTENTION = os.environ.get("MIVAE_NO_SDPA", "0") != "1"
+
+
 class MultiHeadAttention(torch.nn.Module):
     """nn/transformer.py:7-117: separate q/k/v projections, masked_fill(-1e13) on padded keys,
     optional causal (tril) mask.  Scores are materialised like the reference (S <= 512 here)."""
@@ -208,7 +215,7 @@ class MultiHeadAttention(torch.nn.Module):
         k = self._split(self._projections["key"](key))
         v = self._split(self._projections["value"](value))
         S = q.size(2)
-        if (q.is_cuda and q.dtype == torch.bfloat16 and torch.is_autocast_enabled()
+        if (USE_FUSED_ATTENTION and q.is_cuda and q.dtype == torch.bfloat16 and torch.is_autocast_enabled()
                 and not (self.training and isinstance(self._dropout, torch.nn.Dropout) and self._dropout.p > 0)):
             # bf16 training bracket: the library's fused attention (same key-padding x causal mask, -inf instead of
             # -1e13 fill: identical for every row that has a valid key, i.e. always with prefix masks)
