@@ -68,7 +68,77 @@ ACTIVATIONS = {
     "relu": torch.relu,
     "tanh": torch.tanh,
     "sigmoid": torch.sigmoid,
+    "elu": torch.nn.functional.elu,
 }
+
+
+# ----------------------------------------------------------------------------- MADE / MAF / IAF (8f-2)
+def made_masks(input_size: int, hidden_sizes: Sequence[int], permute_order: bool = True, seed: int = 13):
+    """Connectivity masks of MADE, one (in, out) 0/1 array per MaskedLinear.  made.py:93-118.
+
+    numpy RandomState(seed): input order = permutation (or arange), hidden degrees =
+    randint(min(previous degrees), input_size - 1); hidden masks use <=, the output mask uses < and is
+    replicated for the two (s, t) output groups."""
+    import numpy as np
+    rng = np.random.RandomState(seed)
+    deg = {-1: rng.permutation(input_size) if permute_order else np.arange(input_size)}
+    n = len(hidden_sizes)
+    for layer in range(n):
+        deg[layer] = rng.randint(deg[layer - 1].min(), input_size - 1, size=hidden_sizes[layer])
+    masks = [deg[layer - 1][:, None] <= deg[layer][None, :] for layer in range(n)]
+    last = deg[n - 1][:, None] < deg[-1][None, :]
+    masks.append(np.concatenate([last, last], axis=1))
+    return [torch.from_numpy(m.astype("float32")) for m in masks]
+
+
+def made_forward(z, weights, biases, weight_masks, activation: str = "elu"):
+    """MADE.forward: Linear(x, W * weight_mask, b) + activation per layer, no activation after the
+    last.  made.py:39-40, :73-83, :124-127.  `weight_masks` are the (out, in) buffers of the state dict."""
+    act = ACTIVATIONS[activation]
+    x = z
+    for i, (w, b, m) in enumerate(zip(weights, biases, weight_masks)):
+        x = x @ (w * m).t() + b
+        if i + 1 < len(weights):
+            x = act(x)
+    return x
+
+
+def maf_forward(z, made, parity: bool, mask=None):
+    """MAFlow.forward (density direction, one MADE pass).  maf.py:29-45."""
+    D = z.size(-1)
+    st = made(z)
+    s, t = st[..., :D], st[..., D:]
+    out = z * torch.exp(s) + t
+    if parity:
+        out = out.flip(dims=(-1,))
+    log_det = s.sum(dim=-1)
+    if mask is not None:
+        out = out * mask.unsqueeze(-1)
+        log_det = (log_det * mask).sum(dim=-1)
+    return out, log_det
+
+
+def maf_sequential(z, made, parity: bool, mask=None):
+    """MAFlow.backward (sampling direction; IAFlow's training direction, iaf.py:21-23): D sequential MADE
+    passes in NATURAL feature order whatever the MADE ordering is, log-det accumulated with +s.
+    maf.py:47-62.  For 2-D input the reference builds a (B, D) log-det (maf.py:52) that only broadcasts when
+    B == D; the intended per-row sum is returned here."""
+    D = z.size(-1)
+    x = torch.zeros_like(z)
+    log_det = torch.zeros(z.shape[:-1], dtype=z.dtype)
+    zz = z.flip(dims=(-1,)) if parity else z
+    cols = []
+    for i in range(D):
+        st = made(x)
+        s, t = st[..., :D], st[..., D:]
+        xi = (zz[..., i] - t[..., i]) * torch.exp(-s[..., i])
+        cols.append(xi)
+        x = torch.cat([torch.stack(cols, dim=-1), torch.zeros_like(z[..., i + 1:])], dim=-1)
+        log_det = log_det + s[..., i]
+    if mask is not None:
+        x = x * mask.unsqueeze(-1)
+        log_det = (log_det * mask).sum(dim=-1)
+    return x, log_det
 
 
 # ----------------------------------------------------------------------------- coupling MLP

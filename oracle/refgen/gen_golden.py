@@ -31,6 +31,9 @@ from vae_lm.models.base.flows.couplings import (  # noqa: E402
 from vae_lm.nn.recurrent import LSTMCore, GRUCore  # noqa: E402
 from vae_lm.models.base.flows.invertible_flows import (  # noqa: E402
     InvertibleLinearFlow, InvertibleMultiHeadFlow)
+from vae_lm.models.base.flows.made import MADE  # noqa: E402
+from vae_lm.models.base.flows.maf import MAFlow  # noqa: E402
+from vae_lm.models.base.flows.iaf import IAFlow  # noqa: E402
 from vae_lm.models.base import LatentSample  # noqa: E402
 from vae_lm.models.base.losses import LabelSmoothingNLL  # noqa: E402
 from vae_lm.models.base.model import VAELmModel  # noqa: E402
@@ -90,6 +93,52 @@ def jitter(module, gen, scale=0.15):
             if not p.requires_grad:      # frozen sinusoid tables (`_pos_enc`) are constants, not weights
                 continue
             p.add_(scale * torch.randn(p.shape, generator=gen))
+
+
+# ----------------------------------------------------------------------------- MAF / IAF / MADE (8f-2)
+def gen_maf(name, kind, B, S, D, hidden, K, mask_kind, seed, permute=True, activation="elu"):
+    """K stacked MAFlow / IAFlow steps (maf.py:8-67, iaf.py:6-23) with alternating parity.  `S=None` records the
+    2-D (auto) case, training direction only: the reference's sequential direction builds a (B, D) log-det for
+    2-D input (maf.py:52) and fails to broadcast unless B == D."""
+    gen = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    cls = MAFlow if kind == "maf" else IAFlow
+    flows = torch.nn.ModuleList(
+        [cls(MADE(D, list(hidden), permute_order=permute, activation=activation), parity=bool(k % 2))
+         for k in range(K)])
+    jitter(flows, gen, scale=0.1)
+    shape = (B, D) if S is None else (B, S, D)
+    z0 = torch.randn(*shape, generator=gen, requires_grad=True)
+    mask = None if S is None else make_mask(mask_kind, B, S, gen)
+    out = {"z0": z0, "activation": np.array(activation), "kind": np.array(kind), "K": np.int64(K),
+           "permute": np.int64(permute), "hidden": np.asarray(hidden, dtype=np.int64)}
+    if mask is not None:
+        out["mask"] = mask
+    out.update(state(flows, "sd."))
+    if S is None and kind == "iaf":
+        raise ValueError("2-D IAF training direction is not runnable in the reference")
+    z, total = z0, 0.0
+    for k, flow in enumerate(flows):
+        z, ld = flow(z, mask)
+        out[f"fwd.z{k}"], out[f"fwd.ld{k}"] = z, ld
+        total = total + ld
+    cz = torch.randn(z.shape, generator=gen)
+    cl = torch.randn(total.shape, generator=gen)
+    out["cot.z"], out["cot.ld"] = cz, cl
+    ((z * cz).sum() + (total * cl).sum()).backward()
+    out["grad.z0"] = z0.grad
+    out.update(grads(flows, "grad.sd."))
+    if S is not None or kind == "iaf":
+        eps = torch.randn(*shape, generator=gen)
+        if mask is not None:
+            eps = eps * mask.unsqueeze(-1)
+        out["inv.eps"] = eps
+        with torch.no_grad():
+            zz = eps
+            for k, flow in enumerate(list(flows)[::-1]):
+                zz, ld = flow.backward(zz, None if mask is None else mask.float())
+                out[f"inv.z{k}"], out[f"inv.ld{k}"] = zz, ld
+    save(name, **out)
 
 
 # ----------------------------------------------------------------------------- NICE / FlowPrior
@@ -528,6 +577,12 @@ if __name__ == "__main__":
     gen_infovae("infovae", 24)
     gen_model_auto("model_auto_n1", 6, 9, 16, 24, 32, 2, 40, 1, False, None, 0.0, 25)
     gen_model_auto("model_auto_n2_iwae", 5, 8, 32, 16, 32, 3, 40, 2, True, 0.5, 0.1, 26)
+    gen_maf("maf_tiny_ragged", "maf", 4, 6, 8, [16], 3, "ragged", 31)
+    gen_maf("maf_d16_natural_holes", "maf", 3, 5, 16, [32], 2, "holes", 32, permute=False, activation="tanh")
+    gen_maf("maf_d64_2layer", "maf", 4, 9, 64, [64, 48], 2, "ragged", 33, activation="relu")
+    gen_maf("maf_auto_2d", "maf", 5, None, 16, [32], 2, None, 34)
+    gen_maf("iaf_tiny_ragged", "iaf", 4, 6, 8, [16], 2, "ragged", 35)
+    gen_maf("iaf_d16_natural", "iaf", 3, 5, 16, [24], 2, "full", 36, permute=False, activation="gelu")
     if only:
         sys.exit(0)
     gen_nice("nice_tiny_full", 4, 6, 8, 16, 4, "full", 13)

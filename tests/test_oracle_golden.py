@@ -265,3 +265,70 @@ def test_integer_helpers_bit_exact():
     pm = O.prefix_mask([3, 1, 5], 3)
     assert pm.tolist() == [[1, 1, 1, 0, 0], [1, 0, 0, 0, 0], [1, 1, 1, 1, 1]]
     assert O.prefix_mask([2], 3).shape == (3, 2)
+
+
+# ------------------------------------------------------------------------------------- MAF / IAF / MADE (8f-2)
+MAF_CASES = ["maf_tiny_ragged", "maf_d16_natural_holes", "maf_d64_2layer", "maf_auto_2d", "iaf_tiny_ragged",
+             "iaf_d16_natural"]
+
+
+def made_fns(g, requires_grad=False):
+    """One oracle MADE closure per recorded flow + the tensors it uses (state-dict layout of made.py:72-83)."""
+    act = str(g["activation"])
+    fns, params = [], []
+    for k in range(int(g["K"])):
+        ws, bs, ms, i = [], [], [], 0
+        while f"sd.{k}._made._nets.{2 * i}.weight" in g:
+            ws.append(g[f"sd.{k}._made._nets.{2 * i}.weight"].clone().requires_grad_(requires_grad))
+            bs.append(g[f"sd.{k}._made._nets.{2 * i}.bias"].clone().requires_grad_(requires_grad))
+            ms.append(g[f"sd.{k}._made._nets.{2 * i}.weight_mask"])
+            i += 1
+        fns.append(lambda x, ws=ws, bs=bs, ms=ms: O.made_forward(x, ws, bs, ms, act))
+        params.append((ws, bs))
+    return fns, params
+
+
+@pytest.mark.parametrize("name", MAF_CASES)
+def test_made_masks_match_recorded_buffers(name):
+    g = load_golden(name)
+    D = g["z0"].shape[-1]
+    masks = O.made_masks(D, [int(h) for h in g["hidden"]], bool(int(g["permute"])))
+    for i, m in enumerate(masks):
+        assert torch.equal(m.t(), g[f"sd.0._made._nets.{2 * i}.weight_mask"])      # bit exact (made.py:37)
+
+
+@pytest.mark.parametrize("name", MAF_CASES)
+def test_maf_iaf_steps_and_gradients(name):
+    g = load_golden(name)
+    fns, params = made_fns(g, requires_grad=True)
+    iaf = str(g["kind"]) == "iaf"
+    mask = g["mask"] if "mask" in g else None
+    z0 = g["z0"].clone().requires_grad_(True)
+    z, total = z0, 0.0
+    for k, fn in enumerate(fns):
+        step = O.maf_sequential if iaf else O.maf_forward
+        z, ld = step(z, fn, bool(k % 2), mask)
+        assert rel_err(z, g[f"fwd.z{k}"]) < TOL
+        assert rel_err(ld, g[f"fwd.ld{k}"]) < TOL
+        total = total + ld
+    ((z * g["cot.z"]).sum() + (total * g["cot.ld"]).sum()).backward()
+    assert rel_err(z0.grad, g["grad.z0"]) < 1e-5
+    for k, (ws, bs) in enumerate(params):
+        for i, (w, b) in enumerate(zip(ws, bs)):
+            assert rel_err(w.grad, g[f"grad.sd.{k}._made._nets.{2 * i}.weight"]) < 1e-5
+            assert rel_err(b.grad, g[f"grad.sd.{k}._made._nets.{2 * i}.bias"]) < 1e-5
+
+
+@pytest.mark.parametrize("name", [n for n in MAF_CASES if n != "maf_auto_2d"])
+def test_maf_iaf_reverse_direction(name):
+    g = load_golden(name)
+    fns, _ = made_fns(g)
+    iaf = str(g["kind"]) == "iaf"
+    mask = g["mask"].float() if "mask" in g else None
+    K = len(fns)
+    z = g["inv.eps"]
+    for k, fn in enumerate(reversed(fns)):
+        step = O.maf_forward if iaf else O.maf_sequential
+        z, ld = step(z, fn, bool((K - 1 - k) % 2), mask)
+        assert rel_err(z, g[f"inv.z{k}"]) < TOL
+        assert rel_err(ld, g[f"inv.ld{k}"]) < TOL
