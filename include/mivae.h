@@ -279,6 +279,28 @@ int mivae_adam_clip_step(float* p, void* p_bf16, float* g, float* m, float* v, c
                          void* stream);
 int mivae_scalar_add(float* x, float delta, void* stream);
 
+/* ---- masked autoregressive flows ----------------------------------------------- */
+/* Tail of MAFlow.forward (vae_lm/models/base/flows/maf.py:35-45) given st = MADE(z) as one (rows, 2D) tensor
+ * [s | t]:  out = flip_if_parity(z * exp(s) + t) * mask,  tok_ld[row] = mask * sum_d s.  mask: one int64 0/1 per
+ * row or NULL.  The backward takes the cotangents of out (may be NULL) and of tok_ld (may be NULL) and writes the
+ * direct term dz = g e^s and d st = [g e^s z + dtok | g]; the MADE term of dz comes back through d st. */
+int mivae_maf_affine_fwd(const void* z, const void* st, const int64_t* mask, void* out, float* tok_ld,
+                         int64_t rows, int64_t D, int parity, int dtype, void* stream);
+int mivae_maf_affine_bwd(const void* dout, const float* dtok, const void* z, const void* st, const int64_t* mask,
+                         void* dz, void* dst, int64_t rows, int64_t D, int parity, int dtype, void* stream);
+
+/* MAFlow.backward (maf.py:47-62; IAFlow.forward through iaf.py:21-23) for a MADE with ONE hidden layer, in one
+ * launch: D sequential steps in natural feature order, x_i = (z'_i - t_i(x)) exp(-s_i(x)), z' = flip_if_parity(z),
+ * tok_ld = mask * sum_i s_i (the reference accumulates +s here), out = x * mask.
+ * Packed weights (fp32, masks already multiplied in, made.py:39-40):  w1t [D][Hp] = (W1 * mask1)^T,
+ * b1 [Hp], w2 [2D][Hp] = W2 * mask2, b2 [2D]; hidden units padded with zeros to Hp = 16 * 2^k <= 256.
+ * act: 0 linear, 1 gelu (erf), 2 swish, 3 relu, 4 tanh, 5 sigmoid, 6 elu.  Returns MIVAE_EUNSUPPORTED (-3) when
+ * mivae_maf_sequential_supported(D, Hp) is 0 (weights + token tiles must fit 144 KiB of LDS). */
+int mivae_maf_sequential_supported(int64_t D, int64_t Hp);
+int mivae_maf_sequential(const void* z, const float* w1t, const float* b1, const float* w2, const float* b2,
+                         const int64_t* mask, void* out, float* tok_ld, int64_t rows, int64_t D, int64_t Hp, int act,
+                         int parity, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

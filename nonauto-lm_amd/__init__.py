@@ -3,8 +3,9 @@ reparameterisation + log q, base log p, KL / ELBO) behind the reference's module
 
 HIP kernels + C ABI: csrc/ -> lib/libmivae.so (include/mivae.h); host mirror: this package."""
 from . import _lib, ops
-from .flows import (ActNorm, AttentionCoupling, Coupling, FeedForwardCoupling, Flow, InvertibleLinear,
-                    InvertibleLinearFlow, InvertibleMultiHeadFlow, NICECoupling, RecurrentCoupling)
+from .flows import (MADE, ActNorm, AttentionCoupling, Coupling, FeedForwardCoupling, Flow, IAFlow, InvertibleLinear,
+                    InvertibleLinearFlow, InvertibleMultiHeadFlow, MAFlow, MaskedLinear, NICECoupling,
+                    RecurrentCoupling)
 from .latent import (DefaultKLLoss, DefaultPosterior, DefaultPrior, FlowPrior, InfoVAEKLLoss, KLLoss, LatentSample,
                      Posterior, PosteriorSample, Prior, PriorSample)
 from .model import NonAutoModel, SimpleVocab, VAELmModel, WeightScheduler

@@ -51,6 +51,10 @@ SIGNATURES = {
     "mivae_linear_fwd": [P, P, P, P, I64, I64, I64, P],
     "mivae_linear_dgrad": [P, P, P, I64, I64, I64, P],
     "mivae_linear_wgrad_rows": [I64],
+    "mivae_maf_affine_fwd": [P, P, P, P, P, I64, I64, I32, I32, P],
+    "mivae_maf_affine_bwd": [P, P, P, P, P, P, P, I64, I64, I32, I32, P],
+    "mivae_maf_sequential_supported": [I64, I64],
+    "mivae_maf_sequential": [P, P, P, P, P, P, P, P, I64, I64, I64, I32, I32, I32, P],
     "mivae_linear_wgrad": [P, P, P, I64, I64, I64, P],
     "mivae_layernorm_fwd": [P, P, P, P, P, P, I64, I64, F32, I32, I32, P],
     "mivae_layernorm_workspace_floats": [I64, I64],

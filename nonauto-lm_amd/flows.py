@@ -221,6 +221,141 @@ class ActNorm(Flow):
         return ops.actnorm(z, self._log_scale, self._bias, mask, inverse=True)
 
 
+class MaskedLinear(torch.nn.Linear):
+    """Linear layer with a 0/1 mask on its weights (made.py:8-40); `weight_mask` is a buffer of the state dict."""
+
+    def __init__(self, in_features: int, out_features: int, bias=True) -> None:
+        super().__init__(in_features, out_features, bias)
+        self.register_buffer("weight_mask", torch.ones(out_features, in_features))
+
+    @property
+    def mask(self) -> torch.Tensor:
+        return self.weight_mask
+
+    @mask.setter
+    def mask(self, value: torch.Tensor) -> None:
+        self.weight_mask.data.copy_(value.T)
+
+    def forward(self, x):
+        return torch.nn.functional.linear(x, self.weight * self.weight_mask, self.bias)
+
+
+class MADE(torch.nn.Module):
+    """Masked autoencoder for distribution estimation (made.py:43-127): MaskedLinear / activation stack with
+    2 * input_size outputs ([s | t]); masks from numpy RandomState(13) exactly like `_update_masks` (:93-122)."""
+
+    def __init__(self, input_size: int, hidden_sizes: List[int], permute_order: bool = True,
+                 activation: str = "elu") -> None:
+        super().__init__()
+        self._input_size = input_size
+        self._output_size = input_size * 2
+        self._hidden_sizes = list(hidden_sizes)
+        self._activation_name = activation
+        nets = []
+        hs = [input_size] + self._hidden_sizes + [self._output_size]
+        for h0, h1 in zip(hs, hs[1:]):
+            nets.extend([MaskedLinear(h0, h1), Activation.by_name(activation)])
+        nets.pop()
+        self._nets = torch.nn.Sequential(*nets)
+        self._permute_order = permute_order
+        self._seed = 13
+        self._masks = {}
+        self._update_masks()
+
+    def get_input_size(self) -> int:
+        return self._input_size
+
+    def _update_masks(self) -> None:
+        import numpy as np
+        n = len(self._hidden_sizes)
+        rng = np.random.RandomState(self._seed)
+        self._masks[-1] = rng.permutation(self._input_size) if self._permute_order else np.arange(self._input_size)
+        for layer in range(n):
+            self._masks[layer] = rng.randint(self._masks[layer - 1].min(), self._input_size - 1,
+                                             size=self._hidden_sizes[layer])
+        masks = [self._masks[layer - 1][:, None] <= self._masks[layer][None, :] for layer in range(n)]
+        last = self._masks[n - 1][:, None] < self._masks[-1][None, :]
+        masks.append(np.concatenate([last] * (self._output_size // self._input_size), axis=1))
+        for layer, m in zip(self.masked_layers(), masks):
+            layer.mask = torch.from_numpy(m.astype("float32"))
+
+    def masked_layers(self) -> List[MaskedLinear]:
+        return [m for m in self._nets if isinstance(m, MaskedLinear)]
+
+    def forward(self, z):
+        return self._nets(z)
+
+
+@Flow.register("maf")
+class MAFlow(Flow):
+    """Masked autoregressive flow (maf.py:8-67).  `forward` = one MADE pass (library GEMMs) + the HIP affine /
+    flip / masked log-det tail.  `backward` = the D-step sequential direction: one `mivae_maf_sequential` launch
+    for a one-hidden-layer MADE when no gradient is needed, else the reference's loop on library ops.
+
+    Kept from the reference: features are visited in natural order whatever the MADE ordering is, and the
+    sequential direction accumulates the log-det with +s (maf.py:54-58).  Deviations: the log-det is created on
+    z's device (the reference builds it on the CPU, maf.py:52, and cannot run this direction on a GPU), and for 2-D
+    input it is the per-row sum (B,) (the reference's (B, D) buffer only broadcasts when B == D)."""
+
+    def __init__(self, made: MADE, parity: bool) -> None:
+        super().__init__()
+        self._made = made
+        self._dim = made.get_input_size()
+        self._parity = parity
+
+    def _density(self, z, mask=None):
+        return ops.maf_affine(z, self._made(z), mask, self._parity)
+
+    def _sequential(self, z, mask=None):
+        layers = self._made.masked_layers()
+        needs_grad = torch.is_grad_enabled() and (z.requires_grad or any(p.requires_grad for p in self._made.parameters()))
+        if (not needs_grad and len(layers) == 2 and self._made._activation_name in ops.MAF_ACT_IDS
+                and z.dtype in (torch.float32, torch.bfloat16)):
+            l1, l2 = layers
+            packed = ops.maf_sequential_pack(l1.weight, l1.weight_mask, l1.bias, l2.weight, l2.weight_mask, l2.bias)
+            if packed is not None:
+                return ops.maf_sequential(z, packed, mask, self._made._activation_name, self._parity)
+        # composed path (training direction of IAF, deeper MADEs): the reference's loop, maf.py:51-62
+        from . import _lib as L
+        L.require_gpu(z, mask)
+        D = self._dim
+        x = torch.zeros_like(z)
+        log_det = torch.zeros(z.shape[:-1], dtype=z.dtype, device=z.device)
+        zz = z.flip(dims=(-1,)) if self._parity else z
+        for i in range(D):
+            st = self._made(x.clone())
+            x[..., i] = (zz[..., i] - st[..., D + i]) * torch.exp(-st[..., i])
+            log_det = log_det + st[..., i]
+        if mask is not None:
+            x = x * mask.unsqueeze(-1)
+            log_det = log_det.mul(mask).sum(dim=-1)
+        return x, log_det
+
+    def forward(self, z, mask=None):
+        return self._density(z, mask)
+
+    def backward(self, z, mask=None):
+        return self._sequential(z, mask)
+
+    @classmethod
+    def from_params(cls, **params):
+        # maf.py:64-67 builds `MAFlow(...)` whatever `cls` is, so a config with type "iaf" yields a MAFlow in the
+        # reference; reproduced (IAFlow is reachable by direct construction only, there as here).
+        made = MADE(**params.pop("made"))
+        return MAFlow(made=made, **params)
+
+
+@Flow.register("iaf")
+class IAFlow(MAFlow):
+    """Inverse autoregressive flow (iaf.py:6-23): MAF with the two directions swapped."""
+
+    def forward(self, z, mask=None):
+        return self._sequential(z, mask)
+
+    def backward(self, z, mask=None):
+        return self._density(z, mask)
+
+
 class InvertibleLinear(Flow, Registrable):
     """Registry of invertible linear flows (invertible_flows.py:11-12)."""
 

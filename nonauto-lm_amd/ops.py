@@ -227,6 +227,98 @@ def nice_affine(z, s, t, mask, inverse: bool = False):
     return out, _SegmentSum.apply(tok, Bn, S)
 
 
+# ----------------------------------------------------------------------------------- MAF / IAF (8f-2)
+MAF_ACT_IDS = dict(ACT_IDS, elu=6)
+MAF_HIDDEN_PER_LANE = 16
+
+
+class _MafAffine(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, st, mask, parity):
+        Bn, S, D = _shape3(z)
+        z, st = z.contiguous(), st.contiguous().to(z.dtype)
+        out = torch.empty_like(z)
+        tok = torch.empty(Bn * S, dtype=torch.float32, device=z.device)
+        L.call("mivae_maf_affine_fwd", L.ptr(z), L.ptr(st), L.ptr(mask), L.ptr(out), L.ptr(tok), Bn * S, D,
+               int(parity), L.dtype_code(z.dtype), L.stream())
+        ctx.save_for_backward(z, st, mask)
+        ctx.meta = (Bn * S, D, int(parity))
+        return out, tok
+
+    @staticmethod
+    def backward(ctx, dout, dtok):
+        z, st, mask = ctx.saved_tensors
+        rows, D, parity = ctx.meta
+        dz, dst = torch.empty_like(z), torch.empty_like(st)
+        dout = None if dout is None else dout.contiguous().to(z.dtype)
+        dtok = None if dtok is None else dtok.contiguous().float()
+        L.call("mivae_maf_affine_bwd", L.ptr(dout), L.ptr(dtok), L.ptr(z), L.ptr(st), L.ptr(mask), L.ptr(dz),
+               L.ptr(dst), rows, D, parity, L.dtype_code(z.dtype), L.stream())
+        return dz, dst, None, None
+
+
+def _tok_logdet(tok, z, mask, Bn, S):
+    """Per-token log-dets -> the reference's shape: (B,) for masked 3-D and for 2-D input, (B, S) otherwise."""
+    if z.dim() == 2:
+        return tok
+    if mask is None:
+        return tok.view(Bn, S)
+    return _SegmentSum.apply(tok, Bn, S)
+
+
+def maf_affine(z, st, mask, parity: bool):
+    """Tail of MAFlow.forward given st = MADE(z) (maf.py:35-45): flip_if_parity(z * exp(s) + t) * mask and the masked
+    log-det sum(s)."""
+    L.require_gpu(z, st, mask)
+    mask = _mask_i64(mask)
+    Bn, S, D = _shape3(z)
+    if st.shape != (*z.shape[:-1], 2 * D):
+        raise ValueError(f"MADE output must be {(*z.shape[:-1], 2 * D)}, got {tuple(st.shape)}")
+    if mask is not None and mask.numel() != Bn * S:
+        raise ValueError("mask must be (B, S) for a (B, S, D) latent")
+    out, tok = _MafAffine.apply(z, st, mask, bool(parity))
+    return out, _tok_logdet(tok, z, mask, Bn, S)
+
+
+def maf_sequential_pack(w1, m1, b1, w2, m2, b2):
+    """Packed fp32 weights of a one-hidden-layer MADE for mivae_maf_sequential (layout in include/mivae.h), or None
+    when the shape is unsupported.  w*/m* are the (out, in) weight and weight_mask tensors (made.py:39-40)."""
+    H, D = w1.shape
+    lanes = 1
+    while lanes * MAF_HIDDEN_PER_LANE < H:
+        lanes *= 2
+    Hp = lanes * MAF_HIDDEN_PER_LANE
+    if not L.query("mivae_maf_sequential_supported", D, Hp):
+        return None
+    w1t = torch.zeros(D, Hp, dtype=torch.float32, device=w1.device)
+    w1t[:, :H] = (w1.detach().float() * m1).t()
+    b1p = torch.zeros(Hp, dtype=torch.float32, device=w1.device)
+    b1p[:H] = b1.detach().float()
+    w2p = torch.zeros(2 * D, Hp, dtype=torch.float32, device=w1.device)
+    w2p[:, :H] = w2.detach().float() * m2
+    return w1t, b1p, w2p, b2.detach().float().contiguous(), Hp
+
+
+def maf_sequential(z, packed, mask, activation: str, parity: bool):
+    """MAFlow.backward / IAFlow.forward (maf.py:47-62) in one launch; no autograd (sampling / inference direction)."""
+    L.require_gpu(z, mask)
+    mask = _mask_i64(mask)
+    Bn, S, D = _shape3(z)
+    w1t, b1, w2, b2, Hp = packed
+    if mask is not None and mask.numel() != Bn * S:
+        raise ValueError("mask must be (B, S) for a (B, S, D) latent")
+    zc = z.detach().contiguous()
+    out = torch.empty_like(zc)
+    tok = torch.empty(Bn * S, dtype=torch.float32, device=z.device)
+    L.call("mivae_maf_sequential", L.ptr(zc), L.ptr(w1t), L.ptr(b1), L.ptr(w2), L.ptr(b2), L.ptr(mask), L.ptr(out),
+           L.ptr(tok), Bn * S, D, Hp, MAF_ACT_IDS[activation], int(parity), L.dtype_code(z.dtype), L.stream())
+    if z.dim() == 2:
+        return out, tok
+    if mask is None:
+        return out, tok.view(Bn, S)
+    return out, segment_sum(tok, Bn, S)
+
+
 class _SegmentSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tok, nseg, S):

@@ -852,3 +852,125 @@ def test_grad_sink_matches_autograd_accumulation(M):
     assert any(float(b.abs().max()) > 0 for b in grads[True])
     for a, b in zip(grads[False], grads[True]):
         assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------ 8f-2: MAF / IAF / MADE
+MAF_GOLDEN = ["maf_tiny_ragged", "maf_d16_natural_holes", "maf_d64_2layer", "maf_auto_2d", "iaf_tiny_ragged",
+              "iaf_d16_natural"]
+
+
+def _maf_flows(M, g):
+    """The recorded stack rebuilt through the reference's constructor signatures with its state dict loaded."""
+    D = g["z0"].shape[-1]
+    cls = M.IAFlow if str(g["kind"]) == "iaf" else M.MAFlow
+    flows = torch.nn.ModuleList(
+        [cls(M.MADE(D, [int(h) for h in g["hidden"]], permute_order=bool(int(g["permute"])),
+                    activation=str(g["activation"])), parity=bool(k % 2)) for k in range(int(g["K"]))])
+    sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    for k, v in sd.items():          # the numpy-seeded masks this build derives == the reference's buffers
+        if k.endswith("weight_mask"):
+            assert torch.equal(flows.state_dict()[k], v), k
+    flows.load_state_dict(sd, strict=True)
+    return flows.to(DEV)
+
+
+@pytest.mark.parametrize("name", MAF_GOLDEN)
+def test_maf_iaf_training_direction_golden(M, name):
+    """flow(z, mask) per step + gradients vs the reference: MAF = MADE GEMMs + HIP affine tail (fwd and bwd
+    kernels); IAF = the sequential direction under autograd (composed path)."""
+    g = load_golden(name)
+    flows = _maf_flows(M, g)
+    mask = dev(g["mask"]) if "mask" in g else None
+    z0 = dev(g["z0"]).clone().requires_grad_(True)
+    z, total = z0, 0.0
+    for k, flow in enumerate(flows):
+        z, ld = flow(z, mask)
+        assert ld.shape == g[f"fwd.ld{k}"].shape
+        assert rel_err(z, g[f"fwd.z{k}"]) < TOL, k
+        assert rel_err(ld, g[f"fwd.ld{k}"]) < TOL, k
+        total = total + ld
+    ((z * dev(g["cot.z"])).sum() + (total * dev(g["cot.ld"])).sum()).backward()
+    assert rel_err(z0.grad, g["grad.z0"]) < GTOL
+    errs = _grad_errs(flows, g)
+    assert errs and max(errs.values()) < 1e-4, max(errs, key=errs.get)
+
+
+@pytest.mark.parametrize("name", [n for n in MAF_GOLDEN if n != "maf_auto_2d"])
+def test_maf_iaf_reverse_direction_golden(M, name):
+    """flow.backward over the reversed stack under no_grad: for MAF this is the one-launch sequential kernel
+    (one hidden layer) or the composed loop (maf_d64_2layer); for IAF the density tail."""
+    g = load_golden(name)
+    flows = _maf_flows(M, g)
+    mask = dev(g["mask"]).float() if "mask" in g else None
+    z = dev(g["inv.eps"])
+    with torch.no_grad():
+        for k, flow in enumerate(list(flows)[::-1]):
+            z, ld = flow.backward(z, mask)
+            assert ld.shape == g[f"inv.ld{k}"].shape
+            assert rel_err(z, g[f"inv.z{k}"]) < 2e-5, k
+            assert rel_err(ld, g[f"inv.ld{k}"]) < 2e-5, k
+
+
+@pytest.mark.parametrize("B,S,D,H,act,parity,masked", [
+    (16, 64, 64, 64, "elu", False, True), (7, 33, 64, 128, "gelu", True, True), (5, 9, 32, 40, "tanh", True, False),
+    (3, 1, 16, 16, "relu", False, False), (4, 17, 128, 64, "swish", True, True), (2, 5, 8, 256, "sigmoid", False, True),
+    (3, 4, 24, 20, "linear", True, True)])
+def test_maf_sequential_kernel_vs_oracle(M, B, S, D, H, act, parity, masked):
+    """mivae_maf_sequential through the module vs the oracle's D-pass loop on seeded inputs (padded hidden sizes,
+    every activation, both parities, ragged rows-per-block), and the round trip forward(backward(z)) == z."""
+    gen = torch.Generator().manual_seed(100 + D + H)
+    torch.manual_seed(7)
+    flow = M.MAFlow(M.MADE(D, [H], permute_order=False, activation=act), parity=parity)
+    with torch.no_grad():
+        for p in flow.parameters():
+            p.add_(0.05 * torch.randn(p.shape, generator=gen))
+    l1, l2 = flow._made.masked_layers()
+    ws, bs = [l1.weight.detach().clone(), l2.weight.detach().clone()], [l1.bias.detach().clone(), l2.bias.detach().clone()]
+    ms = [l1.weight_mask.clone(), l2.weight_mask.clone()]
+    z = torch.randn(B, S, D, generator=gen)
+    mask = None
+    if masked:
+        lens = torch.randint(1, S + 1, (B,), generator=gen)
+        mask = (torch.arange(S)[None, :] < lens[:, None]).to(torch.int64)
+        z = z * mask.unsqueeze(-1)
+    xo, ldo = O.maf_sequential(z, lambda x: O.made_forward(x, ws, bs, ms, act), parity, mask)
+    flow = flow.to(DEV)
+    packed = M.ops.maf_sequential_pack(l1.weight, l1.weight_mask, l1.bias, l2.weight, l2.weight_mask, l2.bias)
+    assert packed is not None                      # these shapes must take the kernel, not the composed loop
+    with torch.no_grad():
+        x, ld = flow.backward(dev(z), dev(mask))
+        assert ld.shape == ldo.shape
+        assert rel_err(x, xo) < 2e-5 and rel_err(ld, ldo) < 2e-5
+        back, ldf = flow(x, dev(mask))             # natural order: the sequential direction inverts the density one
+        assert rel_err(back, z) < 2e-4
+
+
+@pytest.mark.parametrize("dtype,vec", [(torch.float32, True), (torch.bfloat16, True), (torch.float32, False)])
+@pytest.mark.parametrize("parity", [False, True])
+def test_maf_affine_kernels_vs_oracle(M, dtype, vec, parity):
+    """mivae_maf_affine_fwd/bwd vs the oracle tail on the same (rounded) inputs; D % 8 != 0 takes the scalar path."""
+    gen = torch.Generator().manual_seed(5)
+    B, S, D = 6, 19, (64 if vec else 13)
+    z = torch.randn(B, S, D, generator=gen).to(dtype)
+    st = (0.5 * torch.randn(B, S, 2 * D, generator=gen)).to(dtype)
+    mask = (torch.rand(B, S, generator=gen) > 0.3).to(torch.int64)
+    zo, sto = z.float().clone().requires_grad_(True), st.float().clone().requires_grad_(True)
+    oo, ldo = O.maf_forward(zo, lambda x: sto, parity, mask)
+    cz, cl = torch.randn(B, S, D, generator=gen), torch.randn(B, generator=gen)
+    ((oo * cz).sum() + (ldo * cl).sum()).backward()
+    zd, std_ = dev(z).detach().requires_grad_(True), dev(st).detach().requires_grad_(True)
+    out, ld = M.ops.maf_affine(zd, std_, dev(mask), parity)
+    ((out.float() * dev(cz)).sum() + (ld * dev(cl)).sum()).backward()
+    tol = TOL if dtype == torch.float32 else 4e-3
+    assert rel_err(out.float(), oo) < tol and rel_err(ld, ldo) < TOL
+    assert rel_err(zd.grad.float(), zo.grad) < tol * 2 and rel_err(std_.grad.float(), sto.grad) < tol * 2
+
+
+def test_flow_registry_builds_maf(M):
+    """Flow.from_params(type="maf" | "iaf", made={...}, parity=...) (maf.py:64-67): both yield a MAFlow, as in the
+    reference, with the reference's state-dict keys."""
+    for t in ("maf", "iaf"):
+        f = M.Flow.from_params(type=t, made=dict(input_size=8, hidden_sizes=[16]), parity=True)
+        assert type(f) is M.MAFlow
+        assert sorted(f.state_dict()) == sorted(
+            f"_made._nets.{i}.{n}" for i in (0, 2) for n in ("weight", "bias", "weight_mask"))
