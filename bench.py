@@ -147,8 +147,11 @@ def flow_kernel_times(model, tokens, dtype, reps=50, graph=True):
     use_lce = dtype == torch.bfloat16 and ops.linear_nll_supported(hdec, w16)
     if use_lce:
         wp16 = torch.empty(L.query("mivae_lce_pack_elems", V, E), dtype=torch.bfloat16, device=dev)
-        L.call("mivae_lce_pack", L.ptr(w16), L.ptr(pbias), L.ptr(wp16), V, E, L.stream())
+        wt16 = torch.empty(V * E, dtype=torch.bfloat16, device=dev)
+        L.call("mivae_lce_pack2", L.ptr(w16), L.ptr(pbias), L.ptr(wp16), L.ptr(wt16), V, E, L.stream())
         w16 = wp16
+        dh_ws = e(max(L.query("mivae_lce_dh_workspace_floats", N, E, V), 1), dt=torch.float32)
+        dh16 = torch.empty(N, E, dtype=torch.bfloat16, device=dev)
     lce_ws = e(max(L.query("mivae_lce_workspace_floats", N, V), 1), dt=torch.float32)
     dl16 = torch.empty(N, V, dtype=torch.bfloat16, device=dev)
     calls = {}
@@ -158,6 +161,9 @@ def flow_kernel_times(model, tokens, dtype, reps=50, graph=True):
                                       L.ptr(per_seq), L.ptr(aux[0]), L.ptr(aux[1]), L.ptr(lce_ws), B, S, E, V, 0.0, L.stream()),
             "lce_bwd": lambda: L.call("mivae_lce_bwd", L.ptr(hdec), L.ptr(w16), L.ptr(tokens), L.ptr(aux[0]),
                                       L.ptr(aux[1]), L.ptr(dper), L.ptr(dl16), B, S, E, V, 0.0, L.stream()),
+            "lce_bwd_dh": lambda: L.call("mivae_lce_bwd_dh", L.ptr(hdec), L.ptr(w16), L.ptr(wt16), L.ptr(tokens), L.ptr(aux[0]),
+                                         L.ptr(aux[1]), L.ptr(dper), L.ptr(dl16), L.ptr(dh_ws), L.ptr(dh16), B, S, E, V, 0.0,
+                                         L.stream()),
         })
     calls.update({
         "nll_fwd": lambda: L.call("mivae_nll_fwd", L.ptr(logits), L.ptr(tokens), L.ptr(w), L.ptr(per_seq), L.ptr(aux[0]),
@@ -306,16 +312,20 @@ def main():
             # the backward writes d logits once and reads nothing of that size
             "lce_fwd": N * D * 2 + VOCAB * D * 2 + 32 * N,
             "lce_bwd": N * VOCAB * 2 + N * D * 2 + VOCAB * D * 2 + 16 * N,
+            # + d h in the same pass: W^T image read, d h written (slice partials are scratch, not algorithmic)
+            "lce_bwd_dh": N * VOCAB * 2 + N * D * 2 + 2 * VOCAB * D * 2 + 16 * N + N * D * 2,
         }
-        in_step = {"nll_fwd", "nll_bwd"} if not fused_lce else {"lce_fwd", "lce_bwd"}
-        flops = {"nll_fwd": 0, "nll_bwd": 0, "lce_fwd": 2 * N * VOCAB * D, "lce_bwd": 2 * N * VOCAB * D, "nice_stack_fwd": 4 * K * N * D * H, "nice_stack_bwd": 8 * K * N * D * H, "nice_dw": 4 * K * N * D * H}
+        in_step = {"nll_fwd", "nll_bwd"} if not fused_lce else \
+            {"lce_fwd", "lce_bwd_dh" if ops.LCE_FUSED_DH else "lce_bwd"}
+        flops = {"nll_fwd": 0, "nll_bwd": 0, "lce_fwd": 2 * N * VOCAB * D, "lce_bwd": 2 * N * VOCAB * D,
+                 "lce_bwd_dh": 4 * N * VOCAB * D, "nice_stack_fwd": 4 * K * N * D * H, "nice_stack_bwd": 8 * K * N * D * H, "nice_dw": 4 * K * N * D * H}
         kern = flow_kernel_times(model, tokens, torch.bfloat16 if dtype_name == "bf16" else torch.float32)
         kernel_timing = ("each entry point (C ABI) captured 10x back to back in a HIP graph, the graph replayed 5x between "
                          "two HIP events on the launch stream; same process, bench shape, trained weights")
         roofline = None
         if kern:
             # dominant = the slowest hand-written launch that the timed step actually runs
-            skip = {"nll_fwd", "nll_bwd", "lce_fwd", "lce_bwd"} - in_step
+            skip = {"nll_fwd", "nll_bwd", "lce_fwd", "lce_bwd", "lce_bwd_dh"} - in_step
             dom = max((k for k in kern if k in algo and k not in skip), key=lambda k: kern[k]["avg_us"])
             us = kern[dom]["avg_us"]
             ach = algo[dom] / (us * 1e-6) / 1e9

@@ -225,6 +225,16 @@ int mivae_lce_fwd(const void* h, const void* W, const int64_t* target,
 int mivae_lce_bwd(const void* h, const void* W, const int64_t* target, const float* lse,
                   const float* tokscale, const float* dper_seq, void* dlogits, int64_t Bn, int64_t S,
                   int64_t E, int64_t V, float smoothing, void* stream);
+/* As mivae_lce_bwd, and d h (Bn*S, E) bf16 = dlogits W (autograd of the vocabulary projection w.r.t. its input,
+ * nonauto_lm/model.py:105) is formed in the same pass on the matrix cores from the bf16 dlogits tiles while they are
+ * in registers: the (N, V) x (V, E) GEMM and its read of dlogits disappear.  Wtp (V * E bf16): the W^T fragment
+ * image written by mivae_lce_pack2 (mivae_lce_pack + Wtp, one launch; Wtp may be NULL there).  workspace:
+ * mivae_lce_dh_workspace_floats(Bn*S, E, V) floats (per-vocabulary-slice fp32 partials, summed in slice order). */
+int mivae_lce_pack2(const void* W, const float* bias, void* Wp, void* Wtp, int64_t V, int64_t E, void* stream);
+int64_t mivae_lce_dh_workspace_floats(int64_t N, int64_t E, int64_t V);
+int mivae_lce_bwd_dh(const void* h, const void* W, const void* Wtp, const int64_t* target, const float* lse,
+                     const float* tokscale, const float* dper_seq, void* dlogits, float* workspace, void* dh,
+                     int64_t Bn, int64_t S, int64_t E, int64_t V, float smoothing, void* stream);
 
 /* ---- token-parallel small Linear layers ---------------------------------------------------------------- */
 /* torch.nn.Linear over many tokens and few features, bf16 operands, fp32 accumulation on the matrix cores: the

@@ -51,6 +51,9 @@ SIGNATURES = {
     "mivae_linear_fwd": [P, P, P, P, I64, I64, I64, P],
     "mivae_linear_dgrad": [P, P, P, I64, I64, I64, P],
     "mivae_linear_wgrad_rows": [I64],
+    "mivae_lce_pack2": [P, P, P, P, I64, I64, P],
+    "mivae_lce_dh_workspace_floats": [I64, I64, I64],
+    "mivae_lce_bwd_dh": [P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P],
     "mivae_maf_affine_fwd": [P, P, P, P, P, I64, I64, I32, I32, P],
     "mivae_maf_affine_bwd": [P, P, P, P, P, P, P, I64, I64, I32, I32, P],
     "mivae_maf_sequential_supported": [I64, I64],
@@ -80,6 +83,7 @@ _RET = {
     "mivae_sumsq_blocks": I64,
     "mivae_lce_workspace_floats": I64,
     "mivae_lce_pack_elems": I64,
+    "mivae_lce_dh_workspace_floats": I64,
     "mivae_linear_wgrad_rows": I64,
     "mivae_layernorm_workspace_floats": I64,
     "mivae_nice_stack_npad": I64,

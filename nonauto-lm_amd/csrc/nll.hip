@@ -279,6 +279,8 @@ struct LceArgs {
   const float* tokscale;        // (N)           [bwd]
   const float* dper;            // (Bn)          [bwd]
   unsigned short* dlogits;      // (N, V) bf16   [bwd]
+  const unsigned short* Wt;     // W^T fragments for d h (k_lce_pack), or null   [bwd with d h]
+  float* dhp;                   // (VSB, N, E) fp32 d h partials                [bwd with d h]
   int64_t N;
   int S, V, per;                // per: chunks (fwd) or chunk pairs (bwd) per vocabulary slice
   float smoothing;
@@ -287,11 +289,31 @@ struct LceArgs {
 // Wp[chunk c][k-step ks][lane (hh, r32)][j] = W[32 c + r32][16 ks + 8 hh + j] for ks < E / 16 (the A fragments of
 // the logits tiles); the extra k-step ks = E / 16 holds {bf16 hi, bf16 lo} of bias[32 c + r32] in slots 0, 1 of the
 // hh = 0 lanes (hi + lo carries the fp32 bias to ~2^-17 relative) and zeros elsewhere.
+//
+// Wtp (optional, for the fused d h product): the A fragments of d h^T (E x tokens) += W^T (E x 32 rows) dl (32 x tokens)
+// with the contraction index in ACCUMULATOR order, so that the d logits tile a lane already holds is its B fragment:
+// Wtp[chunk c][k-step s][E block eb][lane (hh, r32)][j] = W[32 c + 8 (2 s + (j >> 2)) + 4 hh + (j & 3)][32 eb + r32].
 __global__ __launch_bounds__(256) void k_lce_pack(const unsigned short* __restrict__ W, const float* __restrict__ bias,
-                                                   unsigned short* __restrict__ Wp, int64_t V, int E) {
+                                                   unsigned short* __restrict__ Wp, unsigned short* __restrict__ Wtp,
+                                                   int64_t V, int E) {
   const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;       // one 16-byte group per thread
   const int nf = (E >> 4) + 1;
-  if (g >= (V >> 5) * nf * 64) return;
+  const int64_t g1 = (V >> 5) * nf * 64;
+  if (g >= g1) {
+    const int EB = E >> 5;
+    const int64_t g2 = g - g1;
+    if (!Wtp || g2 >= (V >> 5) * 2 * EB * 64) return;
+    const int lane = (int)(g2 & 63), r32 = lane & 31, hh = lane >> 5;
+    const int64_t q = g2 >> 6;
+    const int eb = (int)(q % EB), s2 = (int)((q / EB) & 1);
+    const int64_t c = q / (2 * EB);
+    u16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      v[j] = W[(32 * c + 8 * (2 * s2 + (j >> 2)) + 4 * hh + (j & 3)) * E + 32 * eb + r32];
+    *reinterpret_cast<u16x8*>(Wtp + g2 * 8) = v;
+    return;
+  }
   const int lane = (int)(g & 63);
   const int64_t q = g >> 6;
   const int ks = (int)(q % nf);
@@ -390,20 +412,26 @@ __global__ __launch_bounds__(256) void k_lce_combine(const f32x4* __restrict__ p
 
 constexpr int kLceStride = 72;   // bf16 per staged token row (64 + pad): 144 B keeps 16-byte alignment
 
-template <int NKS>
+// DH: every wave also accumulates d h^T (E x 32 tokens) += W^T dl on the matrix cores from the bf16 d logits it has
+// just formed (the accumulator tile IS the B fragment, see k_lce_pack) and writes one fp32 partial tile per
+// vocabulary slice (k_lce_dh_combine sums the slices in order): the (N, V) x (V, E) library GEMM and its read of
+// d logits disappear.  The 4 waves of a block walk the same vocabulary slice, so W / W^T fragments hit in L1.
+template <int NKS, bool DH>
 __global__ __launch_bounds__(256) void k_lce_bwd(LceArgs a) {
   constexpr int NF = NKS + 1;
+  constexpr int E = 16 * NKS, EB = (E + 31) / 32;
   __shared__ __attribute__((aligned(16))) unsigned short stage_all[4][32 * kLceStride];
   const int lane = threadIdx.x & 63, r32 = lane & 31, hh = lane >> 5;
   const int wave = threadIdx.x >> 6;
   unsigned short* stage = stage_all[wave];
   const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  const int slice = (int)blockIdx.y;
   const int64_t tok0 = tile * 32, tok = tok0 + r32;
   if (tok0 >= a.N) return;                                   // wave-uniform
   const bool valid = tok < a.N;
   const float coef = valid ? a.dper[tok / a.S] * a.tokscale[tok] : 0.f;
   const int npair = a.V >> 6;
-  const int p0 = blockIdx.y * a.per;
+  const int p0 = slice * a.per;
   int p1 = p0 + a.per;
   if (p1 > npair) p1 = npair;
   // copy-out geometry: lane -> (row = lane >> 3 (+ 8 i), 16-byte column lane & 7)
@@ -416,11 +444,24 @@ __global__ __launch_bounds__(256) void k_lce_bwd(LceArgs a) {
         const int64_t row = tok0 + orow + 8 * i;
         if (row < a.N) *reinterpret_cast<u16x8*>(a.dlogits + row * a.V + 64 * p + ocol) = z;
       }
+    if (DH) {                                                // zero d h partial rows of this tile
+      const f32x4 zf = {0.f, 0.f, 0.f, 0.f};
+      for (int idx = lane; idx < 32 * (E / 4); idx += 64) {
+        const int row = idx / (E / 4), c4 = idx % (E / 4);
+        if (tok0 + row < a.N)
+          *reinterpret_cast<f32x4*>(a.dhp + ((int64_t)slice * a.N + tok0 + row) * E + 4 * c4) = zf;
+      }
+    }
     return;
   }
   lce_bf16x8 hf[NF];
   lce_load_h<NF>(a.h, tok, valid, hh, hf);
   const int t = valid ? (int)a.target[tok] : -1;
+  f32x16 dh[EB];
+#pragma unroll
+  for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dh[eb][r] = 0.f;
   // coef * softmax = sign(coef) * 2^(x log2e - lse log2e + log2|coef|): one fma + one v_exp_f32 per element, the sign
   // goes on with an integer xor (coef = 0 -> 2^-inf = 0: padding tokens inside a live tile get exact zeros)
   const float c0 = valid ? __builtin_amdgcn_logf(fabsf(coef)) - a.lse[tok] * kLog2e : -INFINITY;
@@ -437,7 +478,16 @@ __global__ __launch_bounds__(256) void k_lce_bwd(LceArgs a) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int c = 2 * p + u;
+      lce_bf16x8 af[2][EB];
+      if (DH) {                                              // in flight under this chunk's MFMA + exp work
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int eb = 0; eb < EB; ++eb)
+            af[s2][eb] = *reinterpret_cast<const lce_bf16x8*>(a.Wt + ((((int64_t)c * 2 + s2) * EB + eb) * 64 + lane) * 8);
+      }
       const f32x16 x = lce_tile<NF>(wf[u], hf);
+      u16x4 ov[4];
       if (!slow) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -446,6 +496,7 @@ __global__ __launch_bounds__(256) void k_lce_bwd(LceArgs a) {
           for (int i = 0; i < 4; ++i)
             o[i] = f32_to_bf16(__uint_as_float(__float_as_uint(ex2(fmaf(x[4 * q + i], kLog2e, c0))) ^ sgn));
           *reinterpret_cast<u16x4*>(stage + r32 * kLceStride + 32 * u + 8 * q + 4 * hh) = o;
+          ov[q] = o;
         }
       } else {
         const int rel = t - 32 * c - 4 * hh;
@@ -459,6 +510,18 @@ __global__ __launch_bounds__(256) void k_lce_bwd(LceArgs a) {
             o[i] = f32_to_bf16(g);
           }
           *reinterpret_cast<u16x4*>(stage + r32 * kLceStride + 32 * u + 8 * q + 4 * hh) = o;
+          ov[q] = o;
+        }
+      }
+      if (DH) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const u16x8 braw = {ov[2 * s2][0], ov[2 * s2][1], ov[2 * s2][2], ov[2 * s2][3],
+                              ov[2 * s2 + 1][0], ov[2 * s2 + 1][1], ov[2 * s2 + 1][2], ov[2 * s2 + 1][3]};
+          const lce_bf16x8 bfr = __builtin_bit_cast(lce_bf16x8, braw);
+#pragma unroll
+          for (int eb = 0; eb < EB; ++eb)
+            dh[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s2][eb], bfr, dh[eb], 0, 0, 0);
         }
       }
     }
@@ -473,6 +536,183 @@ __global__ __launch_bounds__(256) void k_lce_bwd(LceArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
   }
+  if (DH && valid) {                                         // lane = token column; 4 consecutive E rows per store
+#pragma unroll
+    for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = {dh[eb][4 * q], dh[eb][4 * q + 1], dh[eb][4 * q + 2], dh[eb][4 * q + 3]};
+        *reinterpret_cast<f32x4*>(a.dhp + ((int64_t)slice * a.N + tok) * E + 32 * eb + 8 * q + 4 * hh) = v;
+      }
+  }
+}
+
+// LDS-staged variant for E <= 64: the 4 waves of a block (4 token tiles, one vocabulary slice) need the same W / W^T
+// fragments, and with per-wave global loads the 20-36 KB per chunk pair and block go through the CU's L1 at more
+// than its 64 B/clk -- the kernel was L1-bound, not HBM-bound.  Here the block fetches each pair's fragment image
+// ONCE (register-staged: loads for pair p+1 are in flight under pair p's math, committed to the other LDS buffer at
+// the end of the iteration, one barrier per pair) and every wave reads its fragments with conflict-free ds_read_b128.
+template <int NKS, bool DH>
+__global__ __launch_bounds__(256) void k_lce_bwd_s(LceArgs a) {
+  constexpr int NF = NKS + 1;
+  constexpr int E = 16 * NKS, EB = (E + 31) / 32;
+  constexpr int WB = 2 * NF * 1024;                  // bytes of W fragments per chunk pair
+  constexpr int TB = DH ? 2 * 2 * EB * 1024 : 0;     // bytes of W^T fragments per chunk pair
+  constexpr int SB = WB + TB;
+  constexpr int NV = (SB / 16 + 255) / 256;          // 16-byte vectors per thread and stage
+  __shared__ __attribute__((aligned(16))) unsigned short stage_all[4][32 * kLceStride];
+  __shared__ __attribute__((aligned(16))) char wbuf[2][SB];
+  const int lane = threadIdx.x & 63, r32 = lane & 31, hh = lane >> 5;
+  const int wave = threadIdx.x >> 6;
+  unsigned short* stage = stage_all[wave];
+  const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  const int slice = (int)blockIdx.y;
+  const int64_t tok0 = tile * 32, tok = tok0 + r32;
+  const bool valid = tok < a.N;
+  const float coef = valid ? a.dper[tok / a.S] * a.tokscale[tok] : 0.f;
+  const int npair = a.V >> 6;
+  const int p0 = slice * a.per;
+  int p1 = p0 + a.per;
+  if (p1 > npair) p1 = npair;
+  const int orow = lane >> 3, ocol = (lane & 7) * 8;
+  const bool live = __any(coef != 0.f) != 0;                 // wave-uniform; tiles past N are not live either
+  if (!live) {                                               // padding tile: zero gradient rows, nothing read
+    const u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int p = p0; p < p1; ++p)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t row = tok0 + orow + 8 * i;
+        if (row < a.N) *reinterpret_cast<u16x8*>(a.dlogits + row * a.V + 64 * p + ocol) = z;
+      }
+    if (DH) {
+      const f32x4 zf = {0.f, 0.f, 0.f, 0.f};
+      for (int idx = lane; idx < 32 * (E / 4); idx += 64) {
+        const int row = idx / (E / 4), c4 = idx % (E / 4);
+        if (tok0 + row < a.N)
+          *reinterpret_cast<f32x4*>(a.dhp + ((int64_t)slice * a.N + tok0 + row) * E + 4 * c4) = zf;
+      }
+    }
+  }
+  if (!__syncthreads_or(live ? 1 : 0)) return;               // no live tile in this block: no weights needed
+  lce_bf16x8 hf[NF];
+  lce_load_h<NF>(a.h, live ? tok : 0, live && valid, hh, hf);
+  const int t = valid ? (int)a.target[tok] : -1;
+  f32x16 dh[EB];
+#pragma unroll
+  for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dh[eb][r] = 0.f;
+  const float c0 = valid ? __builtin_amdgcn_logf(fabsf(coef)) - a.lse[tok] * kLog2e : -INFINITY;
+  const unsigned sgn = __float_as_uint(coef) & 0x80000000u;
+  const float uni = coef * (a.smoothing > 0.f ? a.smoothing / (float)a.V : 0.f);
+  const float hot = coef * (a.smoothing > 0.f ? 1.f - a.smoothing : 1.f);
+  const bool smooth = a.smoothing > 0.f;
+  const char* wsrc = reinterpret_cast<const char*>(a.W);
+  const char* tsrc = reinterpret_cast<const char*>(a.Wt);
+  u16x8 pre[NV];
+  auto fetch = [&](int p) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int off = (v * 256 + (int)threadIdx.x) * 16;
+      if (off < WB) pre[v] = *reinterpret_cast<const u16x8*>(wsrc + (int64_t)p * WB + off);
+      else if (DH && off < SB) pre[v] = *reinterpret_cast<const u16x8*>(tsrc + (int64_t)p * TB + (off - WB));
+    }
+  };
+  auto commit = [&](int b) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int off = (v * 256 + (int)threadIdx.x) * 16;
+      if (off < SB) *reinterpret_cast<u16x8*>(wbuf[b] + off) = pre[v];
+    }
+  };
+  if (p0 < p1) { fetch(p0); commit(0); }
+  __syncthreads();
+  for (int p = p0; p < p1; ++p) {
+    const int b = (p - p0) & 1;
+    if (p + 1 < p1) fetch(p + 1);                            // in flight under this pair's math
+    if (live) {
+      const bool slow = smooth || (__any((t >> 6) == p) != 0);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int c = 2 * p + u;
+        lce_bf16x8 wf[NF];
+#pragma unroll
+        for (int ks = 0; ks < NF; ++ks)
+          wf[ks] = *reinterpret_cast<const lce_bf16x8*>(wbuf[b] + ((u * NF + ks) * 64 + lane) * 16);
+        const f32x16 x = lce_tile<NF>(wf, hf);
+        u16x4 ov[4];
+        if (!slow) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            u16x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              o[i] = f32_to_bf16(__uint_as_float(__float_as_uint(ex2(fmaf(x[4 * q + i], kLog2e, c0))) ^ sgn));
+            *reinterpret_cast<u16x4*>(stage + r32 * kLceStride + 32 * u + 8 * q + 4 * hh) = o;
+            ov[q] = o;
+          }
+        } else {
+          const int rel = t - 32 * c - 4 * hh;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            u16x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              float g = __uint_as_float(__float_as_uint(ex2(fmaf(x[4 * q + i], kLog2e, c0))) ^ sgn) - uni;
+              if (rel == i + 8 * q) g -= hot;
+              o[i] = f32_to_bf16(g);
+            }
+            *reinterpret_cast<u16x4*>(stage + r32 * kLceStride + 32 * u + 8 * q + 4 * hh) = o;
+            ov[q] = o;
+          }
+        }
+        if (DH) {
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const u16x8 braw = {ov[2 * s2][0], ov[2 * s2][1], ov[2 * s2][2], ov[2 * s2][3],
+                                ov[2 * s2 + 1][0], ov[2 * s2 + 1][1], ov[2 * s2 + 1][2], ov[2 * s2 + 1][3]};
+            const lce_bf16x8 bfr = __builtin_bit_cast(lce_bf16x8, braw);
+#pragma unroll
+            for (int eb = 0; eb < EB; ++eb) {
+              const lce_bf16x8 af = *reinterpret_cast<const lce_bf16x8*>(
+                  wbuf[b] + WB + (((u * 2 + s2) * EB + eb) * 64 + lane) * 16);
+              dh[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, dh[eb], 0, 0, 0);
+            }
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = orow + 8 * i;
+        const u16x8 v = *reinterpret_cast<const u16x8*>(stage + row * kLceStride + ocol);
+        if (tok0 + row < a.N) *reinterpret_cast<u16x8*>(a.dlogits + (tok0 + row) * a.V + 64 * p + ocol) = v;
+      }
+    }
+    if (p + 1 < p1) commit(b ^ 1);
+    __syncthreads();       // pair p+1 visible; every wave is done with buffer b and with its transpose stage
+  }
+  if (DH && live && valid) {
+#pragma unroll
+    for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = {dh[eb][4 * q], dh[eb][4 * q + 1], dh[eb][4 * q + 2], dh[eb][4 * q + 3]};
+        *reinterpret_cast<f32x4*>(a.dhp + ((int64_t)slice * a.N + tok) * E + 32 * eb + 8 * q + 4 * hh) = v;
+      }
+  }
+}
+
+// d h (N, E) bf16 = sum over the VSB vocabulary-slice partials, in slice order
+__global__ __launch_bounds__(256) void k_lce_dh_combine(const float* __restrict__ partial, unsigned short* __restrict__ dh,
+                                                         int64_t NE, int VSB) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= NE) return;
+  f32x4 s = *reinterpret_cast<const f32x4*>(partial + i);
+  for (int v = 1; v < VSB; ++v) s += *reinterpret_cast<const f32x4*>(partial + (int64_t)v * NE + i);
+  const u16x4 o = {f32_to_bf16(s[0]), f32_to_bf16(s[1]), f32_to_bf16(s[2]), f32_to_bf16(s[3])};
+  *reinterpret_cast<u16x4*>(dh + i) = o;
 }
 
 int lce_check(const char* name, int64_t Bn, int64_t S, int64_t E, int64_t V, float smoothing) {
@@ -505,15 +745,23 @@ extern "C" int64_t mivae_lce_workspace_floats(int64_t N, int64_t V) {
 // W (V, E) bf16 row-major + bias (V) fp32 (or NULL) -> Wp (V * (E + 16) bf16): what mivae_lce_fwd / _bwd read
 extern "C" int64_t mivae_lce_pack_elems(int64_t V, int64_t E) { return V > 0 && E > 0 ? V * (E + 16) : 0; }
 
-extern "C" int mivae_lce_pack(const void* W, const float* bias, void* Wp, int64_t V, int64_t E, void* stream) {
+// Wtp (V * E bf16, may be NULL): the W^T fragment image mivae_lce_bwd_dh reads, written by the same launch.
+extern "C" int mivae_lce_pack2(const void* W, const float* bias, void* Wp, void* Wtp, int64_t V, int64_t E,
+                               void* stream) {
   MIVAE_REQUIRE(W && Wp, "lce_pack: null pointer");
   MIVAE_REQUIRE((E == 32 || E == 64 || E == 128 || E == 256) && V >= 32 && V % 32 == 0 && V < (1ll << 31),
                 "lce_pack: bad shape V=%lld E=%lld", (long long)V, (long long)E);
-  MIVAE_REQUIRE(aligned16(W) && aligned16(Wp), "lce_pack: operands must be 16-byte aligned");
-  const int64_t groups = (V / 32) * (E / 16 + 1) * 64;
-  k_lce_pack<<<(unsigned)((groups + 255) / 256), 256, 0, S_(stream)>>>((const unsigned short*)W, bias, (unsigned short*)Wp, V, (int)E);
+  MIVAE_REQUIRE(aligned16(W) && aligned16(Wp) && aligned16(Wtp), "lce_pack: operands must be 16-byte aligned");
+  int64_t groups = (V / 32) * (E / 16 + 1) * 64;
+  if (Wtp) groups += (V / 32) * 2 * (E / 32) * 64;
+  k_lce_pack<<<(unsigned)((groups + 255) / 256), 256, 0, S_(stream)>>>((const unsigned short*)W, bias, (unsigned short*)Wp,
+                                                                         (unsigned short*)Wtp, V, (int)E);
   MIVAE_CHECK_LAUNCH("lce_pack");
   return MIVAE_OK;
+}
+
+extern "C" int mivae_lce_pack(const void* W, const float* bias, void* Wp, int64_t V, int64_t E, void* stream) {
+  return mivae_lce_pack2(W, bias, Wp, nullptr, V, E, stream);
 }
 
 // per_seq (Bn), lse (N), tokscale (N) as mivae_nll_fwd; h (N, E) bf16, W = packed weight + bias (mivae_lce_pack).
@@ -574,11 +822,60 @@ extern "C" int mivae_lce_bwd(const void* h, const void* W, const int64_t* target
   dim3 grid((unsigned)(((N + 31) / 32 + 3) / 4), (unsigned)VS);
   hipStream_t st = S_(stream);
   switch (E) {
-    case 32: k_lce_bwd<2><<<grid, 256, 0, st>>>(a); break;
-    case 64: k_lce_bwd<4><<<grid, 256, 0, st>>>(a); break;
-    case 128: k_lce_bwd<8><<<grid, 256, 0, st>>>(a); break;
-    default: k_lce_bwd<16><<<grid, 256, 0, st>>>(a); break;
+    case 32: k_lce_bwd_s<2, false><<<grid, 256, 0, st>>>(a); break;
+    case 64: k_lce_bwd_s<4, false><<<grid, 256, 0, st>>>(a); break;
+    case 128: k_lce_bwd<8, false><<<grid, 256, 0, st>>>(a); break;
+    default: k_lce_bwd<16, false><<<grid, 256, 0, st>>>(a); break;
   }
   MIVAE_CHECK_LAUNCH("lce_bwd");
+  return MIVAE_OK;
+}
+
+// vocabulary slices of mivae_lce_bwd_dh: ~2048 waves (one resident set at 2 waves / SIMD) keeps the fp32 d h
+// partials (slices x N x E) small
+static int lce_dh_blocks(int64_t N, int64_t V) {
+  const int64_t tiles = (N + 31) / 32;
+  static const int64_t target = getenv("MIVAE_LCE_DH_WAVES") ? atoll(getenv("MIVAE_LCE_DH_WAVES")) : 2048;
+  int64_t vs = (target + tiles - 1) / tiles;
+  if (vs > 64) vs = 64;
+  if (vs > V / 64) vs = V / 64;
+  return vs < 1 ? 1 : (int)vs;
+}
+
+extern "C" int64_t mivae_lce_dh_workspace_floats(int64_t N, int64_t E, int64_t V) {
+  if (N <= 0 || E <= 0 || V <= 0) return 0;
+  return (int64_t)lce_dh_blocks(N, V) * N * E;
+}
+
+// mivae_lce_bwd that also produces d h (N, E) bf16 = dlogits W in the same pass (Wtp from mivae_lce_pack2,
+// workspace of mivae_lce_dh_workspace_floats(N, E, V) floats); dlogits is still written for the d W product.
+extern "C" int mivae_lce_bwd_dh(const void* h, const void* W, const void* Wtp, const int64_t* target, const float* lse,
+                                const float* tokscale, const float* dper_seq, void* dlogits, float* workspace, void* dh,
+                                int64_t Bn, int64_t S, int64_t E, int64_t V, float smoothing, void* stream) {
+  int rc = lce_check("lce_bwd_dh", Bn, S, E, V, smoothing);
+  if (rc) return rc;
+  if (Bn == 0) return MIVAE_OK;
+  MIVAE_REQUIRE(h && W && Wtp && target && lse && tokscale && dper_seq && dlogits && workspace && dh,
+                "lce_bwd_dh: null pointer");
+  MIVAE_REQUIRE(aligned16(h) && aligned16(W) && aligned16(Wtp) && aligned16(dlogits) && aligned16(workspace) &&
+                aligned16(dh), "lce_bwd_dh: operands must be 16-byte aligned");
+  const int64_t N = Bn * S;
+  LceArgs a = {};
+  a.h = (const unsigned short*)h; a.W = (const unsigned short*)W; a.Wt = (const unsigned short*)Wtp; a.target = target;
+  a.lse = lse; a.tokscale = tokscale; a.dper = dper_seq; a.dlogits = (unsigned short*)dlogits; a.dhp = workspace;
+  a.N = N; a.S = (int)S; a.V = (int)V; a.smoothing = smoothing;
+  const int VSB = lce_dh_blocks(N, V);
+  a.per = (int)((V / 64 + VSB - 1) / VSB);
+  dim3 grid((unsigned)(((N + 31) / 32 + 3) / 4), (unsigned)VSB);
+  hipStream_t st = S_(stream);
+  switch (E) {
+    case 32: k_lce_bwd_s<2, true><<<grid, 256, 0, st>>>(a); break;
+    case 64: k_lce_bwd_s<4, true><<<grid, 256, 0, st>>>(a); break;
+    case 128: k_lce_bwd<8, true><<<grid, 256, 0, st>>>(a); break;
+    default: k_lce_bwd<16, true><<<grid, 256, 0, st>>>(a); break;
+  }
+  MIVAE_CHECK_LAUNCH("lce_bwd_dh");
+  k_lce_dh_combine<<<(unsigned)((N * E / 4 + 255) / 256), 256, 0, st>>>(workspace, (unsigned short*)dh, N * E, VSB);
+  MIVAE_CHECK_LAUNCH("lce_dh_combine");
   return MIVAE_OK;
 }

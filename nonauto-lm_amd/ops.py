@@ -625,7 +625,8 @@ class _LinearNLL(torch.autograd.Function):
         b32 = None if bias is None else bias.detach().float().contiguous()
         # fragment-ordered weight + bias image for the two kernels
         wp = torch.empty(L.query("mivae_lce_pack_elems", V, E), dtype=torch.bfloat16, device=h.device)
-        L.call("mivae_lce_pack", L.ptr(w16), L.ptr(b32), L.ptr(wp), V, E, L.stream())
+        wtp = torch.empty(V * E, dtype=torch.bfloat16, device=h.device) if LCE_FUSED_DH and h.requires_grad else None
+        L.call("mivae_lce_pack2", L.ptr(w16), L.ptr(b32), L.ptr(wp), L.ptr(wtp), V, E, L.stream())
         tgt = target.reshape(Bn, S).contiguous().long()
         w = weights.reshape(Bn, S).contiguous().float()
         dev = h.device
@@ -636,6 +637,7 @@ class _LinearNLL(torch.autograd.Function):
             L.call("mivae_lce_fwd", L.ptr(h2), L.ptr(wp), L.ptr(tgt), L.ptr(w), L.ptr(per_seq), L.ptr(aux[0]),
                    L.ptr(aux[1]), L.ptr(ws), Bn, S, E, V, float(smoothing), L.stream())
         ctx.save_for_backward(h2, w16, wp, tgt, aux)
+        ctx.wtp = wtp
         ctx.meta = (Bn, S, E, V, float(smoothing), h.shape, h.dtype, weight.dtype, bias is not None)
         return per_seq
 
@@ -644,12 +646,23 @@ class _LinearNLL(torch.autograd.Function):
         h2, w16, wp, tgt, aux = ctx.saved_tensors
         Bn, S, E, V, smoothing, hshape, hdtype, wdtype, has_bias = ctx.meta
         dl = torch.empty(Bn * S, V, dtype=torch.bfloat16, device=h2.device)
-        with _timed("lce_bwd"):
-            L.call("mivae_lce_bwd", L.ptr(h2), L.ptr(wp), L.ptr(tgt), L.ptr(aux[0]), L.ptr(aux[1]),
-                   L.ptr(dper.contiguous().float()), L.ptr(dl), Bn, S, E, V, smoothing, L.stream())
         dh = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dh = dl.matmul(w16).view(hshape).to(hdtype)
+        if ctx.wtp is not None and ctx.needs_input_grad[0]:
+            # d h = dl W on the matrix cores inside the same pass (no (N, V) x (V, E) library GEMM, no re-read of dl)
+            N = Bn * S
+            dh2 = torch.empty(N, E, dtype=torch.bfloat16, device=h2.device)
+            ws = torch.empty(L.query("mivae_lce_dh_workspace_floats", N, E, V), dtype=torch.float32, device=h2.device)
+            with _timed("lce_bwd"):
+                L.call("mivae_lce_bwd_dh", L.ptr(h2), L.ptr(wp), L.ptr(ctx.wtp), L.ptr(tgt), L.ptr(aux[0]), L.ptr(aux[1]),
+                       L.ptr(dper.contiguous().float()), L.ptr(dl), L.ptr(ws), L.ptr(dh2), Bn, S, E, V, smoothing,
+                       L.stream())
+            dh = dh2.view(hshape).to(hdtype)
+        else:
+            with _timed("lce_bwd"):
+                L.call("mivae_lce_bwd", L.ptr(h2), L.ptr(wp), L.ptr(tgt), L.ptr(aux[0]), L.ptr(aux[1]),
+                       L.ptr(dper.contiguous().float()), L.ptr(dl), Bn, S, E, V, smoothing, L.stream())
+            if ctx.needs_input_grad[0]:
+                dh = dl.matmul(w16).view(hshape).to(hdtype)
         want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1] and want_db:
             # one dense product for both: d W = dl^T h and d b = dl^T 1 (a ones block appended to h)
@@ -664,6 +677,7 @@ class _LinearNLL(torch.autograd.Function):
 
 
 LCE_FEATURES = (32, 64, 128, 256)
+LCE_FUSED_DH = True        # d h inside the lce backward pass (mivae_lce_bwd_dh); False: library GEMM on d logits
 
 
 def linear_nll_supported(h, weight) -> bool:

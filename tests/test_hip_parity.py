@@ -765,6 +765,37 @@ def test_linear_nll_fused_vs_oracle(M, Bn, S, E, V, sm, bias):
     assert torch.equal(hg.grad[pad], torch.zeros_like(hg.grad[pad]))
 
 
+@pytest.mark.parametrize("Bn,S,E,V,sm", [(6, 9, 64, 128, 0.0), (4, 33, 32, 1024, 0.1), (3, 70, 128, 8192, 0.0),
+                                         (5, 7, 256, 512, 0.2), (64, 64, 64, 8192, 0.0)])
+def test_lce_bwd_fused_dh_matches_library_product(M, Bn, S, E, V, sm):
+    """mivae_lce_bwd_dh: d h formed inside the backward pass (MFMA on the in-register bf16 d logits tiles, fixed-order
+    slice partials) vs the library product d logits @ W on the d logits the plain entry point writes: same bf16
+    operands, so they agree to the final bf16 rounding of d h; d logits itself must be bit-identical."""
+    gen = torch.Generator().manual_seed(Bn + S + E + V)
+    h = dev(torch.randn(Bn, S, E, generator=gen).to(torch.bfloat16))
+    W = dev(torch.randn(V, E, generator=gen) * 0.3)
+    b = dev(torch.randn(V, generator=gen))
+    target = torch.randint(1, V, (Bn, S), generator=gen)
+    lengths = torch.randint(0, S + 1, (Bn,), generator=gen)
+    lengths[0] = S
+    target[torch.arange(S)[None, :] >= lengths[:, None]] = 0
+    w = dev(O.tokens_mask(target).float())
+    gout = dev(torch.randn(Bn, generator=gen))
+    res = {}
+    for fused in (True, False):
+        M.ops.LCE_FUSED_DH = fused
+        try:
+            hg, Wg, bg = h.clone().requires_grad_(True), W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            (M.ops.linear_nll(hg, Wg, bg, dev(target), w, sm) * gout).sum().backward()
+        finally:
+            M.ops.LCE_FUSED_DH = True
+        res[fused] = (hg.grad.float(), Wg.grad, bg.grad)
+    assert torch.equal(res[True][1], res[False][1]) and torch.equal(res[True][2], res[False][2])   # same d logits
+    assert rel_err(res[True][0], res[False][0]) < 4e-3
+    pad = w == 0
+    assert torch.equal(res[True][0][pad], torch.zeros_like(res[True][0][pad]))
+
+
 def test_fused_decode_matches_unfused(M):
     """NonAutoModel.decode: fused projection + NLL path (training_outputs_only, bf16 autocast) vs the unfused
     projection -> LabelSmoothingNLL path on the same weights and latents."""

@@ -13,9 +13,13 @@ import os
 import sys
 from collections import defaultdict
 
-NAMES = {"k_nll_fwd": "nll_fwd", "k_nll_bwd": "nll_bwd", "k_stack_fwd": "nice_stack_fwd", "k_stack_bwd": "nice_stack_bwd",
-         "k_dw_partial": "nice_dw", "k_dw_reduce": "nice_dw", "k_lce_fwd": "lce_fwd", "k_lce_combine": "lce_fwd",
-         "k_lce_bwd": "lce_bwd"}
+import re
+
+# device kernel (regex on the demangled name) -> logical entry point of bench.py's kernel table
+NAMES = {r"k_nll_fwd<": "nll_fwd", r"k_nll_bwd<": "nll_bwd", r"k_stack_fwd<": "nice_stack_fwd",
+         r"k_stack_bwd<": "nice_stack_bwd", r"k_dw_partial[<(]": "nice_dw", r"k_dw_reduce[<(]": "nice_dw",
+         r"k_lce_fwd<": "lce_fwd", r"k_lce_combine\(": "lce_fwd", r"k_lce_bwd(_s)?<\d+, false>": "lce_bwd",
+         r"k_lce_bwd(_s)?<\d+, true>": "lce_bwd_dh", r"k_lce_dh_combine\(": "lce_bwd_dh"}
 
 
 def collect(directory, counter):
@@ -25,7 +29,7 @@ def collect(directory, counter):
             if row["Counter_Name"] != counter:
                 continue
             for key, name in NAMES.items():
-                if key + "<" in row["Kernel_Name"] or key + "(" in row["Kernel_Name"]:
+                if re.search(key, row["Kernel_Name"]):
                     per[name][key].append(float(row["Counter_Value"]))
     # one logical launch = one dispatch of each of its device kernels
     return {name: sum(sum(v) / len(v) for v in ks.values()) for name, ks in per.items()}
