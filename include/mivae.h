@@ -172,6 +172,11 @@ int mivae_colsum(const void* x, float* out, float* workspace, int64_t rows, int6
  * extra kernel per parameter). */
 int mivae_colsum_sink(const void* x, float* out0, float* out1, int64_t split, float* workspace, int64_t rows,
                       int64_t D, int dtype, void* stream);
+/* mivae_colsum_sink for MANY short matrices in one launch: jobs = njobs x {x, out0, out1, rows (<= 512), D, split} as
+ * 6 x int64 per job in device memory; bit-identical to njobs calls of mivae_colsum_sink (same summation order).
+ * Folds the [dW | db] partials of every small Linear of a training step at the end of backward
+ * (trainer.py:284, loss.backward()).  max_D = the largest D in the table. */
+int mivae_colsum_sink_multi(const void* jobs, int64_t njobs, int64_t max_D, void* stream);
 
 /* ---- KL / ELBO tail -------------------------------------------------------------------------------- */
 /* kl = clamp(logq - logp, min = free_bits) (clamp only if use_fb).  Replaces DefaultKLLoss.forward

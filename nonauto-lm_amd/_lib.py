@@ -51,6 +51,7 @@ SIGNATURES = {
     "mivae_linear_fwd": [P, P, P, P, I64, I64, I64, P],
     "mivae_linear_dgrad": [P, P, P, I64, I64, I64, P],
     "mivae_linear_wgrad_rows": [I64],
+    "mivae_colsum_sink_multi": [P, I64, I64, P],
     "mivae_lce_pack2": [P, P, P, P, I64, I64, P],
     "mivae_lce_dh_workspace_floats": [I64, I64, I64],
     "mivae_lce_bwd_dh": [P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P],

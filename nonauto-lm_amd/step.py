@@ -38,10 +38,15 @@ class TrainStep:
     def _fwd_bwd(self):
         from . import ops
         ops.GRAD_SINK = self.grad_sink       # weight-gradient kernels add straight into the flat buckets
+        if self.grad_sink:
+            ops.begin_deferred_sinks()       # ... the small-Linear partials in one launch at the end of backward
         try:
-            return self._fwd_bwd_inner()
+            info = self._fwd_bwd_inner()
+            ops.flush_grad_sinks()
+            return info
         finally:
             ops.GRAD_SINK = False
+            ops._DEFER = None
 
     def _fwd_bwd_inner(self):
         with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None):

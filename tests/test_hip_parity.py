@@ -870,19 +870,25 @@ def test_grad_sink_matches_autograd_accumulation(M):
     tokens = torch.where(tokens > 0, tokens % 500 + 4, tokens).to(DEV)
     eps = torch.randn(64, 1, 64, 64, device=DEV)
     grads = {}
-    for sink in (False, True):
+    for sink in (False, True, "deferred"):       # deferred: one mivae_colsum_sink_multi launch after backward
         reducer.zero_grad()
-        M.ops.GRAD_SINK = sink
+        M.ops.GRAD_SINK = bool(sink)
+        if sink == "deferred":
+            M.ops.begin_deferred_sinks()
         try:
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 out = model(tokens, tokens, eps=eps)
             out["loss_info"]["batch-loss"].backward()
+            if sink == "deferred":
+                assert len(M.ops._DEFER) >= 8        # the small Linear layers were queued, not folded one by one
+                M.ops.flush_grad_sinks()
         finally:
             M.ops.GRAD_SINK = False
+            M.ops._DEFER = None
         grads[sink] = [b.clone() for b in reducer.buckets]
     assert any(float(b.abs().max()) > 0 for b in grads[True])
-    for a, b in zip(grads[False], grads[True]):
-        assert torch.equal(a, b)
+    for a, b, c in zip(grads[False], grads[True], grads["deferred"]):
+        assert torch.equal(a, b) and torch.equal(a, c)
 
 
 # ------------------------------------------------------------------------------------ 8f-2: MAF / IAF / MADE
