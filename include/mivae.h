@@ -252,6 +252,15 @@ int mivae_linear_fwd(const void* x, const void* w, const void* bias, void* y, in
 int mivae_linear_dgrad(const void* dy, const void* w, void* dx, int64_t N, int64_t Fi, int64_t Fo, void* stream);
 /* partial (mivae_linear_wgrad_rows(N), Fo*Fi + Fo) fp32: per-wave [dy^T x | colsum dy]; its column sums
  * (mivae_colsum) are [dW (Fo, Fi) | db (Fo)] (autograd w.r.t. weight and bias).  Fi, Fo in {32, 64, 128}. */
+/* G (1..4) Linear layers of one shape applied to the SAME input -- the query / key / value projections of
+ * self-attention (nn/transformer.py:41-48, 60-62) and the mu / sigma heads of the posterior (posterior.py:19-27,
+ * row a3): y_g = x W_g^T + bias_g for all g in one launch (one read of x), and dx = sum_g dy_g W_g as ONE contraction
+ * over G * Fo <= 256 (no per-layer dx, no accumulation kernels).  w / bias / y / dy: HOST arrays of G device pointers
+ * (bias or its entries may be NULL).  Weight gradients: mivae_linear_wgrad per layer. */
+int mivae_linear_fwd_group(const void* x, const void* const* w, const void* const* bias, void* const* y, int64_t G,
+                           int64_t N, int64_t Fi, int64_t Fo, void* stream);
+int mivae_linear_dgrad_group(const void* const* dy, const void* const* w, void* dx, int64_t G, int64_t N, int64_t Fi,
+                             int64_t Fo, void* stream);
 int64_t mivae_linear_wgrad_rows(int64_t N);
 int mivae_linear_wgrad(const void* x, const void* dy, float* partial, int64_t N, int64_t Fi, int64_t Fo,
                        void* stream);
@@ -274,6 +283,12 @@ int mivae_layernorm_bwd(const void* dy, const void* x, const float* gamma, const
 int mivae_layernorm_bwd_sink(const void* dy, const void* x, const float* gamma, const float* mean,
                              const float* rstd, void* dx, float* dgamma, float* dbeta, float* workspace,
                              int64_t rows, int64_t D, int in_dtype, int out_dtype, void* stream);
+/* dx as mivae_layernorm_bwd; the parameter gradients stay as per-block partials: workspace is a (count, 2 D) fp32
+ * matrix whose column sums are [d gamma | d beta]; count (> 0) is RETURNED (negative = error status).  Fold with
+ * mivae_colsum_sink(_multi) (split = D), e.g. once per step for all LayerNorm layers. */
+int64_t mivae_layernorm_bwd_partial(const void* dy, const void* x, const float* gamma, const float* mean,
+                                    const float* rstd, void* dx, float* workspace, int64_t rows, int64_t D,
+                                    int in_dtype, int out_dtype, void* stream);
 
 /* ---- step-harness tail on flat buffers ---------------------------------------------------------- */
 /* Gradient clipping + Adam + zero_grad of DefaultTrainer._train_batch (training/trainers/trainer.py:286-289

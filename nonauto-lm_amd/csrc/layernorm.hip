@@ -233,11 +233,13 @@ extern "C" int mivae_layernorm_fwd(const void* x, const float* gamma, const floa
 
 static int layernorm_bwd_impl(const void* dy, const void* x, const float* gamma, const float* mean,
                               const float* rstd, void* dx, float* dgamma_dbeta, float* dbeta_sink, float* workspace,
-                              int64_t rows, int64_t D, int in_dtype, int out_dtype, void* stream) {
+                              int64_t rows, int64_t D, int in_dtype, int out_dtype, void* stream,
+                              int* nblk_out = nullptr) {
   MIVAE_REQUIRE(rows >= 1 && D >= 1, "layernorm_bwd: bad shape");
   MIVAE_REQUIRE((in_dtype == MIVAE_F32 || in_dtype == MIVAE_BF16) && (out_dtype == MIVAE_F32 || out_dtype == MIVAE_BF16),
                 "layernorm_bwd: dtype must be 0 (f32) or 1 (bf16)");
-  MIVAE_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma_dbeta && workspace, "layernorm_bwd: null pointer");
+  MIVAE_REQUIRE(dy && x && gamma && mean && rstd && dx && (dgamma_dbeta || nblk_out) && workspace,
+                "layernorm_bwd: null pointer");
   LnCfg c;
   MIVAE_REQUIRE(ln_cfg(rows, D, D % 4 == 0 && aligned16(x) && aligned16(dy) && aligned16(dx), c),
                 "layernorm_bwd: D = %lld too wide for this kernel", (long long)D);
@@ -247,6 +249,7 @@ static int layernorm_bwd_impl(const void* dy, const void* x, const float* gamma,
   else if (out_dtype == MIVAE_F32) launch_bwd<unsigned short, float>(c, dy, x, gamma, mean, rstd, dx, workspace, rows, (int)D, st);
   else launch_bwd<unsigned short, unsigned short>(c, dy, x, gamma, mean, rstd, dx, workspace, rows, (int)D, st);
   MIVAE_CHECK_LAUNCH("layernorm_bwd");
+  if (nblk_out) { *nblk_out = c.nblk; return MIVAE_OK; }    // partials only: the caller folds them
   const int total = 2 * (int)D;
   k_ln_finish<<<(unsigned)((total + 63) / 64), 256, 0, st>>>(workspace, dgamma_dbeta, c.nblk, total, dbeta_sink, (int)D,
                                                               dbeta_sink ? 1 : 0);
@@ -266,4 +269,17 @@ extern "C" int mivae_layernorm_bwd_sink(const void* dy, const void* x, const flo
                                         int64_t rows, int64_t D, int in_dtype, int out_dtype, void* stream) {
   MIVAE_REQUIRE(dbeta, "layernorm_bwd_sink: null pointer");
   return layernorm_bwd_impl(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, rows, D, in_dtype, out_dtype, stream);
+}
+
+// dx as mivae_layernorm_bwd, but the parameter gradients are left as per-block partials in workspace:
+// workspace[b][0][c] = sum dy * xhat, workspace[b][1][c] = sum dy over block b's rows, b < the RETURNED count (> 0;
+// negative = error status).  Column sums of that (count, 2 D) matrix are [d gamma | d beta]: fold them with
+// mivae_colsum_sink / mivae_colsum_sink_multi (split = D), e.g. once per step for all LayerNorms.
+extern "C" int64_t mivae_layernorm_bwd_partial(const void* dy, const void* x, const float* gamma, const float* mean,
+                                               const float* rstd, void* dx, float* workspace, int64_t rows, int64_t D,
+                                               int in_dtype, int out_dtype, void* stream) {
+  int nblk = 0;
+  const int rc = layernorm_bwd_impl(dy, x, gamma, mean, rstd, dx, nullptr, nullptr, workspace, rows, D, in_dtype,
+                                    out_dtype, stream, &nblk);
+  return rc == MIVAE_OK ? (int64_t)nblk : (int64_t)rc;
 }

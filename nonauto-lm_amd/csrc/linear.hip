@@ -19,13 +19,18 @@ typedef __bf16 lin_bf16x8 __attribute__((ext_vector_type(8)));
 static inline hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
 __device__ __forceinline__ int lin_row(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
 
+constexpr int kMaxGroup = 4;
+
+// A group of G Linear layers that share their input (q / k / v projections of self-attention, the mu / sigma heads
+// of the posterior): forward = G outputs from one read of x in one launch; dgrad = dx = sum_g dy_g W_g as ONE
+// contraction over K = G * Fo (no per-layer dx tensors, no accumulation kernels).
 struct LinArgs {
-  const unsigned short* x;     // (N, K) bf16: activations (fwd) or dy (dgrad)
-  const unsigned short* w;     // (Fo, Fi) bf16 row-major (torch.nn.Linear layout)
-  const unsigned short* bias;  // (Fo) bf16 or null (fwd only)
-  unsigned short* y;           // (N, M) bf16
+  const unsigned short* x[kMaxGroup];     // fwd: x[0] = activations (N, Fi); dgrad: dy_g (N, Fo)
+  const unsigned short* w[kMaxGroup];     // (Fo, Fi) bf16 row-major (torch.nn.Linear layout)
+  const unsigned short* bias[kMaxGroup];  // (Fo) bf16 or null (fwd only)
+  unsigned short* y[kMaxGroup];           // fwd: y_g (N, Fo); dgrad: y[0] = dx (N, Fi)
   int64_t N;
-  int Fo, Fi;
+  int Fo, Fi, G;
 };
 
 // fwd  (TRANS = false): K = Fi, M = Fo, A fragments straight from W (rows = outputs, k = inputs)
@@ -33,31 +38,41 @@ struct LinArgs {
 template <int NK, bool TRANS>
 __global__ __launch_bounds__(256) void k_lin(LinArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned short wt[];   // TRANS: [M][K + 8]
-  constexpr int K = 16 * NK;
+  constexpr int K = 16 * NK;                          // fwd: Fi; dgrad: G * Fo (the whole group is one contraction)
   const int M = TRANS ? a.Fi : a.Fo;
   const int lane = threadIdx.x & 63, r32 = lane & 31, hh = lane >> 5;
   if (TRANS) {
-    // W (Fo = K rows, Fi = M cols) -> wt[m][k]; each thread moves 8 consecutive m of one k per step
+    // W_g (Fo rows, Fi = M cols) -> wt[m][g * Fo + k]; each thread moves 8 consecutive m of one k per step
     const int groups = K * (M >> 3);
     for (int g = threadIdx.x; g < groups; g += 256) {
       const int k = g / (M >> 3), m8 = (g % (M >> 3)) * 8;
-      const u16x8 v = *reinterpret_cast<const u16x8*>(a.w + (int64_t)k * M + m8);
+      const int gi = k / a.Fo, kl = k - gi * a.Fo;
+      const u16x8 v = *reinterpret_cast<const u16x8*>(a.w[gi] + (int64_t)kl * M + m8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) wt[(m8 + e) * (K + 8) + k] = v[e];
     }
     __syncthreads();
   }
   // one (32-token tile, 32-output chunk) unit per wave: 2-8 x more waves than tiles, the chip needs them
-  const int nch = M >> 5;
+  const int cpg = M >> 5;                             // chunks per layer
+  const int nch = TRANS ? cpg : cpg * a.G;
   const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t tile = unit / nch;
-  const int c = (int)(unit - tile * nch);
+  const int cg = (int)(unit - tile * nch);
+  const int gi = TRANS ? 0 : cg / cpg;                // wave-uniform: which layer of the group (fwd)
+  const int c = cg - gi * cpg;
   const int64_t tok = tile * 32 + r32;
   if (tile * 32 >= a.N) return;                       // wave-uniform, after the only barrier
   const bool valid = tok < a.N;
   lin_bf16x8 xf[NK];
-  {
-    const unsigned short* xp = a.x + (valid ? tok : 0) * K + 8 * hh;
+  if (TRANS) {
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+      const int k0 = 16 * ks, gk = k0 / a.Fo;
+      xf[ks] = *reinterpret_cast<const lin_bf16x8*>(a.x[gk] + (valid ? tok : 0) * a.Fo + (k0 - gk * a.Fo) + 8 * hh);
+    }
+  } else {
+    const unsigned short* xp = a.x[0] + (valid ? tok : 0) * K + 8 * hh;
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) xf[ks] = *reinterpret_cast<const lin_bf16x8*>(xp + 16 * ks);
   }
@@ -68,17 +83,18 @@ __global__ __launch_bounds__(256) void k_lin(LinArgs a) {
 #pragma unroll
       for (int ks = 0; ks < NK; ++ks) wf[ks] = *reinterpret_cast<const lin_bf16x8*>(p + 16 * ks);
     } else {
-      const unsigned short* p = a.w + (int64_t)(32 * c + r32) * K + 8 * hh;
+      const unsigned short* p = a.w[gi] + (int64_t)(32 * c + r32) * K + 8 * hh;
 #pragma unroll
       for (int ks = 0; ks < NK; ++ks) wf[ks] = *reinterpret_cast<const lin_bf16x8*>(p + 16 * ks);
     }
+    const unsigned short* bias = TRANS ? nullptr : a.bias[gi];
     f32x16 acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = (!TRANS && a.bias) ? bf16_to_f32(a.bias[32 * c + lin_row(r, hh)]) : 0.f;
+    for (int r = 0; r < 16; ++r) acc[r] = bias ? bf16_to_f32(bias[32 * c + lin_row(r, hh)]) : 0.f;
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xf[ks], acc, 0, 0, 0);
     if (valid) {
-      unsigned short* yp = a.y + tok * M + 32 * c + 4 * hh;
+      unsigned short* yp = a.y[gi] + tok * M + 32 * c + 4 * hh;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         u16x4 o = {f32_to_bf16(acc[4 * q]), f32_to_bf16(acc[4 * q + 1]), f32_to_bf16(acc[4 * q + 2]), f32_to_bf16(acc[4 * q + 3])};
@@ -192,9 +208,11 @@ __global__ __launch_bounds__(256) void k_lin_wgrad(WgArgs a) {
 
 bool lin_dim_ok(int64_t f) { return f == 32 || f == 64 || f == 128 || f == 256; }
 
+// K = contraction length (fwd: Fi; dgrad: G * Fo), M = output features per layer, units = 32-wide output chunks
 template <bool TRANS>
 int lin_launch(const LinArgs& a, int K, int M, hipStream_t st) {
-  const unsigned grid = (unsigned)((((a.N + 31) / 32) * (M / 32) + 3) / 4);
+  const int chunks = (M / 32) * (TRANS ? 1 : a.G);
+  const unsigned grid = (unsigned)((((a.N + 31) / 32) * chunks + 3) / 4);
   const size_t lds = TRANS ? (size_t)M * (K + 8) * 2 : 0;
   auto big = [&](const void* fn) {
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -202,7 +220,9 @@ int lin_launch(const LinArgs& a, int K, int M, hipStream_t st) {
   switch (K) {
     case 32: big((const void*)k_lin<2, TRANS>); k_lin<2, TRANS><<<grid, 256, lds, st>>>(a); return 0;
     case 64: big((const void*)k_lin<4, TRANS>); k_lin<4, TRANS><<<grid, 256, lds, st>>>(a); return 0;
+    case 96: big((const void*)k_lin<6, TRANS>); k_lin<6, TRANS><<<grid, 256, lds, st>>>(a); return 0;
     case 128: big((const void*)k_lin<8, TRANS>); k_lin<8, TRANS><<<grid, 256, lds, st>>>(a); return 0;
+    case 192: big((const void*)k_lin<12, TRANS>); k_lin<12, TRANS><<<grid, 256, lds, st>>>(a); return 0;
     case 256: big((const void*)k_lin<16, TRANS>); k_lin<16, TRANS><<<grid, 256, lds, st>>>(a); return 0;
   }
   return -1;
@@ -228,8 +248,9 @@ extern "C" int mivae_linear_fwd(const void* x, const void* w, const void* bias, 
   if (N == 0) return MIVAE_OK;
   MIVAE_REQUIRE(x && w && y, "linear_fwd: null pointer");
   MIVAE_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y), "linear_fwd: operands must be 16-byte aligned");
-  LinArgs a = {(const unsigned short*)x, (const unsigned short*)w, (const unsigned short*)bias, (unsigned short*)y, N,
-               (int)Fo, (int)Fi};
+  LinArgs a = {};
+  a.x[0] = (const unsigned short*)x; a.w[0] = (const unsigned short*)w; a.bias[0] = (const unsigned short*)bias;
+  a.y[0] = (unsigned short*)y; a.N = N; a.Fo = (int)Fo; a.Fi = (int)Fi; a.G = 1;
   MIVAE_REQUIRE(lin_launch<false>(a, (int)Fi, (int)Fo, S_(stream)) == 0, "linear_fwd: no kernel instance");
   MIVAE_CHECK_LAUNCH("linear_fwd");
   return MIVAE_OK;
@@ -244,9 +265,54 @@ extern "C" int mivae_linear_dgrad(const void* dy, const void* w, void* dx, int64
   if (N == 0) return MIVAE_OK;
   MIVAE_REQUIRE(dy && w && dx, "linear_dgrad: null pointer");
   MIVAE_REQUIRE(aligned16(dy) && aligned16(w) && aligned16(dx), "linear_dgrad: operands must be 16-byte aligned");
-  LinArgs a = {(const unsigned short*)dy, (const unsigned short*)w, nullptr, (unsigned short*)dx, N, (int)Fo, (int)Fi};
+  LinArgs a = {};
+  a.x[0] = (const unsigned short*)dy; a.w[0] = (const unsigned short*)w; a.y[0] = (unsigned short*)dx;
+  a.N = N; a.Fo = (int)Fo; a.Fi = (int)Fi; a.G = 1;
   MIVAE_REQUIRE(lin_launch<true>(a, (int)Fo, (int)Fi, S_(stream)) == 0, "linear_dgrad: no kernel instance");
   MIVAE_CHECK_LAUNCH("linear_dgrad");
+  return MIVAE_OK;
+}
+
+// G (2..4) Linear layers of the same shape applied to the SAME input: y_g (N, Fo) = x W_g^T + bias_g, one launch.
+// w / bias / y: host arrays of G device pointers (bias entries or the bias array itself may be NULL).
+extern "C" int mivae_linear_fwd_group(const void* x, const void* const* w, const void* const* bias, void* const* y,
+                                      int64_t G, int64_t N, int64_t Fi, int64_t Fo, void* stream) {
+  MIVAE_REQUIRE(G >= 1 && G <= kMaxGroup, "linear_fwd_group: G must be 1..%d", kMaxGroup);
+  MIVAE_REQUIRE(N >= 0 && N < (1ll << 31), "linear_fwd_group: bad N");
+  MIVAE_REQUIRE(lin_dim_ok(Fi) && lin_dim_ok(Fo), "linear_fwd_group: features must be 32, 64, 128 or 256 (Fi=%lld Fo=%lld)",
+                (long long)Fi, (long long)Fo);
+  if (N == 0) return MIVAE_OK;
+  MIVAE_REQUIRE(x && w && y && aligned16(x), "linear_fwd_group: null or misaligned pointer");
+  LinArgs a = {};
+  a.x[0] = (const unsigned short*)x; a.N = N; a.Fo = (int)Fo; a.Fi = (int)Fi; a.G = (int)G;
+  for (int g = 0; g < G; ++g) {
+    MIVAE_REQUIRE(w[g] && y[g] && aligned16(w[g]) && aligned16(y[g]), "linear_fwd_group: null or misaligned pointer");
+    a.w[g] = (const unsigned short*)w[g]; a.y[g] = (unsigned short*)y[g];
+    a.bias[g] = bias ? (const unsigned short*)bias[g] : nullptr;
+  }
+  MIVAE_REQUIRE(lin_launch<false>(a, (int)Fi, (int)Fo, S_(stream)) == 0, "linear_fwd_group: no kernel instance");
+  MIVAE_CHECK_LAUNCH("linear_fwd_group");
+  return MIVAE_OK;
+}
+
+// dx (N, Fi) = sum_g dy_g (N, Fo) W_g: the input gradient of the group as one contraction over G * Fo (<= 256).
+extern "C" int mivae_linear_dgrad_group(const void* const* dy, const void* const* w, void* dx, int64_t G, int64_t N,
+                                        int64_t Fi, int64_t Fo, void* stream) {
+  MIVAE_REQUIRE(G >= 1 && G <= kMaxGroup, "linear_dgrad_group: G must be 1..%d", kMaxGroup);
+  MIVAE_REQUIRE(N >= 0 && N < (1ll << 31), "linear_dgrad_group: bad N");
+  MIVAE_REQUIRE(lin_dim_ok(Fi) && lin_dim_ok(Fo) && G * Fo <= 256,
+                "linear_dgrad_group: features must be 32, 64, 128 or 256 and G * Fo <= 256 (Fi=%lld Fo=%lld G=%lld)",
+                (long long)Fi, (long long)Fo, (long long)G);
+  if (N == 0) return MIVAE_OK;
+  MIVAE_REQUIRE(dy && w && dx && aligned16(dx), "linear_dgrad_group: null or misaligned pointer");
+  LinArgs a = {};
+  a.y[0] = (unsigned short*)dx; a.N = N; a.Fo = (int)Fo; a.Fi = (int)Fi; a.G = (int)G;
+  for (int g = 0; g < G; ++g) {
+    MIVAE_REQUIRE(dy[g] && w[g] && aligned16(dy[g]) && aligned16(w[g]), "linear_dgrad_group: null or misaligned pointer");
+    a.x[g] = (const unsigned short*)dy[g]; a.w[g] = (const unsigned short*)w[g];
+  }
+  MIVAE_REQUIRE(lin_launch<true>(a, (int)(G * Fo), (int)Fi, S_(stream)) == 0, "linear_dgrad_group: no kernel instance");
+  MIVAE_CHECK_LAUNCH("linear_dgrad_group");
   return MIVAE_OK;
 }
 

@@ -12,7 +12,7 @@ import torch.distributions as D
 
 from . import ops
 from .flows import Flow, fused_stack_spec
-from .nn_bracket import Linear
+from .nn_bracket import Linear, linear_group
 from .registrable import Registrable
 
 
@@ -180,8 +180,10 @@ class Posterior(torch.nn.Module, Registrable):
         return torch.randn(lead, device=mu.device, dtype=mu.dtype)
 
     def sample_and_log_prob(self, encoded, mask, random=True, eps=None):
-        self._mu = self._mu_net(encoded)
-        self._sigma = self._sigma_net(encoded)
+        # a3: the two heads share `encoded` -> one grouped launch forward, one for the input gradient
+        mu, pre = linear_group(encoded, [self._mu_net, self._sigma_net[0]])
+        self._mu = mu
+        self._sigma = self._sigma_net[2](self._sigma_net[1](pre))
         noise = self._draw(self._mu, random, eps)
         z, log_prob = ops.reparam_logq(self._mu, self._sigma, noise, mask, self.samples)
         rep_mask = None if mask is None else mask.repeat_interleave(self.samples, dim=0)

@@ -110,6 +110,61 @@ class Linear(torch.nn.Linear):
         return super().forward(x)
 
 
+class _GroupLinearFn(torch.autograd.Function):
+    """G same-shape Linear layers on one input (q / k / v of self-attention; mu / sigma heads): one forward launch,
+    one input-gradient launch (a single contraction over G * Fo), weight gradients per layer into the sinks."""
+
+    @staticmethod
+    def forward(ctx, x, G, *flat):
+        ws, bs, wl, bl = flat[0:G], flat[G:2 * G], flat[2 * G:3 * G], flat[3 * G:4 * G]
+        x2 = x.contiguous().view(-1, x.size(-1))
+        ctx.save_for_backward(x2, *wl)
+        ctx.params = list(zip(ws, bs))
+        ctx.G, ctx.xshape, ctx.param_dtype = G, x.shape, ws[0].dtype
+        ys = ops.linear_fwd_group(x2, list(wl), list(bl))
+        return tuple(y.view(*x.shape[:-1], y.size(-1)) for y in ys)
+
+    @staticmethod
+    def backward(ctx, *gys):
+        x2, *wl = ctx.saved_tensors
+        G = ctx.G
+        Fo = wl[0].size(0)
+        gs = [torch.zeros(x2.size(0), Fo, dtype=torch.bfloat16, device=x2.device) if g is None
+              else g.contiguous().view(-1, Fo).to(torch.bfloat16) for g in gys]
+        gx = ops.linear_dgrad_group(gs, wl).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        gws, gbs = [], []
+        for g, (w, b) in zip(gs, ctx.params):
+            if ops.grad_sink_ok(w, b):
+                ops.linear_wgrad(x2, g, sink=(w.grad, b.grad))
+                gws.append(None)
+                gbs.append(None)
+            else:
+                gw, gb = ops.linear_wgrad(x2, g)
+                gws.append(gw.to(ctx.param_dtype))
+                gbs.append(gb.to(ctx.param_dtype))
+        return (gx, None, *gws, *gbs, *([None] * (2 * G)))
+
+
+def linear_group(x, layers):
+    """[layer(x) for layer in layers] for same-shape `Linear` layers sharing their input; under bf16 autocast with
+    many tokens the group runs as one forward and one input-gradient launch (libmivae), otherwise layer by layer."""
+    if (x.is_cuda and torch.is_grad_enabled() and torch.is_autocast_enabled() and len(layers) >= 2
+            and torch.get_autocast_dtype("cuda") == torch.bfloat16 and x.numel() // x.size(-1) >= 4096
+            and all(isinstance(l, Linear) and l.bias is not None for l in layers)
+            and all(l.out_features <= 128 and l.in_features <= 128 for l in layers)):
+        wl, bl = [], []
+        for l in layers:
+            w_lp = getattr(l.weight, "_mivae_lp", None)
+            b_lp = getattr(l.bias, "_mivae_lp", None)
+            wl.append(w_lp if w_lp is not None and w_lp.dtype == torch.bfloat16 else l.weight.detach().to(torch.bfloat16))
+            bl.append(b_lp if b_lp is not None and b_lp.dtype == torch.bfloat16 else l.bias.detach().to(torch.bfloat16))
+        x16 = x.to(torch.bfloat16)
+        if ops.linear_group_supported(x16, wl):
+            return list(_GroupLinearFn.apply(x16, len(layers), *[l.weight for l in layers], *[l.bias for l in layers],
+                                             *wl, *bl))
+    return [l(x) for l in layers]
+
+
 # ----------------------------------------------------------------------------------- activations
 def _gelu(x):
     return x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))   # erf GELU, nn/activation.py:16
@@ -211,9 +266,13 @@ class MultiHeadAttention(torch.nn.Module):
         return x.view(b, s, self._num_heads, self._attn_size).transpose(1, 2)
 
     def forward(self, query, key, value, mask=None):
-        q = self._split(self._projections["query"](query))
-        k = self._split(self._projections["key"](key))
-        v = self._split(self._projections["value"](value))
+        if query is key and key is value:        # self-attention: the three projections share their input
+            q, k, v = linear_group(query, [self._projections[n] for n in ("query", "key", "value")])
+            q, k, v = self._split(q), self._split(k), self._split(v)
+        else:
+            q = self._split(self._projections["query"](query))
+            k = self._split(self._projections["key"](key))
+            v = self._split(self._projections["value"](value))
         S = q.size(2)
         if (USE_FUSED_ATTENTION and q.is_cuda and q.dtype == torch.bfloat16 and torch.is_autocast_enabled()
                 and not (self.training and isinstance(self._dropout, torch.nn.Dropout) and self._dropout.p > 0)):

@@ -420,6 +420,18 @@ class _LayerNorm(torch.autograd.Function):
         ws = torch.empty(L.query("mivae_layernorm_workspace_floats", rows, D), dtype=torch.float32, device=x2.device)
         if grad_sink_ok(*ctx.params):
             gw, gb = ctx.params[0].grad, ctx.params[1].grad
+            key = (gw.data_ptr(), rows, -D)
+            if _DEFER is not None and key not in _DEFER:      # partials now, folded with the Linear ones after backward
+                wsp = _PART_BUFS.get(key)
+                if wsp is None or wsp.device != x2.device:
+                    wsp = _PART_BUFS[key] = torch.empty_like(ws)
+                nblk = L.query("mivae_layernorm_bwd_partial", L.ptr(dy2), L.ptr(x2), L.ptr(weight), L.ptr(stats[0]),
+                               L.ptr(stats[1]), L.ptr(dx), L.ptr(wsp), rows, D, L.dtype_code(x2.dtype),
+                               L.dtype_code(dy2.dtype), L.stream())
+                if nblk <= 0:
+                    raise RuntimeError(f"mivae_layernorm_bwd_partial failed ({nblk}): {L.lib().mivae_last_error().decode()}")
+                _DEFER[key] = (wsp[:nblk * 2 * D].view(nblk, 2 * D), gw, gb, D)
+                return dx.view(ctx.shape), None, None, None, None
             L.call("mivae_layernorm_bwd_sink", L.ptr(dy2), L.ptr(x2), L.ptr(weight), L.ptr(stats[0]), L.ptr(stats[1]),
                    L.ptr(dx), L.ptr(gw), L.ptr(gb), L.ptr(ws), rows, D, L.dtype_code(x2.dtype), L.dtype_code(dy2.dtype),
                    L.stream())
@@ -517,6 +529,37 @@ def linear_dgrad(g2, w16):
     Fi = w16.size(1)
     dx = torch.empty(N, Fi, dtype=torch.bfloat16, device=g2.device)
     L.call("mivae_linear_dgrad", L.ptr(g2), L.ptr(w16), L.ptr(dx), N, Fi, Fo, L.stream())
+    return dx
+
+
+def _ptr_array(tensors):
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+def linear_group_supported(x, weights) -> bool:
+    """2..4 same-shape layers on one input, each eligible for the MFMA small-Linear kernels, G * Fo <= 256."""
+    w0 = weights[0]
+    return bool(2 <= len(weights) <= 4 and all(w.shape == w0.shape for w in weights)
+                and all(linear_small_supported(x, w) for w in weights) and len(weights) * w0.size(0) <= 256)
+
+
+def linear_fwd_group(x2, ws16, bs16):
+    """[x2 w^T + b for (w, b) in the group] in one launch: q / k / v projections, mu / sigma heads (a3)."""
+    N, Fi = x2.shape
+    Fo = ws16[0].size(0)
+    ys = [torch.empty(N, Fo, dtype=torch.bfloat16, device=x2.device) for _ in ws16]
+    L.call("mivae_linear_fwd_group", L.ptr(x2), _ptr_array(ws16), _ptr_array(bs16), _ptr_array(ys), len(ws16), N, Fi, Fo,
+           L.stream())
+    return ys
+
+
+def linear_dgrad_group(gs, ws16):
+    """sum_g gs[g] @ ws16[g] as one contraction."""
+    N, Fo = gs[0].shape
+    Fi = ws16[0].size(1)
+    dx = torch.empty(N, Fi, dtype=torch.bfloat16, device=gs[0].device)
+    L.call("mivae_linear_dgrad_group", _ptr_array(gs), _ptr_array(ws16), L.ptr(dx), len(gs), N, Fi, Fo, L.stream())
     return dx
 
 

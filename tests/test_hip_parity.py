@@ -1011,3 +1011,50 @@ def test_flow_registry_builds_maf(M):
         assert type(f) is M.MAFlow
         assert sorted(f.state_dict()) == sorted(
             f"_made._nets.{i}.{n}" for i in (0, 2) for n in ("weight", "bias", "weight_mask"))
+
+
+# ------------------------------------------------------------------------------------ a3 / bracket: grouped Linear
+@pytest.mark.parametrize("N,Fi,Fo,G", [(4096, 64, 64, 3), (5000, 64, 64, 2), (4100, 32, 32, 4), (4096, 128, 64, 3),
+                                       (4096, 64, 128, 2)])
+def test_linear_group_kernels_vs_fp64(M, N, Fi, Fo, G):
+    """mivae_linear_fwd_group / mivae_linear_dgrad_group (q / k / v projections, posterior mu / sigma heads) vs fp64
+    products of the same bf16 operands; ragged last token tile."""
+    gen = torch.Generator().manual_seed(N + Fi + Fo + G)
+    x = dev(torch.randn(N, Fi, generator=gen).to(torch.bfloat16))
+    ws = [dev((torch.randn(Fo, Fi, generator=gen) * 0.2).to(torch.bfloat16)) for _ in range(G)]
+    bs = [dev(torch.randn(Fo, generator=gen).to(torch.bfloat16)) for _ in range(G)]
+    gs = [dev(torch.randn(N, Fo, generator=gen).to(torch.bfloat16)) for _ in range(G)]
+    assert M.ops.linear_group_supported(x, ws)
+    ys = M.ops.linear_fwd_group(x, ws, bs)
+    for y, w, b in zip(ys, ws, bs):
+        ref = x.double() @ w.double().t() + b.double()
+        assert rel_err(y.float(), ref) < 4e-3
+        assert torch.equal(y, M.ops.linear_fwd(x, w, b))          # same arithmetic as the single-layer entry point
+    dx = M.ops.linear_dgrad_group(gs, ws)
+    ref = sum(g.double() @ w.double() for g, w in zip(gs, ws))
+    assert rel_err(dx.float(), ref) < 4e-3
+
+
+def test_linear_group_module_matches_layerwise(M):
+    """nn_bracket.linear_group under bf16 autocast == the same layers applied one by one (outputs bit-identical,
+    input gradient within the bf16 rounding of one sum instead of G rounded terms, weight gradients identical)."""
+    torch.manual_seed(3)
+    layers = [M.nn_bracket.Linear(64, 64).to(DEV) for _ in range(3)]
+    x = torch.randn(64, 64, 64, device=DEV)
+    cot = [torch.randn(64, 64, 64, device=DEV) for _ in range(3)]
+    res = {}
+    for grouped in (True, False):
+        for l in layers:
+            l.zero_grad()
+        xg = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            ys = M.nn_bracket.linear_group(xg, layers) if grouped else [l(xg) for l in layers]
+            assert all(y.dtype == torch.bfloat16 for y in ys)
+            sum((y.float() * c).sum() for y, c in zip(ys, cot)).backward()
+        res[grouped] = ([y.detach().clone() for y in ys], xg.grad.clone(), [l.weight.grad.clone() for l in layers],
+                        [l.bias.grad.clone() for l in layers])
+    for a, b in zip(res[True][0], res[False][0]):
+        assert torch.equal(a, b)
+    assert rel_err(res[True][1], res[False][1]) < 8e-3
+    for a, b in zip(res[True][2] + res[True][3], res[False][2] + res[False][3]):
+        assert torch.equal(a, b)
