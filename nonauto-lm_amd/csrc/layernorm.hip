@@ -170,7 +170,7 @@ static bool ln_cfg(int64_t rows, int64_t D, bool vec4, LnCfg& c) {
   c.L = lanes_per_row(D, c.vec);
   if ((int64_t)c.L * c.vec * kMaxChunks < D) return false;
   const int rif = kBlock / c.L;
-  int64_t nblk = (rows + 63) / 64;
+  int64_t nblk = (rows + rif - 1) / rif;           // one pass of row groups per block while that fills <= 1024 blocks
   if (nblk > 1024) nblk = 1024;
   if (nblk < 1) nblk = 1;
   int64_t rpb = (rows + nblk - 1) / nblk;

@@ -5,9 +5,10 @@
 // hipBLASLt dispatches these (16384 x 64 x 64) products to a 256-workgroup 64x64 tiling at ~9 us per call; they
 // are 4 MB of HBM traffic.  Here a wave owns 32 tokens, keeps their features as MFMA B fragments in registers and
 // walks the output features in chunks of 32 (v_mfma_f32_32x32x16_bf16, fp32 accumulation, bf16 operands exactly
-// like the library path): one read of x, one write of y.  The weight gradient contracts over tokens: both operand
-// tiles are transposed through wave-private LDS ([feature][token]) so the fragments are 16-byte reads; every wave
-// dumps its partial (dW | db) and mivae_colsum folds the partials in fixed order (no atomics).
+// like the library path): one read of x, one write of y.  The weight gradient contracts over tokens: a block stages
+// 128 tokens of both operands row-major in LDS and reads the k = token fragments with the transposing LDS read
+// (ds_read_b64_tr_b16); every block dumps its partial (dW | db) and mivae_colsum(_sink_multi) folds the partials in
+// fixed order (no atomics).
 #include "common.hpp"
 
 using namespace mivae;
@@ -112,98 +113,89 @@ struct WgArgs {
   int Fo, Fi, tiles_per_wave;
 };
 
-constexpr int kTokPad = 40;   // staged row = 32 tokens + 8 pad (80 B: 16-byte aligned fragment reads)
+// ---- weight gradient: no LDS transpose writes, no cross-wave reduction -----------------------------------------
+// A block stages 128 tokens of dy and x ROW-major in LDS (coalesced 16-byte copies), and the MFMA fragments, which
+// need 8 consecutive TOKENS of one feature, come out of gfx950's transposing LDS read (ds_read_b64_tr_b16: per
+// 16-lane group a 4-row x 16-column block delivered column-major).  The 4 waves split the OUTPUT tiles of
+// dW (Fo x Fi) instead of the tokens, so every wave owns its accumulators outright and writes its part of the
+// block's partial row directly.  Row strides are padded to 16 (mod 64) banks: the transposed reads are conflict free.
+typedef __bf16 lin_bf16x4 __attribute__((__vector_size__(4 * sizeof(__bf16))));
+#define LIN_LDS __attribute__((address_space(3)))
 
-// MO = Fo / 32, NI = Fi / 32 accumulator tiles per wave
+// fragment f[j] = tile[tok0 + 8 hh + j][fbase + r32]   (A or B operand of v_mfma_f32_32x32x16_bf16, k = tokens)
+__device__ __forceinline__ lin_bf16x8 lin_tr_frag(const unsigned short* tile, int stride, int fbase, int tok0, int lane) {
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+  const unsigned short* a0 = tile + (tok0 + 8 * (g >> 1) + q) * stride + fbase + 16 * (g & 1) + 4 * p;
+  const lin_bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LIN_LDS lin_bf16x4*)(a0));
+  const lin_bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LIN_LDS lin_bf16x4*)(a0 + 4 * stride));
+  return __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+constexpr int kSlab = 128;    // tokens staged per block and pass
+
 template <int MO, int NI>
-__global__ __launch_bounds__(256) void k_lin_wgrad(WgArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];   // per wave: [Fo + Fi][kTokPad]
+__global__ __launch_bounds__(256) void k_lin_wgrad2(WgArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  constexpr int Fo = 32 * MO, Fi = 32 * NI;
+  constexpr int SG = Fo + (MO == 1 ? 0 : 32), SX = Fi + (NI == 1 ? 0 : 32);   // row strides (elements)
+  constexpr int T = MO * NI, TPW = (T + 3) / 4;
+  unsigned short* gt = lds;                       // [kSlab][SG] dy rows
+  unsigned short* xt = lds + kSlab * SG;          // [kSlab][SX] x rows
   const int lane = threadIdx.x & 63, r32 = lane & 31, hh = lane >> 5;
   const int wave = threadIdx.x >> 6;
-  constexpr int Fo = 32 * MO, Fi = 32 * NI;
-  unsigned short* gt = lds + wave * (Fo + Fi) * kTokPad;   // dy^T tile [Fo][kTokPad]
-  unsigned short* xt = gt + Fo * kTokPad;                  // x^T  tile [Fi][kTokPad]
-  const int64_t t0 = ((int64_t)blockIdx.x * 4 + wave) * a.tiles_per_wave;
-  f32x16 acc[MO][NI], accb[MO];
+  f32x16 acc[TPW], accb[TPW];
 #pragma unroll
-  for (int m = 0; m < MO; ++m) {
+  for (int i = 0; i < TPW; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) accb[m][r] = 0.f;
-#pragma unroll
-    for (int n = 0; n < NI; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-  }
+    for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; accb[i][r] = 0.f; }
   const u16x8 ones_raw = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
   const lin_bf16x8 ones = __builtin_bit_cast(lin_bf16x8, ones_raw);
-  const int64_t ntiles = (a.N + 31) / 32;
-  for (int i = 0; i < a.tiles_per_wave; ++i) {
-    const int64_t tile = t0 + i;
-    if (tile >= ntiles) break;                             // wave-uniform; no block barrier inside this loop
-    const int64_t tokb = tile * 32;
-    // stage both tiles transposed: each lane moves 16 B (8 features of one token) per step
-#pragma unroll 2
-    for (int g = lane; g < 32 * (Fo >> 3); g += 64) {
-      const int tk = g / (Fo >> 3), f8 = (g % (Fo >> 3)) * 8;
+  const int slabs = a.tiles_per_wave;             // 128-token slabs per block (= 4 waves x tiles_per_wave tiles)
+  for (int sl = 0; sl < slabs; ++sl) {
+    const int64_t tb = ((int64_t)blockIdx.x * slabs + sl) * kSlab;
+    if (tb >= a.N) break;                         // block-uniform
+    if (sl) __syncthreads();                      // the previous slab has been consumed
+    for (int idx = threadIdx.x; idx < kSlab * (Fo >> 3); idx += 256) {
+      const int tk = idx / (Fo >> 3), f8 = (idx % (Fo >> 3)) * 8;
       u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (tokb + tk < a.N) v = *reinterpret_cast<const u16x8*>(a.dy + (tokb + tk) * Fo + f8);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) gt[(f8 + e) * kTokPad + tk] = v[e];
+      if (tb + tk < a.N) v = *reinterpret_cast<const u16x8*>(a.dy + (tb + tk) * Fo + f8);
+      *reinterpret_cast<u16x8*>(gt + tk * SG + f8) = v;
     }
-#pragma unroll 2
-    for (int g = lane; g < 32 * (Fi >> 3); g += 64) {
-      const int tk = g / (Fi >> 3), f8 = (g % (Fi >> 3)) * 8;
+    for (int idx = threadIdx.x; idx < kSlab * (Fi >> 3); idx += 256) {
+      const int tk = idx / (Fi >> 3), f8 = (idx % (Fi >> 3)) * 8;
       u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (tokb + tk < a.N) v = *reinterpret_cast<const u16x8*>(a.x + (tokb + tk) * Fi + f8);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) xt[(f8 + e) * kTokPad + tk] = v[e];
+      if (tb + tk < a.N) v = *reinterpret_cast<const u16x8*>(a.x + (tb + tk) * Fi + f8);
+      *reinterpret_cast<u16x8*>(xt + tk * SX + f8) = v;
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {                          // 2 k-steps of 16 tokens
-      lin_bf16x8 af[MO], bf[NI];
-#pragma unroll
-      for (int m = 0; m < MO; ++m) af[m] = *reinterpret_cast<const lin_bf16x8*>(gt + (32 * m + r32) * kTokPad + 16 * s + 8 * hh);
-#pragma unroll
-      for (int n = 0; n < NI; ++n) bf[n] = *reinterpret_cast<const lin_bf16x8*>(xt + (32 * n + r32) * kTokPad + 16 * s + 8 * hh);
-#pragma unroll
-      for (int m = 0; m < MO; ++m) {
-        accb[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], ones, accb[m], 0, 0, 0);
-#pragma unroll
-        for (int n = 0; n < NI; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bf[n], acc[m][n], 0, 0, 0);
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-  }
-  // fold the block's 4 waves in wave order through LDS (the staging area is free now), then one coalesced dump:
-  // partial[block][row * Fi + col] (row = output feature, col = input feature), db at [Fo * Fi + row]
-  float* red = reinterpret_cast<float*>(lds);
-  for (int w = 0; w < 4; ++w) {
     __syncthreads();
-    if (wave != w) continue;
 #pragma unroll
-    for (int m = 0; m < MO; ++m) {
+    for (int i = 0; i < TPW; ++i) {
+      const int t = wave * TPW + i;
+      if (t >= T) continue;                       // wave-uniform: EXEC stays all ones around the transposed reads
+      const int m = t / NI, n = t - m * NI;
 #pragma unroll
-      for (int n = 0; n < NI; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float* q = red + (32 * m + lin_row(r, hh)) * Fi + 32 * n + r32;
-          *q = (w == 0 ? 0.f : *q) + acc[m][n][r];
-        }
-      if (r32 == 0) {                                      // every column of accb holds the row sums
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float* q = red + Fo * Fi + 32 * m + lin_row(r, hh);
-          *q = (w == 0 ? 0.f : *q) + accb[m][r];
-        }
+      for (int s = 0; s < kSlab / 16; ++s) {
+        const lin_bf16x8 af = lin_tr_frag(gt, SG, 32 * m, 16 * s, lane);
+        const lin_bf16x8 bf = lin_tr_frag(xt, SX, 32 * n, 16 * s, lane);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[i], 0, 0, 0);
+        if (n == 0) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ones, accb[i], 0, 0, 0);
       }
     }
   }
-  __syncthreads();
+  // partial[block][row * Fi + col] (row = output feature, col = input feature), db at [Fo * Fi + row]
   float* out = a.partial + (int64_t)blockIdx.x * ((int64_t)Fo * Fi + Fo);
-  for (int i = threadIdx.x; i < Fo * Fi + Fo; i += 256) out[i] = red[i];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int t = wave * TPW + i;
+    if (t >= T) continue;
+    const int m = t / NI, n = t - m * NI;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[(32 * m + lin_row(r, hh)) * Fi + 32 * n + r32] = acc[i][r];
+    if (n == 0 && r32 == 0) {                     // every column of accb holds the row sums
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out[Fo * Fi + 32 * m + lin_row(r, hh)] = accb[i][r];
+    }
+  }
 }
 
 bool lin_dim_ok(int64_t f) { return f == 32 || f == 64 || f == 128 || f == 256; }
@@ -337,13 +329,13 @@ extern "C" int mivae_linear_wgrad(const void* x, const void* dy, float* partial,
   int64_t P;
   wgrad_geom(N, a.tiles_per_wave, P);
   const unsigned grid = (unsigned)P;
-  const size_t lds = (size_t)4 * (Fo + Fi) * kTokPad * 2;   // >= (Fo * Fi + Fo) floats for every supported shape
+  const size_t lds = (size_t)kSlab * ((Fo + (Fo == 32 ? 0 : 32)) + (Fi + (Fi == 32 ? 0 : 32))) * 2;
   hipStream_t st = S_(stream);
 #define WG(MO, NI)                                                                                         \
   do {                                                                                                     \
     if (lds > 64 * 1024)                                                                                   \
-      (void)hipFuncSetAttribute((const void*)k_lin_wgrad<MO, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    k_lin_wgrad<MO, NI><<<grid, 256, lds, st>>>(a);                                                        \
+      (void)hipFuncSetAttribute((const void*)k_lin_wgrad2<MO, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    k_lin_wgrad2<MO, NI><<<grid, 256, lds, st>>>(a);                                                       \
   } while (0)
   const int mo = (int)Fo / 32, ni = (int)Fi / 32;
   if (mo == 1 && ni == 1) WG(1, 1); else if (mo == 1 && ni == 2) WG(1, 2); else if (mo == 1 && ni == 4) WG(1, 4);
