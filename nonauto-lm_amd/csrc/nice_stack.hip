@@ -903,7 +903,8 @@ __global__ void __launch_bounds__(LB) k_stack_bwd(StackArgs a) {
         // ---- affine chain, reversed: x1 is the step's saved input half
         const float* b2 = reinterpret_cast<const float*>(buf + tbb - kTailBytes) + 32;
         f32x16 x1[HT];
-        load_acc<T, VEC, HT>(reinterpret_cast<const T*>(a.x1_hist) + ((int64_t)k * a.N + tok) * h, valid, h, hh, x1);
+        // masked tokens read as zeros: the forward does not write the history of all-padding tiles
+        load_acc<T, VEC, HT>(reinterpret_cast<const T*>(a.x1_hist) + ((int64_t)k * a.N + tok) * h, valid && m != 0.f, h, hh, x1);
 #pragma unroll
         for (int t = 0; t < HT; ++t) {
           const f32x16 bt = bias_tile(b2 + 32 * t, hh);

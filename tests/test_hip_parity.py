@@ -871,6 +871,9 @@ def test_grad_sink_matches_autograd_accumulation(M):
     eps = torch.randn(64, 1, 64, 64, device=DEV)
     grads = {}
     for sink in (False, True, "deferred"):       # deferred: one mivae_colsum_sink_multi launch after backward
+        junk = [torch.full((1 << 20,), float("nan"), device=DEV) for _ in range(128)]   # poison the free blocks: a read
+        junk += [torch.full((n,), float("nan"), device=DEV) for n in (512, 8320, 16384, 131072) for _ in range(16)]
+        del junk                                  # of unwritten memory (ragged batch: padding tiles) turns up as NaN
         reducer.zero_grad()
         M.ops.GRAD_SINK = bool(sink)
         if sink == "deferred":
@@ -886,7 +889,7 @@ def test_grad_sink_matches_autograd_accumulation(M):
             M.ops.GRAD_SINK = False
             M.ops._DEFER = None
         grads[sink] = [b.clone() for b in reducer.buckets]
-    assert any(float(b.abs().max()) > 0 for b in grads[True])
+    assert any(float(b.abs().max()) > 0 for b in grads[True]), [[float(b.abs().max()) for b in g] for g in grads.values()]
     for a, b, c in zip(grads[False], grads[True], grads["deferred"]):
         assert torch.equal(a, b) and torch.equal(a, c)
 
@@ -1058,3 +1061,30 @@ def test_linear_group_module_matches_layerwise(M):
     assert rel_err(res[True][1], res[False][1]) < 8e-3
     for a, b in zip(res[True][2] + res[True][3], res[False][2] + res[False][3]):
         assert torch.equal(a, b)
+
+
+def test_nice_stack_padding_tiles_with_poisoned_memory(M):
+    """Regression: 32-token tiles that are all padding are skipped by the fused forward (their activation history is
+    never written); the backward must not read it.  Fresh allocations are poisoned with NaN first, so any read of
+    unwritten memory shows up as a non-finite gradient."""
+    g = load_golden("nice_d64_ragged")
+    D = g["z0"].shape[-1]
+    prior = build_flow_prior(M, g, D)
+    gen = torch.Generator().manual_seed(2)
+    B, S = 8, 64
+    z0 = torch.randn(B, S, D, generator=gen)
+    lens = torch.tensor([64, 1, 20, 32, 33, 5, 64, 2])            # rows with one or more all-padding 32-token tiles
+    mask = (torch.arange(S)[None, :] < lens[:, None]).to(torch.int64)
+    zo = z0.clone().requires_grad_(True)
+    zK_o, logp_o = O.flow_prior_forward(zo, O.nice_steps(nice_oracle_params(g)), mask)
+    cz, cl = torch.randn(B, S, D, generator=gen), torch.randn(B, generator=gen)
+    ((zK_o * cz).sum() + (logp_o * cl).sum()).backward()
+    junk = [torch.full((1 << 18,), float("nan"), device=DEV) for _ in range(64)]
+    junk += [torch.full((n,), float("nan"), device=DEV) for n in (512, 4096, 16384, 32768, 65536) for _ in range(16)]
+    del junk
+    zd = dev(z0).requires_grad_(True)
+    zK, logp = prior.forward_pass(zd, dev(mask))
+    ((zK * dev(cz)).sum() + (logp * dev(cl)).sum()).backward()
+    assert torch.isfinite(zd.grad).all() and all(torch.isfinite(p.grad).all() for p in prior.parameters())
+    assert rel_err(zK, zK_o) < 2e-5 and rel_err(logp, logp_o) < 2e-5
+    assert rel_err(zd.grad, zo.grad) < GTOL
