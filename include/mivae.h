@@ -261,6 +261,15 @@ int mivae_linear_fwd_group(const void* x, const void* const* w, const void* cons
                            int64_t N, int64_t Fi, int64_t Fo, void* stream);
 int mivae_linear_dgrad_group(const void* const* dy, const void* const* w, void* dx, int64_t G, int64_t N, int64_t Fi,
                              int64_t Fo, void* stream);
+/* Pre-norm feed-forward sublayer forward in ONE launch: y = x + W2 relu(W1 LN(x) + b1) + b2 over (N, D) token rows --
+ * SublayerConnection (nn/transformer.py:147-162) around PositionwiseFeedForward (:120-144) with inactive dropout, in
+ * the transformer bracket and the attention coupling (row a11).  x / y fp32 (x_dtype 0) or bf16 (1); gamma / beta fp32;
+ * w1 (H, D), b1 (H), w2 (D, H), b2 (D) bf16.  Written for the backward pass: xn = LN(x) (N, D) bf16, hmid = relu(.)
+ * (N, H) bf16, mean / rstd (N) fp32; the backward is mivae_linear_dgrad / _wgrad + mivae_layernorm_bwd*.
+ * D in {64, 128}, H in {128, 256}, else MIVAE_EUNSUPPORTED (-3). */
+int mivae_ffn_fwd(const void* x, const float* gamma, const float* beta, const void* w1, const void* b1, const void* w2,
+                  const void* b2, void* y, void* xn, void* hmid, float* mean, float* rstd, int64_t N, int64_t D,
+                  int64_t H, float eps, int x_dtype, void* stream);
 int64_t mivae_linear_wgrad_rows(int64_t N);
 int mivae_linear_wgrad(const void* x, const void* dy, float* partial, int64_t N, int64_t Fi, int64_t Fo,
                        void* stream);

@@ -198,6 +198,129 @@ __global__ __launch_bounds__(256) void k_lin_wgrad2(WgArgs a) {
   }
 }
 
+// ---- pre-norm feed-forward sublayer, forward, in one launch ----------------------------------------------------
+// y = x + W2 relu(W1 LN(x) + b1) + b2   (nn/transformer.py:147-162 SublayerConnection around :120-144
+// PositionwiseFeedForward; dropout inactive).  Everything is per token: a wave owns 32 tokens, normalises its rows in
+// registers (two half-rows per token on lanes l and l + 32), runs W1 on the matrix cores, applies bias + relu on the
+// accumulator tiles and feeds them straight back as the B operand of the W2 product (the accumulator layout IS a
+// B-fragment layout for a permuted contraction index; W2's fragments are read with the same permutation), then adds
+// the residual.  No LDS, no barriers.  The LayerNorm output, its statistics and the relu output are written once for
+// the backward pass.  Intermediate roundings match the layer-by-layer path (bf16 after LN, after W1 and after W2).
+struct FfnArgs {
+  const void* x;                    // (N, D) fp32 or bf16 residual stream
+  const float *gamma, *beta;        // (D)
+  const unsigned short *w1, *b1;    // (H, D), (H) bf16
+  const unsigned short *w2, *b2;    // (D, H), (D) bf16
+  void* y;                          // (N, D), dtype of x
+  unsigned short* xn;               // (N, D) bf16: LN(x)
+  unsigned short* hmid;             // (N, H) bf16: relu(W1 xn + b1)
+  float *mean, *rstd;               // (N)
+  int64_t N;
+  float eps;
+};
+
+template <typename TI, int ND, int NH>   // D = 16 ND, H = 32 NH
+__global__ __launch_bounds__(256) void k_ffn_fwd(FfnArgs a) {
+  constexpr int D = 16 * ND, H = 32 * NH, MD = D / 32;
+  const int lane = threadIdx.x & 63, r32 = lane & 31, hh = lane >> 5;
+  const int64_t tok0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;
+  if (tok0 >= a.N) return;                                  // wave-uniform
+  const int64_t tok = tok0 + r32;
+  const bool valid = tok < a.N;
+  const TI* xrow = static_cast<const TI*>(a.x) + (valid ? tok : 0) * D;
+  // half-row in B-fragment order: k-step ks holds features 16 ks + 8 hh + j
+  float xv[ND][8];
+  float s = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < ND; ++ks) {
+    if (sizeof(TI) == 4) {
+      float t0[4], t1[4];
+      RowIO<float, 4>::load(reinterpret_cast<const float*>(xrow) + 16 * ks + 8 * hh, t0);
+      RowIO<float, 4>::load(reinterpret_cast<const float*>(xrow) + 16 * ks + 8 * hh + 4, t1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { xv[ks][j] = t0[j]; xv[ks][4 + j] = t1[j]; }
+    } else {
+      RowIO<unsigned short, 8>::load(reinterpret_cast<const unsigned short*>(xrow) + 16 * ks + 8 * hh, xv[ks]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += xv[ks][j];
+  }
+  s += __shfl_xor(s, 32, 64);
+  const float mean = s / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < ND; ++ks)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float d = xv[ks][j] - mean; q += d * d; }
+  q += __shfl_xor(q, 32, 64);
+  const float rstd = rsqrtf(q / (float)D + a.eps);
+  if (valid && hh == 0) { a.mean[tok] = mean; a.rstd[tok] = rstd; }
+  lin_bf16x8 xf[ND];
+#pragma unroll
+  for (int ks = 0; ks < ND; ++ks) {
+    u16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int f = 16 * ks + 8 * hh + j;
+      o[j] = f32_to_bf16(fmaf((xv[ks][j] - mean) * rstd, a.gamma[f], a.beta[f]));
+    }
+    xf[ks] = __builtin_bit_cast(lin_bf16x8, o);
+    if (valid) *reinterpret_cast<u16x8*>(a.xn + tok * D + 16 * ks + 8 * hh) = o;
+  }
+  // stage 1: hidden^T (H x 32 tokens) = W1 xn^T + b1, relu, bf16
+  u16x4 hb[NH][4];
+#pragma unroll
+  for (int t = 0; t < NH; ++t) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = bf16_to_f32(a.b1[32 * t + lin_row(r, hh)]);
+#pragma unroll
+    for (int ks = 0; ks < ND; ++ks) {
+      const lin_bf16x8 wf = *reinterpret_cast<const lin_bf16x8*>(a.w1 + (int64_t)(32 * t + r32) * D + 16 * ks + 8 * hh);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[ks], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const u16x4 o = {f32_to_bf16(fmaxf(acc[4 * g], 0.f)), f32_to_bf16(fmaxf(acc[4 * g + 1], 0.f)),
+                       f32_to_bf16(fmaxf(acc[4 * g + 2], 0.f)), f32_to_bf16(fmaxf(acc[4 * g + 3], 0.f))};
+      hb[t][g] = o;
+      if (valid) *reinterpret_cast<u16x4*>(a.hmid + tok * H + 32 * t + 8 * g + 4 * hh) = o;
+    }
+  }
+  // stage 2: out^T (D x 32 tokens) = W2 hidden^T + b2; contraction slot j of k-step s2 of hidden tile t is hidden
+  // unit 32 t + 16 s2 + 8 (j >> 2) + 4 hh + (j & 3): what the accumulator registers of stage 1 hold
+#pragma unroll
+  for (int m = 0; m < MD; ++m) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = bf16_to_f32(a.b2[32 * m + lin_row(r, hh)]);
+#pragma unroll
+    for (int t = 0; t < NH; ++t)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const unsigned short* wp = a.w2 + (int64_t)(32 * m + r32) * H + 32 * t + 16 * s2 + 4 * hh;
+        const u16x4 w0 = *reinterpret_cast<const u16x4*>(wp), w1v = *reinterpret_cast<const u16x4*>(wp + 8);
+        const u16x8 araw = {w0[0], w0[1], w0[2], w0[3], w1v[0], w1v[1], w1v[2], w1v[3]};
+        const u16x8 braw = {hb[t][2 * s2][0], hb[t][2 * s2][1], hb[t][2 * s2][2], hb[t][2 * s2][3],
+                            hb[t][2 * s2 + 1][0], hb[t][2 * s2 + 1][1], hb[t][2 * s2 + 1][2], hb[t][2 * s2 + 1][3]};
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(lin_bf16x8, araw),
+                                                      __builtin_bit_cast(lin_bf16x8, braw), acc, 0, 0, 0);
+      }
+    if (valid) {
+      TI* yrow = static_cast<TI*>(a.y) + tok * D;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int f = 32 * m + 8 * g + 4 * hh;
+        float xr[4], o[4];
+        RowIO<TI, 4>::load(xrow + f, xr);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = xr[i] + bf16_to_f32(f32_to_bf16(acc[4 * g + i]));   // W2 output is bf16
+        RowIO<TI, 4>::store(yrow + f, o);
+      }
+    }
+  }
+}
+
 bool lin_dim_ok(int64_t f) { return f == 32 || f == 64 || f == 128 || f == 256; }
 
 // K = contraction length (fwd: Fi; dgrad: G * Fo), M = output features per layer, units = 32-wide output chunks
@@ -343,5 +466,39 @@ extern "C" int mivae_linear_wgrad(const void* x, const void* dy, float* partial,
   else if (mo == 4 && ni == 1) WG(4, 1); else if (mo == 4 && ni == 2) WG(4, 2); else WG(4, 4);
 #undef WG
   MIVAE_CHECK_LAUNCH("linear_wgrad");
+  return MIVAE_OK;
+}
+
+// y = x + W2 relu(W1 LN(x) + b1) + b2 for (N, D) rows in one launch (pre-norm feed-forward sublayer forward);
+// x / y fp32 (x_dtype 0) or bf16 (1); gamma / beta fp32; w1 (H, D), b1 (H), w2 (D, H), b2 (D) bf16.  Also written for
+// the backward pass: xn = LN(x) (N, D) bf16, hmid = relu(W1 xn + b1) (N, H) bf16, mean / rstd (N) fp32.
+// Supported: D in {64, 128}, H in {128, 256}; MIVAE_EUNSUPPORTED otherwise.
+extern "C" int mivae_ffn_fwd(const void* x, const float* gamma, const float* beta, const void* w1, const void* b1,
+                             const void* w2, const void* b2, void* y, void* xn, void* hmid, float* mean, float* rstd,
+                             int64_t N, int64_t D, int64_t H, float eps, int x_dtype, void* stream) {
+  MIVAE_REQUIRE(N >= 0 && N < (1ll << 31), "ffn_fwd: bad N");
+  MIVAE_REQUIRE(x_dtype == MIVAE_F32 || x_dtype == MIVAE_BF16, "ffn_fwd: x dtype must be f32 or bf16");
+  if (!((D == 64 || D == 128) && (H == 128 || H == 256))) {
+    mivae_set_error("ffn_fwd: unsupported shape D=%lld H=%lld (D in {64, 128}, H in {128, 256})", (long long)D, (long long)H);
+    return MIVAE_EUNSUPPORTED;
+  }
+  if (N == 0) return MIVAE_OK;
+  MIVAE_REQUIRE(x && gamma && beta && w1 && b1 && w2 && b2 && y && xn && hmid && mean && rstd, "ffn_fwd: null pointer");
+  MIVAE_REQUIRE(aligned16(x) && aligned16(w1) && aligned16(w2) && aligned16(y) && aligned16(xn) && aligned16(hmid),
+                "ffn_fwd: operands must be 16-byte aligned");
+  FfnArgs a = {x, gamma, beta, (const unsigned short*)w1, (const unsigned short*)b1, (const unsigned short*)w2,
+               (const unsigned short*)b2, y, (unsigned short*)xn, (unsigned short*)hmid, mean, rstd, N, eps};
+  const unsigned grid = (unsigned)(((N + 31) / 32 + 3) / 4);
+  hipStream_t st = S_(stream);
+#define FFN(TI, ND, NH) k_ffn_fwd<TI, ND, NH><<<grid, 256, 0, st>>>(a)
+  if (x_dtype == MIVAE_F32) {
+    if (D == 64 && H == 128) FFN(float, 4, 4); else if (D == 64) FFN(float, 4, 8);
+    else if (H == 128) FFN(float, 8, 4); else FFN(float, 8, 8);
+  } else {
+    if (D == 64 && H == 128) FFN(unsigned short, 4, 4); else if (D == 64) FFN(unsigned short, 4, 8);
+    else if (H == 128) FFN(unsigned short, 8, 4); else FFN(unsigned short, 8, 8);
+  }
+#undef FFN
+  MIVAE_CHECK_LAUNCH("ffn_fwd");
   return MIVAE_OK;
 }

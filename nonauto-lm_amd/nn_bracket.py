@@ -165,6 +165,65 @@ def linear_group(x, layers):
     return [l(x) for l in layers]
 
 
+def _lp(p):
+    """bf16 compute copy of an fp32 parameter: the shadow dp.FusedAdam keeps, else a cast."""
+    q = getattr(p, "_mivae_lp", None)
+    return q if q is not None and q.dtype == torch.bfloat16 else p.detach().to(torch.bfloat16)
+
+
+class _FfnBlockFn(torch.autograd.Function):
+    """x + W2 relu(W1 LN(x) + b1) + b2 (pre-norm feed-forward sublayer): forward in one libmivae launch; backward on
+    the small-Linear / LayerNorm kernels with the tensors the forward saved (no recomputation)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, w1, b1, w2, b2, eps):
+        x2 = x.contiguous().view(-1, x.size(-1))
+        w1l, b1l, w2l, b2l = _lp(w1), _lp(b1), _lp(w2), _lp(b2)
+        y, xn, hmid, stats = ops.ffn_fwd(x2, gamma, beta, w1l, b1l, w2l, b2l, eps)
+        ctx.save_for_backward(x2, gamma, xn, hmid, stats, w1l, w2l)
+        ctx.params = (gamma, beta, w1, b1, w2, b2)
+        ctx.xshape = x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, gamma, xn, hmid, stats, w1l, w2l = ctx.saved_tensors
+        g, be, w1, b1, w2, b2 = ctx.params
+        dy2 = dy.contiguous().view(-1, dy.size(-1))
+        dy16 = dy2 if dy2.dtype == torch.bfloat16 else dy2.to(torch.bfloat16)
+        dh = ops.linear_dgrad(dy16, w2l)                                   # (N, H)
+        dh = torch.ops.aten.threshold_backward(dh, hmid, 0)                # relu'
+        grads = {}
+        for name, (xin, gout, w, b) in (("2", (hmid, dy16, w2, b2)), ("1", (xn, dh, w1, b1))):
+            small = w.size(0) <= 128 and w.size(1) <= 128
+            if small and ops.grad_sink_ok(w, b):
+                ops.linear_wgrad(xin, gout, sink=(w.grad, b.grad))
+                grads[name] = (None, None)
+            elif small:
+                gw, gb = ops.linear_wgrad(xin, gout)
+                grads[name] = (gw.to(w.dtype), gb.to(b.dtype))
+            else:                                                          # wide layer: library products
+                grads[name] = (gout.t().matmul(xin).to(w.dtype), ops.colsum(gout).to(b.dtype))
+        dxn = ops.linear_dgrad(dh, w1l)
+        dx, gg, gb_ = ops.layer_norm_bwd(dxn, x2, gamma, stats, (g, be))
+        dx = (dx + dy2.to(dx.dtype)).view(ctx.xshape)
+        return dx, gg, gb_, grads["1"][0], grads["1"][1], grads["2"][0], grads["2"][1], None
+
+
+def ffn_block_supported(x, norm, ffn, sub) -> bool:
+    """bf16-autocast training bracket, inactive dropout, shapes the fused forward is instantiated for."""
+    def off(d):
+        return not isinstance(d, torch.nn.Dropout) or d.p == 0 or not d.training
+    D = x.size(-1)
+    return bool(x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and torch.is_autocast_enabled()
+                and torch.get_autocast_dtype("cuda") == torch.bfloat16 and x.numel() // D >= 4096
+                and isinstance(norm, LayerNorm) and norm.elementwise_affine and norm.bias is not None
+                and norm.weight.dtype == torch.float32 and tuple(norm.normalized_shape) == (D,)
+                and (D, ffn._w_1.out_features) in ops.FFN_DIMS and ffn._w_1.in_features == D
+                and ffn._w_2.out_features == D and ffn._w_1.bias is not None and ffn._w_2.bias is not None
+                and off(ffn._dropout) and off(sub._dropout))
+
+
 # ----------------------------------------------------------------------------------- activations
 def _gelu(x):
     return x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))   # erf GELU, nn/activation.py:16
@@ -240,6 +299,7 @@ def _maybe_dropout(p):
 # the explicit masked-softmax path, e.g. to profile a HIP-graph replayed step with rocprofv3, which aborts on the
 # graph-captured library attention kernel on ROCm 7.2)
 USE_FUSED_ATTENTION = os.environ.get("MIVAE_NO_SDPA", "0") != "1"
+USE_FUSED_FFN = True     # pre-norm feed-forward sublayer forward in one libmivae launch (bf16 autocast)
 
 
 class MultiHeadAttention(torch.nn.Module):
@@ -365,7 +425,12 @@ class _TransformerLayer(torch.nn.Module):
 
     def forward(self, x, mask):
         x = self._sublayers["attn"](x, lambda y: self._attn(y, y, y, mask))
-        return self._sublayers["pos_ffn"](x, self._pos_ffn)
+        sub = self._sublayers["pos_ffn"]
+        if USE_FUSED_FFN and ffn_block_supported(x, sub._norm, self._pos_ffn, sub):
+            f = self._pos_ffn
+            return _FfnBlockFn.apply(x, sub._norm.weight, sub._norm.bias, f._w_1.weight, f._w_1.bias, f._w_2.weight,
+                                     f._w_2.bias, sub._norm.eps)
+        return sub(x, self._pos_ffn)
 
 
 class TransformerEncoderLayer(_TransformerLayer):

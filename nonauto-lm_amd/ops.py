@@ -415,31 +415,56 @@ class _LayerNorm(torch.autograd.Function):
     def backward(ctx, dy):
         x2, weight, stats = ctx.saved_tensors
         rows, D = x2.shape
-        dy2 = dy.contiguous().view(rows, D)
-        dx = torch.empty_like(x2)
-        ws = torch.empty(L.query("mivae_layernorm_workspace_floats", rows, D), dtype=torch.float32, device=x2.device)
-        if grad_sink_ok(*ctx.params):
-            gw, gb = ctx.params[0].grad, ctx.params[1].grad
-            key = (gw.data_ptr(), rows, -D)
-            if _DEFER is not None and key not in _DEFER:      # partials now, folded with the Linear ones after backward
-                wsp = _PART_BUFS.get(key)
-                if wsp is None or wsp.device != x2.device:
-                    wsp = _PART_BUFS[key] = torch.empty_like(ws)
-                nblk = L.query("mivae_layernorm_bwd_partial", L.ptr(dy2), L.ptr(x2), L.ptr(weight), L.ptr(stats[0]),
-                               L.ptr(stats[1]), L.ptr(dx), L.ptr(wsp), rows, D, L.dtype_code(x2.dtype),
-                               L.dtype_code(dy2.dtype), L.stream())
-                if nblk <= 0:
-                    raise RuntimeError(f"mivae_layernorm_bwd_partial failed ({nblk}): {L.lib().mivae_last_error().decode()}")
-                _DEFER[key] = (wsp[:nblk * 2 * D].view(nblk, 2 * D), gw, gb, D)
-                return dx.view(ctx.shape), None, None, None, None
-            L.call("mivae_layernorm_bwd_sink", L.ptr(dy2), L.ptr(x2), L.ptr(weight), L.ptr(stats[0]), L.ptr(stats[1]),
-                   L.ptr(dx), L.ptr(gw), L.ptr(gb), L.ptr(ws), rows, D, L.dtype_code(x2.dtype), L.dtype_code(dy2.dtype),
-                   L.stream())
-            return dx.view(ctx.shape), None, None, None, None
-        dgb = torch.empty(2, D, dtype=torch.float32, device=x2.device)
-        L.call("mivae_layernorm_bwd", L.ptr(dy2), L.ptr(x2), L.ptr(weight), L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(dx),
-               L.ptr(dgb), L.ptr(ws), rows, D, L.dtype_code(x2.dtype), L.dtype_code(dy2.dtype), L.stream())
-        return dx.view(ctx.shape), dgb[0], dgb[1], None, None
+        dx, gw, gb = layer_norm_bwd(dy.contiguous().view(rows, D), x2, weight, stats, ctx.params)
+        return dx.view(ctx.shape), gw, gb, None, None
+
+
+def layer_norm_bwd(dy2, x2, weight, stats, params):
+    """(dx, d gamma, d beta) of layer_norm for dy2, x2 (rows, D); with gradient sinks active the parameter gradients
+    go straight into params' .grad (deferred: folded by flush_grad_sinks) and None is returned for them."""
+    rows, D = x2.shape
+    dx = torch.empty_like(x2)
+    ws = torch.empty(L.query("mivae_layernorm_workspace_floats", rows, D), dtype=torch.float32, device=x2.device)
+    if grad_sink_ok(*params):
+        gw, gb = params[0].grad, params[1].grad
+        key = (gw.data_ptr(), rows, -D)
+        if _DEFER is not None and key not in _DEFER:      # partials now, folded with the Linear ones after backward
+            wsp = _PART_BUFS.get(key)
+            if wsp is None or wsp.device != x2.device:
+                wsp = _PART_BUFS[key] = torch.empty_like(ws)
+            nblk = L.query("mivae_layernorm_bwd_partial", L.ptr(dy2), L.ptr(x2), L.ptr(weight), L.ptr(stats[0]),
+                           L.ptr(stats[1]), L.ptr(dx), L.ptr(wsp), rows, D, L.dtype_code(x2.dtype),
+                           L.dtype_code(dy2.dtype), L.stream())
+            if nblk <= 0:
+                raise RuntimeError(f"mivae_layernorm_bwd_partial failed ({nblk}): {L.lib().mivae_last_error().decode()}")
+            _DEFER[key] = (wsp[:nblk * 2 * D].view(nblk, 2 * D), gw, gb, D)
+            return dx, None, None
+        L.call("mivae_layernorm_bwd_sink", L.ptr(dy2), L.ptr(x2), L.ptr(weight), L.ptr(stats[0]), L.ptr(stats[1]),
+               L.ptr(dx), L.ptr(gw), L.ptr(gb), L.ptr(ws), rows, D, L.dtype_code(x2.dtype), L.dtype_code(dy2.dtype),
+               L.stream())
+        return dx, None, None
+    dgb = torch.empty(2, D, dtype=torch.float32, device=x2.device)
+    L.call("mivae_layernorm_bwd", L.ptr(dy2), L.ptr(x2), L.ptr(weight), L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(dx),
+           L.ptr(dgb), L.ptr(ws), rows, D, L.dtype_code(x2.dtype), L.dtype_code(dy2.dtype), L.stream())
+    return dx, dgb[0], dgb[1]
+
+
+FFN_DIMS = ((64, 128), (64, 256), (128, 128), (128, 256))
+
+
+def ffn_fwd(x2, gamma, beta, w1, b1, w2, b2, eps: float):
+    """y = x + W2 relu(W1 LN(x) + b1) + b2 in one launch (pre-norm feed-forward sublayer, nn/transformer.py:120-162);
+    returns (y, xn, hmid, stats) with the tensors the backward needs.  x2 (N, D) fp32 / bf16; w*, b* bf16."""
+    N, D = x2.shape
+    H = w1.size(0)
+    y = torch.empty_like(x2)
+    xn = torch.empty(N, D, dtype=torch.bfloat16, device=x2.device)
+    hmid = torch.empty(N, H, dtype=torch.bfloat16, device=x2.device)
+    stats = torch.empty(2, N, dtype=torch.float32, device=x2.device)
+    L.call("mivae_ffn_fwd", L.ptr(x2), L.ptr(gamma), L.ptr(beta), L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2), L.ptr(y),
+           L.ptr(xn), L.ptr(hmid), L.ptr(stats[0]), L.ptr(stats[1]), N, D, H, float(eps), L.dtype_code(x2.dtype),
+           L.stream())
+    return y, xn, hmid, stats
 
 
 LAYERNORM_MAX_D = 1024

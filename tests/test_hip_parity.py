@@ -1088,3 +1088,49 @@ def test_nice_stack_padding_tiles_with_poisoned_memory(M):
     assert torch.isfinite(zd.grad).all() and all(torch.isfinite(p.grad).all() for p in prior.parameters())
     assert rel_err(zK, zK_o) < 2e-5 and rel_err(logp, logp_o) < 2e-5
     assert rel_err(zd.grad, zo.grad) < GTOL
+
+
+@pytest.mark.parametrize("D,H,xdt", [(64, 128, torch.float32), (64, 128, torch.bfloat16), (128, 256, torch.float32),
+                                     (64, 256, torch.bfloat16), (128, 128, torch.float32)])
+def test_ffn_block_fused_forward_vs_fp64_and_layerwise(M, D, H, xdt):
+    """mivae_ffn_fwd (x + W2 relu(W1 LN(x) + b1) + b2 in one launch) vs an fp64 evaluation with the same bf16
+    rounding points, and the whole sublayer (forward + every gradient) vs the layer-by-layer path."""
+    nb = M.nn_bracket
+    torch.manual_seed(D + H)
+    layer = nb.TransformerEncoderLayer(D, H, 4).to(DEV).train()
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    B, S = 70, 64                                                    # 4480 tokens, ragged last tile
+    x = torch.randn(B, S, D, device=DEV).to(xdt)
+    sub, f = layer._sublayers["pos_ffn"], layer._pos_ffn
+    # kernel alone vs fp64 with the same rounding points
+    bf = lambda t: t.to(torch.bfloat16)
+    y, xn, hmid, stats = M.ops.ffn_fwd(x.view(-1, D), sub._norm.weight, sub._norm.bias, bf(f._w_1.weight), bf(f._w_1.bias),
+                                        bf(f._w_2.weight), bf(f._w_2.bias), sub._norm.eps)
+    xd = x.view(-1, D).double()
+    ref_n = torch.nn.functional.layer_norm(xd, (D,), sub._norm.weight.double(), sub._norm.bias.double(), sub._norm.eps)
+    assert rel_err(xn.float(), ref_n) < 4e-3
+    hd = torch.relu(xn.double() @ bf(f._w_1.weight).double().t() + bf(f._w_1.bias).double())
+    assert rel_err(hmid.float(), hd) < 4e-3
+    od = bf(hmid.double() @ bf(f._w_2.weight).double().t() + bf(f._w_2.bias).double()).double()
+    assert rel_err(y.float(), xd + od) < (4e-3 if xdt == torch.bfloat16 else 2e-3)
+    # module: fused vs layer by layer
+    cot = torch.randn(B, S, D, device=DEV)
+    res = {}
+    for fused in (True, False):
+        nb.USE_FUSED_FFN = fused
+        try:
+            layer.zero_grad()
+            xg = x.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = layer(xg, torch.ones(B, S, dtype=torch.int64, device=DEV))
+            (out.float() * cot).sum().backward()
+        finally:
+            nb.USE_FUSED_FFN = True
+        res[fused] = (out.detach().float(), xg.grad.float(), {k: p.grad.clone() for k, p in layer.named_parameters()})
+    assert rel_err(res[True][0], res[False][0]) < 8e-3 and rel_err(res[True][1], res[False][1]) < 2e-2
+    for k in res[True][2]:
+        if k.endswith("key.bias"):          # softmax is invariant to the key bias: its gradient is rounding noise
+            continue
+        assert rel_err(res[True][2][k], res[False][2][k]) < 2e-2, k
