@@ -780,7 +780,20 @@ class _LinearNLL(torch.autograd.Function):
         if ctx.needs_input_grad[1] and want_db:
             # one dense product for both: d W = dl^T h and d b = dl^T 1 (a ones block appended to h)
             h_aug = torch.cat([h2, torch.ones(h2.size(0), 8, dtype=h2.dtype, device=h2.device)], dim=1)
-            dwa = dl.t().matmul(h_aug)
+            n = h2.size(0)
+            G = 8 if (n % 8 == 0 and n // 8 >= 1024) else (4 if (n % 4 == 0 and n // 4 >= 1024) else 1)
+            dwa = None
+            if G > 1:
+                # the token axis is the contraction: one (V, E + 8) output tile per workgroup walks all N tokens in the
+                # library's single GEMM (102 us at C2); split into G batches with fp32 partials, folded in fixed order
+                try:
+                    part = torch.bmm(dl.view(G, n // G, V).transpose(1, 2), h_aug.view(G, n // G, E + 8),
+                                     out_dtype=torch.float32)
+                    dwa = colsum(part.view(G, -1)).view(V, E + 8)
+                except (TypeError, RuntimeError):
+                    dwa = None
+            if dwa is None:
+                dwa = dl.t().matmul(h_aug)
             dw, db = dwa[:, :E].to(wdtype), dwa[:, E].to(wdtype)
         elif ctx.needs_input_grad[1]:
             dw = dl.t().matmul(h2).to(wdtype)
