@@ -172,6 +172,13 @@ int mivae_colsum(const void* x, float* out, float* workspace, int64_t rows, int6
  * extra kernel per parameter). */
 int mivae_colsum_sink(const void* x, float* out0, float* out1, int64_t split, float* workspace, int64_t rows,
                       int64_t D, int dtype, void* stream);
+/* Weight gradient of torch.nn.Embedding (the Embedder in front of VAELmModel.encode, models/base/model.py:213-222):
+ * dW (V, E) fp32 (+)= sum over tokens with ids[t] == v of dy[t] (dy (N, E) fp32, ids (N) int64), rows of padding_idx
+ * (< 0: none) skipped.  Deterministic (token order, no atomics, no sort).  accumulate != 0: add into dW (gradient sink),
+ * else dW is fully written.  E <= 128, else MIVAE_EUNSUPPORTED (-3). */
+int mivae_embedding_bwd(const float* dy, const int64_t* ids, float* dW, int64_t N, int64_t V, int64_t E,
+                        int64_t padding_idx, int accumulate, void* stream);
+
 /* mivae_colsum_sink for MANY short matrices in one launch: jobs = njobs x {x, out0, out1, rows (<= 512), D, split} as
  * 6 x int64 per job in device memory; bit-identical to njobs calls of mivae_colsum_sink (same summation order).
  * Folds the [dW | db] partials of every small Linear of a training step at the end of backward

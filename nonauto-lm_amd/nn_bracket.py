@@ -457,7 +457,10 @@ class Embedder(torch.nn.Module, FromParams):
         self._embedding = torch.nn.Embedding(num_embeddings, embedding_dim, padding_idx=padding_idx, **kwargs)
 
     def forward(self, tokens):
-        return self._embedding(tokens)
+        e = self._embedding
+        if e.max_norm is None and not e.scale_grad_by_freq and not e.sparse:
+            return ops.embedding(tokens, e.weight, e.padding_idx)      # stock lookup, libmivae weight gradient
+        return e(tokens)
 
     @classmethod
     def from_params(cls, vocab, **kwargs):

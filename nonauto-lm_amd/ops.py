@@ -530,6 +530,38 @@ def flush_grad_sinks():
     L.call("mivae_colsum_sink_multi", L.ptr(table), len(rows), max(r[4] for r in rows), L.stream())
 
 
+class _Embedding(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ids, weight, padding_idx):
+        ctx.save_for_backward(ids)
+        ctx.weight = weight
+        ctx.pad = -1 if padding_idx is None else int(padding_idx)
+        return torch.nn.functional.embedding(ids, weight.detach())
+
+    @staticmethod
+    def backward(ctx, dy):
+        (ids,) = ctx.saved_tensors
+        w = ctx.weight
+        V, E = w.shape
+        dy2 = dy.contiguous().view(-1, E)
+        idc = ids.contiguous().view(-1)
+        if grad_sink_ok(w):
+            L.call("mivae_embedding_bwd", L.ptr(dy2), L.ptr(idc), L.ptr(w.grad), idc.numel(), V, E, ctx.pad, 1, L.stream())
+            return None, None, None
+        dw = torch.empty(V, E, dtype=torch.float32, device=dy.device)
+        L.call("mivae_embedding_bwd", L.ptr(dy2), L.ptr(idc), L.ptr(dw), idc.numel(), V, E, ctx.pad, 0, L.stream())
+        return None, dw, None
+
+
+def embedding(ids, weight, padding_idx=None):
+    """torch.nn.functional.embedding whose weight gradient is the deterministic sort-free libmivae scatter-add
+    (fp32 weights of width <= 128 on the GPU); anything else goes to the stock op."""
+    if (weight.is_cuda and weight.dtype == torch.float32 and weight.size(1) <= 128 and ids.dtype == torch.int64
+            and torch.is_grad_enabled() and weight.requires_grad and weight.is_contiguous()):
+        return _Embedding.apply(ids, weight, padding_idx)
+    return torch.nn.functional.embedding(ids, weight, padding_idx)
+
+
 LINEAR_DIMS = (32, 64, 128, 256)
 
 

@@ -1134,3 +1134,26 @@ def test_ffn_block_fused_forward_vs_fp64_and_layerwise(M, D, H, xdt):
         if k.endswith("key.bias"):          # softmax is invariant to the key bias: its gradient is rounding noise
             continue
         assert rel_err(res[True][2][k], res[False][2][k]) < 2e-2, k
+
+
+@pytest.mark.parametrize("N,V,E,pad", [(16384, 8192, 64, 0), (20000, 1000, 32, 0), (5000, 77, 128, None),
+                                       (64, 40, 64, 3), (9000, 33, 64, 0)])
+def test_embedding_weight_gradient_vs_fp64(M, N, V, E, pad):
+    """mivae_embedding_bwd (sort-free deterministic scatter-add) vs an fp64 index_add: heavy id collisions, several
+    8192-token passes, ragged vocabulary slab, padding row; and run-to-run bit reproducibility."""
+    gen = torch.Generator().manual_seed(N + V)
+    ids = torch.randint(0, V, (N,), generator=gen)
+    ids[: N // 8] = ids[0]                                            # a very frequent token
+    w = dev(torch.randn(V, E, generator=gen)).requires_grad_(True)
+    cot = torch.randn(N, E, generator=gen)
+    out = M.ops.embedding(dev(ids), w, pad)
+    assert torch.equal(out, w.detach()[dev(ids)])
+    (out * dev(cot)).sum().backward()
+    ref = torch.zeros(V, E, dtype=torch.float64).index_add_(0, ids, cot.double())
+    if pad is not None:
+        ref[pad] = 0
+    assert rel_err(w.grad, ref) < 2e-6
+    g1 = w.grad.clone()
+    w.grad = None
+    (M.ops.embedding(dev(ids), w, pad) * dev(cot)).sum().backward()
+    assert torch.equal(g1, w.grad)
