@@ -30,6 +30,7 @@ struct LinArgs {
   const unsigned short* w[kMaxGroup];     // (Fo, Fi) bf16 row-major (torch.nn.Linear layout)
   const unsigned short* bias[kMaxGroup];  // (Fo) bf16 or null (fwd only)
   unsigned short* y[kMaxGroup];           // fwd: y_g (N, Fo); dgrad: y[0] = dx (N, Fi)
+  const unsigned short* relu_src;         // dgrad only, optional (N, Fi): dx is zeroed where relu_src <= 0 (relu')
   int64_t N;
   int Fo, Fi, G;
 };
@@ -99,6 +100,11 @@ __global__ __launch_bounds__(256) void k_lin(LinArgs a) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         u16x4 o = {f32_to_bf16(acc[4 * q]), f32_to_bf16(acc[4 * q + 1]), f32_to_bf16(acc[4 * q + 2]), f32_to_bf16(acc[4 * q + 3])};
+        if (TRANS && a.relu_src) {          // the layer's input was a relu output: pass the gradient where it was > 0
+          const u16x4 r = *reinterpret_cast<const u16x4*>(a.relu_src + tok * M + 32 * c + 4 * hh + 8 * q);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[i] = (r[i] == 0 || (r[i] & 0x8000)) ? (unsigned short)0 : o[i];
+        }
         *reinterpret_cast<u16x4*>(yp + 8 * q) = o;
       }
     }
@@ -428,6 +434,26 @@ extern "C" int mivae_linear_dgrad_group(const void* const* dy, const void* const
   }
   MIVAE_REQUIRE(lin_launch<true>(a, (int)(G * Fo), (int)Fi, S_(stream)) == 0, "linear_dgrad_group: no kernel instance");
   MIVAE_CHECK_LAUNCH("linear_dgrad_group");
+  return MIVAE_OK;
+}
+
+// mivae_linear_dgrad fused with the derivative of a relu in front of the layer: dx = (dy W) * (relu_out > 0), with
+// relu_out (N, Fi) bf16 the layer's input (e.g. PositionwiseFeedForward: w_2(relu(w_1 x)), nn/transformer.py:141-144).
+extern "C" int mivae_linear_dgrad_relu(const void* dy, const void* w, const void* relu_out, void* dx, int64_t N,
+                                       int64_t Fi, int64_t Fo, void* stream) {
+  MIVAE_REQUIRE(N >= 0 && N < (1ll << 31), "linear_dgrad_relu: bad N");
+  MIVAE_REQUIRE(lin_dim_ok(Fi) && lin_dim_ok(Fo), "linear_dgrad_relu: features must be 32, 64, 128 or 256 (Fi=%lld Fo=%lld)",
+                (long long)Fi, (long long)Fo);
+  if (N == 0) return MIVAE_OK;
+  MIVAE_REQUIRE(dy && w && dx && relu_out, "linear_dgrad_relu: null pointer");
+  MIVAE_REQUIRE(aligned16(dy) && aligned16(w) && aligned16(dx) && aligned16(relu_out),
+                "linear_dgrad_relu: operands must be 16-byte aligned");
+  LinArgs a = {};
+  a.x[0] = (const unsigned short*)dy; a.w[0] = (const unsigned short*)w; a.y[0] = (unsigned short*)dx;
+  a.relu_src = (const unsigned short*)relu_out;
+  a.N = N; a.Fo = (int)Fo; a.Fi = (int)Fi; a.G = 1;
+  MIVAE_REQUIRE(lin_launch<true>(a, (int)Fo, (int)Fi, S_(stream)) == 0, "linear_dgrad_relu: no kernel instance");
+  MIVAE_CHECK_LAUNCH("linear_dgrad_relu");
   return MIVAE_OK;
 }
 

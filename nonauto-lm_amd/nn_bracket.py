@@ -191,8 +191,7 @@ class _FfnBlockFn(torch.autograd.Function):
         g, be, w1, b1, w2, b2 = ctx.params
         dy2 = dy.contiguous().view(-1, dy.size(-1))
         dy16 = dy2 if dy2.dtype == torch.bfloat16 else dy2.to(torch.bfloat16)
-        dh = ops.linear_dgrad(dy16, w2l)                                   # (N, H)
-        dh = torch.ops.aten.threshold_backward(dh, hmid, 0)                # relu'
+        dh = ops.linear_dgrad_relu(dy16, w2l, hmid)                        # (N, H), relu' applied on store
         grads = {}
         for name, (xin, gout, w, b) in (("2", (hmid, dy16, w2, b2)), ("1", (xn, dh, w1, b1))):
             small = w.size(0) <= 128 and w.size(1) <= 128

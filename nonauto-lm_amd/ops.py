@@ -620,6 +620,15 @@ def linear_dgrad_group(gs, ws16):
     return dx
 
 
+def linear_dgrad_relu(g2, w16, relu_out):
+    """(g2 @ w16) * (relu_out > 0): input gradient of a Linear whose input was a relu output, one launch."""
+    N, Fo = g2.shape
+    Fi = w16.size(1)
+    dx = torch.empty(N, Fi, dtype=torch.bfloat16, device=g2.device)
+    L.call("mivae_linear_dgrad_relu", L.ptr(g2), L.ptr(w16), L.ptr(relu_out), L.ptr(dx), N, Fi, Fo, L.stream())
+    return dx
+
+
 def linear_wgrad(x2, g2, sink=None):
     """(dW (Fo, Fi), db (Fo)) fp32 from x2 (N, Fi), g2 (N, Fo) bf16; Fi, Fo <= 128.  `sink` = (weight.grad,
     bias.grad): the sums are added there instead and None is returned."""
