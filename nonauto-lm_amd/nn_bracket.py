@@ -69,11 +69,15 @@ class _SplitKLinearFn(torch.autograd.Function):
             x2 = x2.to(g2.dtype)
         n = x2.size(0)
         if ctx.needs_input_grad[1]:
-            G = 1
-            while G < 128 and n % (2 * G) == 0 and n // (2 * G) >= 128:
+            G = 1                                   # 16 token slabs: flat optimum for 128..1024-wide layers (MI355X)
+            while G < 16 and n % (2 * G) == 0 and n // (2 * G) >= 128:
                 G *= 2
             if G > 1:
-                part = torch.bmm(g2.view(G, n // G, -1).transpose(1, 2), x2.view(G, n // G, -1))
+                ga, xa = g2.view(G, n // G, -1).transpose(1, 2), x2.view(G, n // G, -1)
+                try:                                # fp32 partials: the fold below is then exact fp32 accumulation
+                    part = torch.bmm(ga, xa, out_dtype=torch.float32)
+                except (TypeError, RuntimeError):
+                    part = torch.bmm(ga, xa)
                 if part.is_cuda and part.dtype in (torch.float32, torch.bfloat16):
                     gw = ops.colsum(part.view(G, -1)).view(part.shape[1:])      # fp32 G-way sum, fixed order
                 else:
@@ -225,7 +229,9 @@ def ffn_block_supported(x, norm, ffn, sub) -> bool:
 
 # ----------------------------------------------------------------------------------- activations
 def _gelu(x):
-    return x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))   # erf GELU, nn/activation.py:16
+    # erf GELU, nn/activation.py:16: x * 0.5 * (1 + erf(x / sqrt 2)) -- the library's exact (erf) gelu is that
+    # expression as one kernel forward and one backward instead of four + six elementwise launches
+    return F.gelu(x)
 
 
 ACTIVATION_FNS: Dict[str, Callable] = {
@@ -272,10 +278,10 @@ class FeedForward(torch.nn.Module, FromParams):
         self._output_size = output_size or hidden_sizes[-1]
         dims = [input_size] + hidden_sizes
         self._linear_layers = torch.nn.ModuleList(
-            [torch.nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:])])
+            [Linear(a, b) for a, b in zip(dims[:-1], dims[1:])])
         self._activations = torch.nn.ModuleList(activations)
         self._dropout = torch.nn.ModuleList([torch.nn.Dropout(p) for p in dropout])
-        self._output = torch.nn.Linear(hidden_sizes[-1], self._output_size)
+        self._output = Linear(hidden_sizes[-1], self._output_size)
 
     def forward(self, x):
         for lin, act, drop in zip(self._linear_layers, self._activations, self._dropout):
