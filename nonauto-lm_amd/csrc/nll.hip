@@ -386,6 +386,94 @@ __global__ __launch_bounds__(256) void k_lce_fwd(LceArgs a) {
   if (valid && hh == 0) { const f32x4 o = {M, s, sx, xt}; *out = o; }
 }
 
+// LDS-staged forward for E <= 64 (see k_lce_bwd_s): the block's 4 waves share one vocabulary slice, so the W fragments of
+// every chunk pair are fetched once per block (register-staged into a double LDS buffer, one barrier per pair) instead
+// of once per wave through the CU's L1.
+template <int NKS, bool SMOOTH>
+__global__ __launch_bounds__(256) void k_lce_fwd_s(LceArgs a) {
+  constexpr int NF = NKS + 1;
+  constexpr int WB = 2 * NF * 1024;                  // bytes of W fragments per chunk pair
+  constexpr int NV = (WB / 16 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) char wbuf[2][WB];
+  const int lane = threadIdx.x & 63, r32 = lane & 31, hh = lane >> 5;
+  const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t tok = tile * 32 + r32;
+  const bool valid = tok < a.N;
+  const float w = valid ? a.weights[tok] : 0.f;
+  f32x4* out = a.partial + (int64_t)blockIdx.y * a.N + tok;
+  const bool live = __any(w != 0.f) != 0;
+  if (!live && valid && hh == 0) { const f32x4 z = {-INFINITY, 0.f, 0.f, 0.f}; *out = z; }
+  if (!__syncthreads_or(live ? 1 : 0)) return;
+  lce_bf16x8 hf[NF];
+  lce_load_h<NF>(a.h, live ? tok : 0, live && valid, hh, hf);
+  const int t = valid ? (int)a.target[tok] : -1;
+  const int npair = (a.V >> 5) >> 1;                 // V is a multiple of 64
+  const int per2 = (a.per + 1) >> 1;                 // chunk pairs per slice (per = chunks per slice, even here)
+  const int p0 = blockIdx.y * per2;
+  int p1 = p0 + per2;
+  if (p1 > npair) p1 = npair;
+  float m = -INFINITY, s = 0.f, sx = 0.f, xt = 0.f;
+  const char* wsrc = reinterpret_cast<const char*>(a.W);
+  u16x8 pre[NV];
+  auto fetch = [&](int p) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int off = (v * 256 + (int)threadIdx.x) * 16;
+      if (off < WB) pre[v] = *reinterpret_cast<const u16x8*>(wsrc + (int64_t)p * WB + off);
+    }
+  };
+  auto commit = [&](int b) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int off = (v * 256 + (int)threadIdx.x) * 16;
+      if (off < WB) *reinterpret_cast<u16x8*>(wbuf[b] + off) = pre[v];
+    }
+  };
+  if (p0 < p1) { fetch(p0); commit(0); }
+  __syncthreads();
+  for (int p = p0; p < p1; ++p) {
+    const int b = (p - p0) & 1;
+    if (p + 1 < p1) fetch(p + 1);
+    if (live) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int c = 2 * p + u;
+        lce_bf16x8 wf[NF];
+#pragma unroll
+        for (int ks = 0; ks < NF; ++ks)
+          wf[ks] = *reinterpret_cast<const lce_bf16x8*>(wbuf[b] + ((u * NF + ks) * 64 + lane) * 16);
+        const f32x16 x = lce_tile<NF>(wf, hf);
+        float cm = x[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) cm = fmaxf(cm, x[r]);
+        const float mn = fmaxf(m, cm * kLog2e);
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          acc += ex2(fmaf(x[r], kLog2e, -mn));
+          if (SMOOTH) sx += x[r];
+        }
+        s = fmaf(s, ex2(m - mn), acc);
+        m = mn;
+        if (__any((t >> 5) == c)) {
+          const int rel = t - 32 * c - 4 * hh;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) xt += (rel == (r & 3) + 8 * (r >> 2)) ? x[r] : 0.f;
+        }
+      }
+    }
+    if (p + 1 < p1) commit(b ^ 1);
+    __syncthreads();
+  }
+  if (!live) return;
+  const float mo = __shfl_xor(m, 32, 64), so = __shfl_xor(s, 32, 64);
+  const float M = fmaxf(m, mo);
+  s = (m == -INFINITY ? 0.f : s * ex2(m - M)) + (mo == -INFINITY ? 0.f : so * ex2(mo - M));
+  sx += __shfl_xor(sx, 32, 64);
+  xt += __shfl_xor(xt, 32, 64);
+  if (valid && hh == 0) { const f32x4 o = {M, s, sx, xt}; *out = o; }
+}
+
 // tok_nll[r] = w_r * nll_r and lse[r] from the per-slice partials (slices folded in slice order)
 __global__ __launch_bounds__(256) void k_lce_combine(const f32x4* __restrict__ partial, const float* __restrict__ weights,
                                                       float* __restrict__ tok_nll, float* __restrict__ lse_out,
@@ -780,6 +868,7 @@ extern "C" int mivae_lce_fwd(const void* h, const void* W, const int64_t* target
   a.N = N; a.S = (int)S; a.V = (int)V; a.smoothing = smoothing;
   const int VS = lce_slices(N, V / 32);
   a.per = (int)((V / 32 + VS - 1) / VS);
+  if (E <= 64) a.per = (a.per + 1) / 2 * 2;          // the staged kernel walks chunk PAIRS: whole pairs per slice
   float* tok_nll = workspace + (int64_t)VS * N * 4;
   dim3 grid((unsigned)(((N + 31) / 32 + 3) / 4), (unsigned)VS);
   hipStream_t st = S_(stream);
@@ -788,13 +877,19 @@ extern "C" int mivae_lce_fwd(const void* h, const void* W, const int64_t* target
     if (smoothing > 0.f) k_lce_fwd<NKS, true><<<grid, 256, 0, st>>>(a);      \
     else k_lce_fwd<NKS, false><<<grid, 256, 0, st>>>(a);                     \
   } while (0)
+#define LCE_FWD_S(NKS)                                                       \
+  do {                                                                       \
+    if (smoothing > 0.f) k_lce_fwd_s<NKS, true><<<grid, 256, 0, st>>>(a);    \
+    else k_lce_fwd_s<NKS, false><<<grid, 256, 0, st>>>(a);                   \
+  } while (0)
   switch (E) {
-    case 32: LCE_FWD(2); break;
-    case 64: LCE_FWD(4); break;
+    case 32: LCE_FWD_S(2); break;
+    case 64: LCE_FWD_S(4); break;
     case 128: LCE_FWD(8); break;
     default: LCE_FWD(16); break;
   }
 #undef LCE_FWD
+#undef LCE_FWD_S
   MIVAE_CHECK_LAUNCH("lce_fwd");
   k_lce_combine<<<(unsigned)((N + 255) / 256), 256, 0, st>>>(a.partial, weights, tok_nll, lse, N, VS, (int)V, smoothing);
   MIVAE_CHECK_LAUNCH("lce_combine");
