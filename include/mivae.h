@@ -277,6 +277,10 @@ int mivae_linear_dgrad_group(const void* const* dy, const void* const* w, void* 
 int mivae_ffn_fwd(const void* x, const float* gamma, const float* beta, const void* w1, const void* b1, const void* w2,
                   const void* b2, void* y, void* xn, void* hmid, float* mean, float* rstd, int64_t N, int64_t D,
                   int64_t H, float eps, int x_dtype, void* stream);
+/* mivae_linear_wgrad for G (2..4) same-shape layers sharing x in one launch (x staged once): partial[g] as above for
+ * layer g; dy / partial are host arrays of G device pointers.  Fi = Fo in {32, 64}, else MIVAE_EUNSUPPORTED (-3). */
+int mivae_linear_wgrad_group(const void* x, const void* const* dy, float* const* partial, int64_t G, int64_t N,
+                             int64_t Fi, int64_t Fo, void* stream);
 /* mivae_linear_dgrad fused with the derivative of a relu in front of the layer: dx = (dy W) * (relu_out > 0);
  * relu_out (N, Fi) bf16 is the layer's input (PositionwiseFeedForward, nn/transformer.py:141-144). */
 int mivae_linear_dgrad_relu(const void* dy, const void* w, const void* relu_out, void* dx, int64_t N, int64_t Fi,

@@ -204,6 +204,82 @@ __global__ __launch_bounds__(256) void k_lin_wgrad2(WgArgs a) {
   }
 }
 
+// The same for a GROUP of G layers that share x (q / k / v, mu / sigma heads): x is staged once, the G dy tiles next to
+// it, and the G * MO * NI output tiles are split over the 4 waves; layer g's partial row goes to its own buffer.
+struct WgGroupArgs {
+  const unsigned short* x;
+  const unsigned short* dy[kMaxGroup];
+  float* partial[kMaxGroup];
+  int64_t N;
+  int tiles_per_wave;
+};
+
+template <int MO, int NI, int G>
+__global__ __launch_bounds__(256) void k_lin_wgrad2g(WgGroupArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  constexpr int Fo = 32 * MO, Fi = 32 * NI;
+  constexpr int SG = Fo + (MO == 1 ? 0 : 32), SX = Fi + (NI == 1 ? 0 : 32);
+  constexpr int T = G * MO * NI, TPW = (T + 3) / 4;
+  unsigned short* xt = lds;                          // [kSlab][SX]
+  unsigned short* gt = lds + kSlab * SX;             // G x [kSlab][SG]
+  const int lane = threadIdx.x & 63, r32 = lane & 31, hh = lane >> 5;
+  const int wave = threadIdx.x >> 6;
+  f32x16 acc[TPW], accb[TPW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; accb[i][r] = 0.f; }
+  const u16x8 ones_raw = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  const lin_bf16x8 ones = __builtin_bit_cast(lin_bf16x8, ones_raw);
+  const int slabs = a.tiles_per_wave;
+  for (int sl = 0; sl < slabs; ++sl) {
+    const int64_t tb = ((int64_t)blockIdx.x * slabs + sl) * kSlab;
+    if (tb >= a.N) break;
+    if (sl) __syncthreads();
+    for (int idx = threadIdx.x; idx < kSlab * (Fi >> 3); idx += 256) {
+      const int tk = idx / (Fi >> 3), f8 = (idx % (Fi >> 3)) * 8;
+      u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (tb + tk < a.N) v = *reinterpret_cast<const u16x8*>(a.x + (tb + tk) * Fi + f8);
+      *reinterpret_cast<u16x8*>(xt + tk * SX + f8) = v;
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+      for (int idx = threadIdx.x; idx < kSlab * (Fo >> 3); idx += 256) {
+        const int tk = idx / (Fo >> 3), f8 = (idx % (Fo >> 3)) * 8;
+        u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (tb + tk < a.N) v = *reinterpret_cast<const u16x8*>(a.dy[g] + (tb + tk) * Fo + f8);
+        *reinterpret_cast<u16x8*>(gt + (g * kSlab + tk) * SG + f8) = v;
+      }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+      const int t = wave * TPW + i;
+      if (t >= T) continue;                          // wave-uniform
+      const int g = t / (MO * NI), m = (t % (MO * NI)) / NI, n = t % NI;
+#pragma unroll
+      for (int s = 0; s < kSlab / 16; ++s) {
+        const lin_bf16x8 af = lin_tr_frag(gt + g * kSlab * SG, SG, 32 * m, 16 * s, lane);
+        const lin_bf16x8 bf = lin_tr_frag(xt, SX, 32 * n, 16 * s, lane);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[i], 0, 0, 0);
+        if (n == 0) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ones, accb[i], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int t = wave * TPW + i;
+    if (t >= T) continue;
+    const int g = t / (MO * NI), m = (t % (MO * NI)) / NI, n = t % NI;
+    float* out = a.partial[g] + (int64_t)blockIdx.x * ((int64_t)Fo * Fi + Fo);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[(32 * m + lin_row(r, hh)) * Fi + 32 * n + r32] = acc[i][r];
+    if (n == 0 && r32 == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out[Fo * Fi + 32 * m + lin_row(r, hh)] = accb[i][r];
+    }
+  }
+}
+
 // ---- pre-norm feed-forward sublayer, forward, in one launch ----------------------------------------------------
 // y = x + W2 relu(W1 LN(x) + b1) + b2   (nn/transformer.py:147-162 SublayerConnection around :120-144
 // PositionwiseFeedForward; dropout inactive).  Everything is per token: a wave owns 32 tokens, normalises its rows in
@@ -492,6 +568,43 @@ extern "C" int mivae_linear_wgrad(const void* x, const void* dy, float* partial,
   else if (mo == 4 && ni == 1) WG(4, 1); else if (mo == 4 && ni == 2) WG(4, 2); else WG(4, 4);
 #undef WG
   MIVAE_CHECK_LAUNCH("linear_wgrad");
+  return MIVAE_OK;
+}
+
+// mivae_linear_wgrad for G (2..4) same-shape layers that share x, in one launch: partial[g] (rows, Fo * Fi + Fo) as
+// above for layer g.  dy / partial: host arrays of G device pointers.  Instantiated for Fi = Fo in {32, 64};
+// MIVAE_EUNSUPPORTED (-3) otherwise (call mivae_linear_wgrad per layer).
+extern "C" int mivae_linear_wgrad_group(const void* x, const void* const* dy, float* const* partial, int64_t G, int64_t N,
+                                        int64_t Fi, int64_t Fo, void* stream) {
+  MIVAE_REQUIRE(N >= 1 && N < (1ll << 31), "linear_wgrad_group: bad N");
+  if (!(G >= 2 && G <= kMaxGroup && Fi == Fo && (Fi == 32 || Fi == 64))) {
+    mivae_set_error("linear_wgrad_group: unsupported G=%lld Fi=%lld Fo=%lld", (long long)G, (long long)Fi, (long long)Fo);
+    return MIVAE_EUNSUPPORTED;
+  }
+  MIVAE_REQUIRE(x && dy && partial && aligned16(x), "linear_wgrad_group: null or misaligned pointer");
+  WgGroupArgs a = {};
+  a.x = (const unsigned short*)x; a.N = N;
+  for (int g = 0; g < G; ++g) {
+    MIVAE_REQUIRE(dy[g] && partial[g] && aligned16(dy[g]) && aligned16(partial[g]),
+                  "linear_wgrad_group: null or misaligned pointer");
+    a.dy[g] = (const unsigned short*)dy[g]; a.partial[g] = partial[g];
+  }
+  int64_t P;
+  wgrad_geom(N, a.tiles_per_wave, P);
+  const unsigned grid = (unsigned)P;
+  const int pad = Fi == 32 ? 0 : 32;
+  const size_t lds = (size_t)kSlab * (Fi + pad) * 2 * (size_t)(G + 1);
+  hipStream_t st = S_(stream);
+#define WGG(MO, GG)                                                                                          \
+  do {                                                                                                       \
+    if (lds > 64 * 1024)                                                                                     \
+      (void)hipFuncSetAttribute((const void*)k_lin_wgrad2g<MO, MO, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    k_lin_wgrad2g<MO, MO, GG><<<grid, 256, lds, st>>>(a);                                                    \
+  } while (0)
+  if (Fi == 64) { if (G == 2) WGG(2, 2); else if (G == 3) WGG(2, 3); else WGG(2, 4); }
+  else { if (G == 2) WGG(1, 2); else if (G == 3) WGG(1, 3); else WGG(1, 4); }
+#undef WGG
+  MIVAE_CHECK_LAUNCH("linear_wgrad_group");
   return MIVAE_OK;
 }
 

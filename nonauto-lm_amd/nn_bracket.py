@@ -136,6 +136,9 @@ class _GroupLinearFn(torch.autograd.Function):
         gs = [torch.zeros(x2.size(0), Fo, dtype=torch.bfloat16, device=x2.device) if g is None
               else g.contiguous().view(-1, Fo).to(torch.bfloat16) for g in gys]
         gx = ops.linear_dgrad_group(gs, wl).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        if all(ops.grad_sink_ok(w, b) for w, b in ctx.params) and \
+                ops.linear_wgrad_group_deferred(x2, gs, [(w.grad, b.grad) for w, b in ctx.params]):
+            return (gx, None, *([None] * (4 * G)))
         gws, gbs = [], []
         for g, (w, b) in zip(gs, ctx.params):
             if ops.grad_sink_ok(w, b):

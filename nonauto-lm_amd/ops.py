@@ -623,6 +623,30 @@ def linear_dgrad_group(gs, ws16):
     return dx
 
 
+def linear_wgrad_group_deferred(x2, gs, sinks) -> bool:
+    """[dW | db] partials of a group of same-shape layers sharing x2 in ONE launch, queued for flush_grad_sinks().
+    Only in deferred-sink mode and for the instantiated shapes; returns False if the caller must go layer by layer."""
+    N, Fi = x2.shape
+    Fo = gs[0].size(1)
+    rows = L.query("mivae_linear_wgrad_rows", N)
+    D = Fo * Fi + Fo
+    if _DEFER is None or rows > 512 or Fi != Fo or Fi not in (32, 64) or not 2 <= len(gs) <= 4:
+        return False
+    keys = [(s0.data_ptr(), rows, D) for s0, _ in sinks]
+    if any(k in _DEFER for k in keys):
+        return False
+    parts = []
+    for k in keys:
+        part = _PART_BUFS.get(k)
+        if part is None or part.device != x2.device:
+            part = _PART_BUFS[k] = torch.empty(rows, D, dtype=torch.float32, device=x2.device)
+        parts.append(part)
+    L.call("mivae_linear_wgrad_group", L.ptr(x2), _ptr_array(gs), _ptr_array(parts), len(gs), N, Fi, Fo, L.stream())
+    for k, part, (s0, s1) in zip(keys, parts, sinks):
+        _DEFER[k] = (part, s0, s1, Fo * Fi)
+    return True
+
+
 def linear_dgrad_relu(g2, w16, relu_out):
     """(g2 @ w16) * (relu_out > 0): input gradient of a Linear whose input was a relu output, one launch."""
     N, Fo = g2.shape
