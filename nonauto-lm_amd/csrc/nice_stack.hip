@@ -1194,7 +1194,11 @@ static int run_stack(const char* name, bool bwd, StackArgs a, int64_t Bn, int h,
 // slab geometry of the weight-gradient kernel, shared by the workspace query and the launch
 static void dw_geom(int64_t Npad, const Geom& g, int& nslab, int& slab_len, int64_t& nitems) {
   const int64_t items0 = (int64_t)g.K * 2 * 2 * g.HC;
-  int64_t want = (2048 + items0 - 1) / items0;
+  // work items (waves) to aim for: small stacks are bound by the fold of the slab partials (C2: 1024 items -> 27 us
+  // pair, 2048 -> 33 us, 4096 -> 48 us), wide ones by the MFMA work of the partial kernel (keep 2048)
+  static const int64_t forced = getenv("MIVAE_DW_ITEMS") ? atoll(getenv("MIVAE_DW_ITEMS")) : 0;
+  const int64_t target = forced > 0 ? forced : (items0 <= 128 ? 1024 : 2048);
+  int64_t want = (target + items0 - 1) / items0;
   const int64_t maxs = (Npad + 63) / 64;
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
