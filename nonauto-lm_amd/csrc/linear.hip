@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void k_lin_wgrad2g(WgGroupArgs a) {
 // registers (two half-rows per token on lanes l and l + 32), runs W1 on the matrix cores, applies bias + relu on the
 // accumulator tiles and feeds them straight back as the B operand of the W2 product (the accumulator layout IS a
 // B-fragment layout for a permuted contraction index; W2's fragments are read with the same permutation), then adds
-// the residual.  No LDS, no barriers.  The LayerNorm output, its statistics and the relu output are written once for
+// the residual.  The two weight matrices are staged once per block in LDS.  The LayerNorm output, its statistics and the relu output are written once for
 // the backward pass.  Intermediate roundings match the layer-by-layer path (bf16 after LN, after W1 and after W2).
 struct FfnArgs {
   const void* x;                    // (N, D) fp32 or bf16 residual stream
@@ -304,9 +304,24 @@ struct FfnArgs {
 template <typename TI, int ND, int NH>   // D = 16 ND, H = 32 NH
 __global__ __launch_bounds__(256) void k_ffn_fwd(FfnArgs a) {
   constexpr int D = 16 * ND, H = 32 * NH, MD = D / 32;
+  // both weight matrices staged once per block (the 4 waves share them); row strides padded by 16 bytes so that the
+  // 32 rows a fragment read touches fall on different banks
+  constexpr int S1 = D + 8, S2 = H + 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned short wlds[];
+  unsigned short* w1s = wlds;                 // [H][S1]
+  unsigned short* w2s = wlds + H * S1;        // [D][S2]
+  for (int i = threadIdx.x; i < H * (D / 8); i += 256) {
+    const int r = i / (D / 8), c8 = (i % (D / 8)) * 8;
+    *reinterpret_cast<u16x8*>(w1s + r * S1 + c8) = *reinterpret_cast<const u16x8*>(a.w1 + (int64_t)r * D + c8);
+  }
+  for (int i = threadIdx.x; i < D * (H / 8); i += 256) {
+    const int r = i / (H / 8), c8 = (i % (H / 8)) * 8;
+    *reinterpret_cast<u16x8*>(w2s + r * S2 + c8) = *reinterpret_cast<const u16x8*>(a.w2 + (int64_t)r * H + c8);
+  }
+  __syncthreads();
   const int lane = threadIdx.x & 63, r32 = lane & 31, hh = lane >> 5;
   const int64_t tok0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;
-  if (tok0 >= a.N) return;                                  // wave-uniform
+  if (tok0 >= a.N) return;                                  // wave-uniform, after the only barrier
   const int64_t tok = tok0 + r32;
   const bool valid = tok < a.N;
   const TI* xrow = static_cast<const TI*>(a.x) + (valid ? tok : 0) * D;
@@ -358,7 +373,7 @@ __global__ __launch_bounds__(256) void k_ffn_fwd(FfnArgs a) {
     for (int r = 0; r < 16; ++r) acc[r] = bf16_to_f32(a.b1[32 * t + lin_row(r, hh)]);
 #pragma unroll
     for (int ks = 0; ks < ND; ++ks) {
-      const lin_bf16x8 wf = *reinterpret_cast<const lin_bf16x8*>(a.w1 + (int64_t)(32 * t + r32) * D + 16 * ks + 8 * hh);
+      const lin_bf16x8 wf = *reinterpret_cast<const lin_bf16x8*>(w1s + (32 * t + r32) * S1 + 16 * ks + 8 * hh);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[ks], acc, 0, 0, 0);
     }
 #pragma unroll
@@ -380,7 +395,7 @@ __global__ __launch_bounds__(256) void k_ffn_fwd(FfnArgs a) {
     for (int t = 0; t < NH; ++t)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const unsigned short* wp = a.w2 + (int64_t)(32 * m + r32) * H + 32 * t + 16 * s2 + 4 * hh;
+        const unsigned short* wp = w2s + (32 * m + r32) * S2 + 32 * t + 16 * s2 + 4 * hh;
         const u16x4 w0 = *reinterpret_cast<const u16x4*>(wp), w1v = *reinterpret_cast<const u16x4*>(wp + 8);
         const u16x8 araw = {w0[0], w0[1], w0[2], w0[3], w1v[0], w1v[1], w1v[2], w1v[3]};
         const u16x8 braw = {hb[t][2 * s2][0], hb[t][2 * s2][1], hb[t][2 * s2][2], hb[t][2 * s2][3],
@@ -629,7 +644,13 @@ extern "C" int mivae_ffn_fwd(const void* x, const float* gamma, const float* bet
                (const unsigned short*)b2, y, (unsigned short*)xn, (unsigned short*)hmid, mean, rstd, N, eps};
   const unsigned grid = (unsigned)(((N + 31) / 32 + 3) / 4);
   hipStream_t st = S_(stream);
-#define FFN(TI, ND, NH) k_ffn_fwd<TI, ND, NH><<<grid, 256, 0, st>>>(a)
+  const size_t lds = ((size_t)H * (D + 8) + (size_t)D * (H + 8)) * 2;
+#define FFN(TI, ND, NH)                                                                                           \
+  do {                                                                                                            \
+    if (lds > 64 * 1024)                                                                                          \
+      (void)hipFuncSetAttribute((const void*)k_ffn_fwd<TI, ND, NH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    k_ffn_fwd<TI, ND, NH><<<grid, 256, lds, st>>>(a);                                                             \
+  } while (0)
   if (x_dtype == MIVAE_F32) {
     if (D == 64 && H == 128) FFN(float, 4, 4); else if (D == 64) FFN(float, 4, 8);
     else if (H == 128) FFN(float, 8, 4); else FFN(float, 8, 8);
