@@ -167,6 +167,16 @@ int mivae_actnorm_stats(const void* z, float* mean, float* std, float* workspace
 int mivae_colsum(const void* x, float* out, float* workspace, int64_t rows, int64_t D, int dtype,
                  void* stream);
 
+/* Allocation-free variant of mivae_colsum.  No counterpart in the reference: it exists for callers that cannot
+ * allocate device memory (code under HIP-graph capture, tight serving loops, harnesses that forbid hipMalloc).  Same
+ * result as mivae_colsum, bit for bit; the split-row partial sums live in a 4 MiB file-scope device array that every
+ * GPU the library runs on holds until the process ends (resolved once per device with hipGetSymbolAddress).  Limit:
+ * mivae_col_workspace_floats(rows, D, dtype) <= mivae_colsum_static_max_floats() (= 2^20), else MIVAE_EUNSUPPORTED (-3)
+ * with a message.  Calls no hipMalloc / hipFree.  Calls on one GPU share the array: calls that overlap in time on the
+ * same GPU (different streams) race. */
+int64_t mivae_colsum_static_max_floats(void);
+int mivae_colsum_static(const void* x, float* out, int64_t rows, int64_t D, int dtype, void* stream);
+
 /* As mivae_colsum, but ADDS columns [0, split) into out0 and [split, D) into out1: a finished [dW | db] row goes
  * straight into the parameters' gradient buffers (the accumulation autograd's AccumulateGrad would do with one
  * extra kernel per parameter). */

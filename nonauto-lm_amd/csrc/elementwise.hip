@@ -1086,6 +1086,49 @@ extern "C" int mivae_colsum(const void* x, float* out, float* workspace, int64_t
   return colsum_impl(x, out, nullptr, 0, 0, workspace, rows, D, dtype, stream);
 }
 
+// ---- allocation-free variant of mivae_colsum ---------------------------------------------------------------------
+// For callers that cannot allocate (HIP-graph capture, serving loops): the split-row partial sums go to a file-scope
+// device array instead of a caller-supplied workspace.  Every GPU the library runs on holds its own copy of the array
+// (4 MiB) until the process ends; its address on a device is resolved once with hipGetSymbolAddress and kept per
+// device -- the array's NAME is only a host-side stand-in and is never handed to a kernel.  Calls on one GPU share the
+// array: two calls that overlap in time on the same GPU (different streams) race.  The partials are fully overwritten
+// before they are read, so nothing needs clearing between calls.
+constexpr int64_t kStaticScratchFloats = 1 << 20;
+static __device__ __align__(256) float scratch[kStaticScratchFloats];
+constexpr int kMaxDevices = 64;
+static float* g_scratch_ptr[kMaxDevices] = {};
+
+extern "C" int64_t mivae_colsum_static_max_floats(void) { return kStaticScratchFloats; }
+
+extern "C" int mivae_colsum_static(const void* x, float* out, int64_t rows, int64_t D, int dtype, void* stream) {
+  MIVAE_REQUIRE(rows >= 1 && D > 0 && D < (1ll << 31), "colsum_static: bad shape");
+  MIVAE_REQUIRE(dtype == MIVAE_F32 || dtype == MIVAE_BF16, "colsum_static: bad dtype");
+  const int64_t need = rows <= 512 ? 0 : mivae_col_workspace_floats(rows, D, dtype);
+  if (need > kStaticScratchFloats) {
+    mivae_set_error("colsum_static: needs %lld scratch floats, the static buffer holds %lld (rows=%lld D=%lld): use "
+                    "mivae_colsum with a caller workspace", (long long)need, (long long)kStaticScratchFloats,
+                    (long long)rows, (long long)D);
+    return MIVAE_EUNSUPPORTED;
+  }
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+    mivae_set_error("colsum_static: cannot identify the current device");
+    return MIVAE_ELAUNCH;
+  }
+  float* ws = __atomic_load_n(&g_scratch_ptr[dev], __ATOMIC_ACQUIRE);
+  if (!ws) {   // first call on this device (racing first calls resolve the same address)
+    void* p = nullptr;
+    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !p) {
+      mivae_set_error("colsum_static: hipGetSymbolAddress failed: %s", hipGetErrorString(e));
+      return MIVAE_ELAUNCH;
+    }
+    ws = static_cast<float*>(p);
+    __atomic_store_n(&g_scratch_ptr[dev], ws, __ATOMIC_RELEASE);
+  }
+  return colsum_impl(x, out, nullptr, 0, 0, ws, rows, D, dtype, stream);
+}
+
 // The same sums ADDED into two destinations: columns [0, split) += into out0, columns [split, D) += into out1
 // (e.g. the [dW | db] row of mivae_linear_wgrad straight into weight.grad and bias.grad).
 extern "C" int mivae_colsum_sink(const void* x, float* out0, float* out1, int64_t split, float* workspace,
