@@ -85,6 +85,13 @@ SIGNATURES = {
     "mivae_nice_stack_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I32, I32, F32, F32, I32, P],
     "mivae_nice_dw_workspace_floats": [I64, I64, I64, I64],
     "mivae_nice_dw": [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I32, P],
+    "mivae_nice_big_supported": [I64, I64, I32],
+    "mivae_nice_big_pack_bytes": [I64, I64, I64, I32],
+    "mivae_nice_big_pack": [P, P, I64, I64, I64, I32, P],
+    "mivae_nice_big_fwd": [P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I32, I32, I32, F32, F32, P],
+    "mivae_nice_big_dw_workspace_floats": [I64, I64, I64, I64],
+    "mivae_nice_big_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I32, I32, F32,
+                           F32, P],
 }
 _RET = {
     "mivae_last_error": ctypes.c_char_p,
@@ -100,6 +107,8 @@ _RET = {
     "mivae_layernorm_workspace_floats": I64,
     "mivae_nice_stack_npad": I64,
     "mivae_nice_dw_workspace_floats": I64,
+    "mivae_nice_big_pack_bytes": I64,
+    "mivae_nice_big_dw_workspace_floats": I64,
 }
 
 _lib = None

@@ -140,7 +140,9 @@ class NICECoupling(Flow):
         ps, pt = self._s_net.fused_params(), self._t_net.fused_params()
         if ps is None or pt is None:
             return None
-        if z.size(-1) > ops.FUSED_MAX_D or z.size(-1) != 2 * self._s_net.get_input_size():
+        if z.size(-1) != 2 * self._s_net.get_input_size():
+            return None
+        if z.size(-1) > ops.FUSED_MAX_D and not ops.nice_big_supported(z, self._s_net._hidden_sizes[0]):
             return None
         if z.dtype not in (torch.float32, torch.bfloat16):
             return None

@@ -10,7 +10,7 @@ import torch
 from . import _lib as L
 
 ACT_IDS = {"linear": 0, "gelu": 1, "swish": 2, "relu": 3, "tanh": 4, "sigmoid": 5}
-FUSED_MAX_D = 256
+FUSED_MAX_D = 256        # small-D kernels (nice_stack.hip); bf16 latents up to D = 512 run nice_big.hip
 
 # Optional per-launch timing of named kernels with HIP events recorded on the launch stream (used by
 # bench.py for the roofline figure; no host sync is added here).
@@ -986,6 +986,88 @@ class _NiceStack(torch.autograd.Function):
         return (dz_in, None, None, None, None, None, None, None, *grads)
 
 
+BIG_STREAMS = {"fwd": 0, "inv": 1, "chain": 2, "nets": 3, "bias": 4}
+
+
+def nice_big_supported(z, H: int) -> bool:
+    """bf16 latents with 96 < D/2 <= 256 run the MFMA-bound kernels of csrc/nice_big.hip (C3, C5)."""
+    return bool(z.is_cuda and z.dtype == torch.bfloat16
+                and L.query("mivae_nice_big_supported", z.size(-1) // 2, int(H), L.dtype_code(z.dtype)))
+
+
+def nice_big_pack(params: Sequence[torch.Tensor], K: int, h: int, H: int, kind: str) -> torch.Tensor:
+    dev = params[0].device
+    for p in params:
+        if p.dtype != torch.float32 or not p.is_contiguous():
+            raise TypeError("NICE parameters must be contiguous float32 tensors")
+    code = BIG_STREAMS[kind]
+    out = torch.empty(L.query("mivae_nice_big_pack_bytes", K, h, H, code), dtype=torch.uint8, device=dev)
+    L.call("mivae_nice_big_pack", L.ptr(_ptr_table(params, dev)), L.ptr(out), K, h, H, code, L.stream())
+    return out
+
+
+class _NiceStackBig(torch.autograd.Function):
+    """K fused NICE-FF steps (+ optional base log-prob) on the wide-latent kernels.  params as _NiceStack."""
+
+    @staticmethod
+    def forward(ctx, z, mask, H, act, inverse, base, mu, std, *params):
+        Bn, S, D = _shape3(z)
+        h = D // 2
+        K = len(params) // 8
+        z = z.contiguous()
+        N = Bn * S
+        pk = nice_big_pack(params, K, h, H, "inv" if inverse else "fwd")
+        pb = nice_big_pack(params, K, h, H, "bias")
+        need_grad = (not inverse) and any(ctx.needs_input_grad)
+        z_out = torch.empty_like(z)
+        hist = torch.empty(K, N, h, dtype=z.dtype, device=z.device) if need_grad else None
+        tok = torch.empty(N, dtype=torch.float32, device=z.device)
+        with _timed("nice_stack_inv" if inverse else "nice_stack_fwd"):
+            L.call("mivae_nice_big_fwd", L.ptr(z), L.ptr(z_out), L.ptr(hist), L.ptr(mask), L.ptr(pk), L.ptr(pb),
+                   L.ptr(tok), Bn, 1, S, D, H, K, act, int(inverse), int(base), float(mu), float(std), L.stream())
+        ctx.meta = (Bn, S, D, H, K, act, int(base), float(mu), float(std))
+        ctx.params = params
+        if need_grad:
+            ctx.save_for_backward(z, z_out, hist, mask, pb)
+        return z_out, tok
+
+    @staticmethod
+    def backward(ctx, dz_out, dtok):
+        z, z_out, hist, mask, pb = ctx.saved_tensors
+        Bn, S, D, H, K, act, base, mu, std = ctx.meta
+        h, N = D // 2, Bn * S
+        dev = z.device
+        params = ctx.params
+        pc = nice_big_pack(params, K, h, H, "chain")
+        pn = nice_big_pack(params, K, h, H, "nets")
+        dz_in = torch.empty_like(z)
+        dsdt = torch.empty(K, 2, N, h, dtype=z.dtype, device=dev)
+        ws = torch.empty(L.query("mivae_nice_big_dw_workspace_floats", N, h, H, K), dtype=torch.float32, device=dev)
+        dlog = None if dtok is None else dtok.contiguous().float()
+        dzo = None if dz_out is None else dz_out.contiguous()
+        sink = grad_sink_ok(*params) and all(ctx.needs_input_grad[8:])
+        if sink:
+            table = _ptr_table([p.grad for p in params], dev)
+            dW1 = db1 = dW2 = db2 = None
+        else:
+            table = None
+            dW1 = torch.empty(K, 2, H, h, dtype=torch.float32, device=dev)
+            db1 = torch.empty(K, 2, H, dtype=torch.float32, device=dev)
+            dW2 = torch.empty(K, 2, h, H, dtype=torch.float32, device=dev)
+            db2 = torch.empty(K, 2, h, dtype=torch.float32, device=dev)
+        with _timed("nice_stack_bwd"):
+            L.call("mivae_nice_big_bwd", L.ptr(z), L.ptr(z_out), L.ptr(hist), L.ptr(mask), L.ptr(pc), L.ptr(pn), L.ptr(pb),
+                   L.ptr(dzo), L.ptr(dlog), L.ptr(dz_in), L.ptr(dsdt), L.ptr(ws), L.ptr(dW1), L.ptr(db1), L.ptr(dW2),
+                   L.ptr(db2), L.ptr(table), Bn, 1, S, D, H, K, act, base, mu, std, L.stream())
+        if sink:
+            return (dz_in, None, None, None, None, None, None, None, *([None] * len(params)))
+        grads = []
+        for k in range(K):
+            for net in range(2):
+                grads += [dW1[k, net], db1[k, net], dW2[k, net], db2[k, net]]
+        return (dz_in, None, None, None, None, None, None, None, *grads)
+
+
 def nice_stack(z, mask, params: Sequence[torch.Tensor], H: int, activation: str, inverse: bool = False,
                base: bool = False, mu: float = 0.0, std: float = 1.0):
     """Fused K-step NICE-FF stack (a6-a10): returns (z_K, val) where val is the masked log-det summed
@@ -994,8 +1076,9 @@ def nice_stack(z, mask, params: Sequence[torch.Tensor], H: int, activation: str,
     L.require_gpu(z, mask, *params)
     mask = _mask_i64(mask)
     Bn, S, D = _shape3(z)
-    z_out, tok = _NiceStack.apply(z, mask, int(H), ACT_IDS[activation], bool(inverse), bool(base),
-                                  float(mu), float(std), *params)
+    fn = _NiceStackBig if nice_big_supported(z, H) else _NiceStack
+    z_out, tok = fn.apply(z, mask, int(H), ACT_IDS[activation], bool(inverse), bool(base), float(mu), float(std),
+                          *params)
     if z.dim() == 2:
         return z_out, tok
     if mask is None and not base:
