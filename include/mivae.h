@@ -368,7 +368,7 @@ int mivae_maf_sequential(const void* z, const float* w1t, const float* b1, const
 /* ---- NICE stack, wide latents (96 < D/2 <= 256, bf16): MFMA-bound re-tiling of the same path ------------------
  * Same arithmetic and outputs as mivae_nice_stack_fwd / _bwd + mivae_nice_dw (NICECoupling.forward / .backward,
  * couplings.py:141-183; FlowPrior.forward_pass / backward_pass, flow_prior.py:37-70; base log-prob prior.py:148-158)
- * for D/2 in (96, 256], D/2 % 8 == 0, H >= 33, bf16 latents (BASELINE configs C3: D = 256 and C5: D = 512).
+ * for D/2 in (96, 256], D/2 % 8 == 0, H >= 65, bf16 latents (BASELINE configs C3: D = 256 and C5: D = 512).
  * The weights are packed once per call into per-kernel streams (stream_kind: 0 forward, 1 inverse, 2 backward chain,
  * 3 backward nets, 4 biases) from the same device pointer table as mivae_nice_pack. */
 int mivae_nice_big_supported(int64_t h, int64_t H, int dtype);
@@ -384,9 +384,12 @@ int64_t mivae_nice_big_dw_workspace_floats(int64_t N, int64_t h, int64_t H, int6
 /* autograd of mivae_nice_big_fwd (forward direction) in three launches + a fixed-order slab fold: dz_in (N, D) and the
  * gradients of all 4K Linear layers -- written to dW1 (K,2,H,h), db1 (K,2,H), dW2 (K,2,h,H), db2 (K,2,h), or ADDED
  * into the buffers of grad_ptrs (device int64[K][8], mivae_nice_pack's order) when that is given.  dlogp (N) = per-token
- * cotangent of tok_val; dSdT = scratch (K, 2, N, h) in the latent dtype; workspace: mivae_nice_big_dw_workspace_floats. */
+ * cotangent of tok_val; ptr_table = the device pointer table given to mivae_nice_big_pack (the weight-gradient kernel reads
+ * its stationary operands from the fp32 parameters); dSdT = scratch (K, 2, N, h) in the latent dtype; workspace:
+ * mivae_nice_big_dw_workspace_floats. */
 int mivae_nice_big_bwd(const void* z_in, const void* z_out, const void* x1_hist, const int64_t* mask,
-                       const void* packed_chain, const void* packed_nets, const void* packed_bias, const void* dz_out,
+                       const int64_t* ptr_table, const void* packed_chain, const void* packed_nets,
+                       const void* packed_bias, const void* dz_out,
                        const float* dlogp, void* dz_in, void* dSdT, float* workspace, float* dW1, float* db1,
                        float* dW2, float* db2, const int64_t* grad_ptrs, int64_t Bn, int64_t mask_div, int64_t S,
                        int64_t D, int64_t H, int64_t K, int act, int base, float mu, float std, void* stream);

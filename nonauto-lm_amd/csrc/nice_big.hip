@@ -62,45 +62,96 @@ static __host__ __device__ int64_t stream_items(const BigGeom& g, int st) {
 // ---- small ALU helpers ---------------------------------------------------------------------------------
 // GELU (nn/activation.py:9-16) for bf16 operands: gelu(x) = max(x, 0) - |x| Phi(-|x|), Phi(-u) = 2^(u q(u) - 1),
 // q = cubic least-squares fit on [0, 5]; max abs error 1.2e-5 in fp32 arithmetic (the result is rounded to bf16
-// for the second MFMA, 4e-3 relative).  8 VALU instructions per element, one of them v_exp_f32.
-__device__ __forceinline__ float phi_neg_abs(float x) {
-  const float a = fminf(fabsf(x), 5.0f);
-  float q = 0.004080009517455981f;
-  q = fmaf(q, a, -0.045314069231662556f);
-  q = fmaf(q, a, -0.4655827256271148f);
-  q = fmaf(q, a, -1.149269309564982f);
-  return __builtin_amdgcn_exp2f(fmaf(q, a, -1.0f));
+// for the second MFMA, 4e-3 relative).  Written stage by stage over the 16 accumulator registers so that the 16
+// dependent chains interleave (a lone wave pays the VALU dependent-issue latency otherwise); v_med3_f32 instead of
+// fmin / fmax avoids the canonicalising v_max the IEEE forms cost.
+// max(x, 0) as ONE instruction: v_med3_f32 with a finite upper bound (fmaxf and med3 with an infinite bound lower to
+// v_max(x, x) + v_max).  NOT inline asm: hipcc pads no MFMA -> VALU hazard wait states around an asm statement, and an
+// asm v_max reading a fresh MFMA result returned the accumulator without the last product (found the hard way).
+__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, 3.0e38f); }
+constexpr float kGq3 = 0.004080009517455981f, kGq2 = -0.045314069231662556f, kGq1 = -0.4655827256271148f,
+                kGq0 = -1.149269309564982f;
+__device__ __forceinline__ void gelu_tile(f32x16& x) {
+  f32x16 a, q;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = __builtin_amdgcn_fmed3f(fabsf(x[r]), 0.f, 5.0f);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) q[r] = fmaf(kGq3, a[r], kGq2);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) q[r] = fmaf(q[r], a[r], kGq1);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) q[r] = fmaf(q[r], a[r], kGq0);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) q[r] = fmaf(q[r], a[r], -1.0f);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) q[r] = __builtin_amdgcn_exp2f(q[r]);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = relu1(x[r]);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) x[r] = fmaf(-fabsf(x[r]), q[r], a[r]);
 }
-__device__ __forceinline__ float gelu_fast(float x) { return fmaf(-fabsf(x), phi_neg_abs(x), fmaxf(x, 0.f)); }
 // value and derivative: d/dx = Phi(x) + x phi(x)
-__device__ __forceinline__ void gelu_fast_fd(float x, float& y, float& d) {
-  const float e = phi_neg_abs(x);
-  y = fmaf(-fabsf(x), e, fmaxf(x, 0.f));
-  const float cdf = x > 0.f ? 1.0f - e : e;
-  d = fmaf(x * kInvSqrt2Pi, __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f), cdf);
+__device__ __forceinline__ void gelu_tile_fd(f32x16& x, f32x16& d) {
+  f32x16 a, q, e;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = __builtin_amdgcn_fmed3f(fabsf(x[r]), 0.f, 5.0f);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) q[r] = fmaf(kGq3, a[r], kGq2);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) e[r] = x[r] * x[r];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) q[r] = fmaf(q[r], a[r], kGq1);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_exp2f(e[r] * -0.72134752044448170f);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) q[r] = fmaf(q[r], a[r], kGq0);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) q[r] = fmaf(q[r], a[r], -1.0f);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) q[r] = __builtin_amdgcn_exp2f(q[r]);      // Phi(-|x|)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) e[r] *= x[r] * kInvSqrt2Pi;                 // x phi(x)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = relu1(x[r]);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) d[r] = (x[r] > 0.f ? 1.0f - q[r] : q[r]) + e[r];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) x[r] = fmaf(-fabsf(x[r]), q[r], a[r]);
+}
+// derivative only (the backward through the nets does not need the activation value)
+__device__ __forceinline__ void gelu_tile_d(const f32x16& x, f32x16& d) {
+  f32x16 a, q, e;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = __builtin_amdgcn_fmed3f(fabsf(x[r]), 0.f, 5.0f);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) q[r] = fmaf(kGq3, a[r], kGq2);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) e[r] = x[r] * x[r];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) q[r] = fmaf(q[r], a[r], kGq1);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_exp2f(e[r] * -0.72134752044448170f);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) q[r] = fmaf(q[r], a[r], kGq0);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) q[r] = fmaf(q[r], a[r], -1.0f);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) q[r] = __builtin_amdgcn_exp2f(q[r]);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) e[r] *= x[r] * kInvSqrt2Pi;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) d[r] = (x[r] > 0.f ? 1.0f - q[r] : q[r]) + e[r];
 }
 
 template <int ACT>
 __device__ __forceinline__ void big_act(int act, f32x16& a) {
-  if constexpr (ACT == ACT_GELU) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) a[r] = gelu_fast(a[r]);
-  } else {
-    act_tile<-1, true>(act, a);
-  }
+  if constexpr (ACT == ACT_GELU) gelu_tile(a);
+  else act_tile<-1, true>(act, a);
 }
 template <int ACT>
 __device__ __forceinline__ void big_act_fd(int act, f32x16& a, f32x16& d) {
-  if constexpr (ACT == ACT_GELU) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float y, dd;
-      gelu_fast_fd(a[r], y, dd);
-      a[r] = y; d[r] = dd;
-    }
-  } else {
-    act_tile_fd<-1, true>(act, a, d);
-  }
+  if constexpr (ACT == ACT_GELU) gelu_tile_fd(a, d);
+  else act_tile_fd<-1, true>(act, a, d);
 }
 
 // 32 consecutive floats from LDS -> accumulator layout (broadcast ds_read_b128)
@@ -133,17 +184,31 @@ __device__ __forceinline__ bool block_live(const int64_t* mask, int64_t N, int S
   return __any(any) != 0;
 }
 
+// LLVM SchedGroupMask bits for __builtin_amdgcn_sched_group_barrier
+#define SG_VALU 0x002
+#define SG_MFMA 0x008
+#define SG_DS_READ 0x100
+
+// derivative of the activation only
+template <int ACT>
+__device__ __forceinline__ void big_act_d(int act, f32x16& a, f32x16& d) {
+  if constexpr (ACT == ACT_GELU) gelu_tile_d(a, d);
+  else act_tile_fd<-1, true>(act, a, d);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // ---- weight ring --------------------------------------------------------------------------------------
-// Items of ITEM bytes are consumed strictly in stream order: the prologue consumes P0 items, body i the next IPB.
-// Slot of item q = q % R.  enter(dead) is called by every wave once per body: it waits until the items the body
-// reads have landed for this wave's own DMA pieces, joins the barrier (=> landed for every wave, and every wave
-// has finished reading the items below `dead`) and refills the freed slots.
-template <int ITEM, int R, int P0, int IPB>
+// Items of ITEM bytes are consumed strictly in stream order: the prologue consumes P0 items, then every group of G
+// bodies the next GI = G * IPB.  Slot of item q = q % R with R = 2 GI: while a group is being consumed the next
+// one is in flight (LDS-DMA, 16 B / lane).  One barrier per GROUP: enter_group(gi) waits for this wave's own DMA
+// pieces (everything issued one group ago), joins the barrier (=> the group has landed for every wave, and every
+// wave has finished reading the previous group) and issues the group after next.
+template <int ITEM, int GI, int P0>
 struct Ring {
-  static constexpr int PI = ITEM / 4096;   // DMA pieces (1 KiB) per wave and item
+  static constexpr int R = 2 * GI > P0 + GI ? 2 * GI : P0 + GI;
+  static constexpr int PI = ITEM / 8192;   // DMA pieces (1 KiB) per wave and item (8 waves)
   const char* src;
   char* lds;
   int total, issued, slot;   // items
@@ -154,31 +219,29 @@ struct Ring {
     char* d = lds + slot * ITEM + wave * 1024;
 #pragma unroll
     for (int p = 0; p < PI; ++p)
-      __builtin_amdgcn_global_load_lds((glb_cvoid_t*)(s + p * 4096), (lds_void_t*)(d + p * 4096), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_cvoid_t*)(s + p * 8192), (lds_void_t*)(d + p * 8192), 16, 0, 0);
     ++issued;
     slot = slot + 1 == R ? 0 : slot + 1;
   }
-  __device__ __forceinline__ void init(const char* s, char* l, int total_, int wave_, int lane_) {
-    src = s; lds = l; total = total_; issued = 0; slot = 0; wave = wave_; lane = lane_;
-    while (issued < R && issued < total) issue_one();
-  }
-  // prologue: items [0, P0) readable afterwards
-  __device__ __forceinline__ void enter_prologue() {
-    if (issued < total) wait_vm<(R - P0) * PI>(); else wait_vm<0>();
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-  }
-  // body i: items [P0 + IPB i, P0 + IPB (i + 1)) readable afterwards; slots below P0 + IPB i are refilled
-  __device__ __forceinline__ void enter(int i) {
-    // issued so far: R + (i > 0 ? P0 + IPB (i - 1) : 0); needed: everything below P0 + IPB (i + 1)
-    if (issued >= total) wait_vm<0>();
-    else if (i == 0) wait_vm<(R - P0 - IPB) * PI>();
-    else wait_vm<(R - 2 * IPB) * PI>();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the slots about to be refilled are done
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    const int lim = P0 + IPB * i + R;
+  __device__ __forceinline__ void issue_upto(int lim) {
     while (issued < lim && issued < total) issue_one();
+  }
+  __device__ __forceinline__ void init(const char* s, char* l, int total_, int wave_, int lane_) {
+    static_assert(P0 + GI <= R, "prologue + first group must fit the ring");
+    src = s; lds = l; total = total_; issued = 0; slot = 0; wave = wave_; lane = lane_;
+    issue_upto(P0 + GI);
+  }
+  __device__ __forceinline__ void sync() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  // prologue: items [0, P0) (and group 0) readable afterwards
+  __device__ __forceinline__ void enter_prologue() { sync(); }
+  // group gi: items [P0 + GI gi, P0 + GI (gi + 1)) readable afterwards; the group after it is issued
+  __device__ __forceinline__ void enter_group(int gi) {
+    sync();
+    issue_upto(P0 + GI * (gi + 2));
   }
   __device__ __forceinline__ const char* item(int q) const { return lds + (q % R) * ITEM; }
 };
@@ -234,21 +297,23 @@ __global__ void __launch_bounds__(256) k_big_pack(const int64_t* __restrict__ pt
     task_of(g, st, task, k, net, c);
     const float* W1 = reinterpret_cast<const float*>(ptrs[k * 8 + net * 4 + 0]);
     const float* W2 = reinterpret_cast<const float*>(ptrs[k * 8 + net * 4 + 2]);
+    // fragments of v_mfma_f32_16x16x32_bf16: lane (r = lane & 15, g = lane >> 4) holds A[row r][k-slot (g, j)]
     const int frag = e >> 9, lane = (e >> 3) & 63, j = e & 7;
-    const int r = lane & 31, hh = lane >> 5;
-    if (kind == KIND_W1) {          // frag = ks: A[row = hidden 32c + r][k = in nat]
-      const int row = 32 * c + r, col = P::nat_k(frag, hh, j);
+    const int r = lane & 15, gq = lane >> 4;
+    const int perm = j < 4 ? 4 * gq + j : 16 + 4 * gq + (j - 4);   // k order of an accumulator pair used as B operand
+    if (kind == KIND_W1) {          // frag = u * HT + ks: A[row = hidden 32c + 16u + r][k = in 32ks + 8g + j]
+      const int u = frag / g.HT, ks = frag % g.HT;
+      const int row = 32 * c + 16 * u + r, col = 32 * ks + 8 * gq + j;
       if (row < g.H && col < g.h) v = W1[(int64_t)row * g.h + col];
-    } else if (kind == KIND_W2) {   // frag = (t, s): A[row = out 32t + r][k = hidden 32c + perm]
-      const int t = frag >> 1, s = frag & 1;
-      const int row = 32 * t + r, col = 32 * c + P::perm_k(s, hh, j);
+    } else if (kind == KIND_W2) {   // frag = v: A[row = out 16v + r][k = hidden 32c + perm]
+      const int row = 16 * frag + r, col = 32 * c + perm;
       if (row < g.h && col < g.H) v = W2[(int64_t)row * g.H + col];
-    } else if (kind == KIND_W2T) {  // frag = ks: A[row = hidden 32c + r][k = out nat] = W2[out][hidden]
-      const int row = P::nat_k(frag, hh, j), col = 32 * c + r;
+    } else if (kind == KIND_W2T) {  // frag = u * HT + ks: A[row = hidden 32c + 16u + r][k = out 32ks + 8g + j] = W2[out][hidden]
+      const int u = frag / g.HT, ks = frag % g.HT;
+      const int row = 32 * ks + 8 * gq + j, col = 32 * c + 16 * u + r;
       if (row < g.h && col < g.H) v = W2[(int64_t)row * g.H + col];
-    } else {                        // KIND_W1T, frag = (t, s): A[row = in 32t + r][k = hidden 32c + perm] = W1[hidden][in]
-      const int t = frag >> 1, s = frag & 1;
-      const int row = 32 * c + P::perm_k(s, hh, j), col = 32 * t + r;
+    } else {                        // KIND_W1T, frag = v: A[row = in 16v + r][k = hidden 32c + perm] = W1[hidden][in]
+      const int row = 32 * c + perm, col = 16 * frag + r;
       if (row < g.H && col < g.h) v = W1[(int64_t)row * g.h + col];
     }
   }
@@ -256,6 +321,10 @@ __global__ void __launch_bounds__(256) k_big_pack(const int64_t* __restrict__ pt
 }
 
 // ---- forward / inverse / backward-chain kernel --------------------------------------------------------------
+// Tiling: v_mfma_f32_16x16x32_bf16, a wave owns 16 tokens (columns), 8 waves = 128 tokens per block, two waves per
+// SIMD (<= 256 registers): the VALU-heavy activation of one wave runs at the full VALU rate beside the other
+// wave's MFMAs.  Lane (tk = lane & 15, g = lane >> 4); accumulator tile v (16 features x 16 tokens) holds
+// features 16 v + 4 g + {0..3} of token tk in its 4 registers.
 struct BigArgs {
   const T* z_in;        // (N, D)
   T* z_out;             // (N, D)            [FWD / INV: written; CHAIN: read (base log-prob gradient)]
@@ -267,6 +336,7 @@ struct BigArgs {
   int64_t N;
   int S, mask_div, D, K, h, H, HC;
   int act, base;
+  int dbg;              // timing ablations (MIVAE_DBG env): 1 = no weight staging, 2 = no arithmetic, 4 = cycle stamps
   float mu, inv2var, cst;
   // CHAIN
   const T* dz_out;      // (N, D) or null
@@ -277,40 +347,131 @@ struct BigArgs {
 
 enum Mode { M_FWD = 0, M_INV = 1, M_CHAIN = 2 };
 
-template <int HT> struct RingCfg { static constexpr int R = HT <= 4 ? 12 : 9; };
+// bodies per barrier group: R = max(2 GI, P0 + GI) items of 2 HT KiB + the 16 KiB of bias slots must fit the 160 KiB of LDS
+#ifndef BIG_G2
+#define BIG_G2 4
+#endif
+template <int HT> struct RingCfg { static constexpr int G2 = HT <= 4 ? BIG_G2 : 2, G3 = HT <= 4 ? 3 : 1; };
 
-// first layer of one chunk: b1 + W1[c] . x0^T  (A fragments from the item, B = x0 fragments in registers)
-template <int HT>
-__device__ __forceinline__ f32x16 big_l1(const char* item, const float* b1c, int lane, int hh, const bf16x8 (&x0f)[2 * HT]) {
-  const bf16x8* w = reinterpret_cast<const bf16x8*>(item) + lane;
-  f32x16 a = lds_bias_tile(b1c, hh);
-#pragma unroll
-  for (int ks = 0; ks < 2 * HT; ++ks) a = P::mma(w[ks * 64], x0f[ks], a);
-  return a;
+__device__ __forceinline__ f32x4 mma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
-// second layer of one chunk: acc[t] += W2[t, c] . hid^T
+// two stacked accumulator tiles (32 rows) -> the B fragment of a K = 32 product over those rows; element j of
+// lane group g is row (j < 4 ? 4 g + j : 16 + 4 g + j - 4): the order k_big_pack gives the other operand.
+__device__ __forceinline__ bf16x8 pair_to_b(const f32x4& lo, const f32x4& hi) {
+  typedef float f32x8 __attribute__((ext_vector_type(8)));
+  const f32x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_convertvector(v, bf16x8);
+}
+// token-row I/O in the two layouts.  B fragments (natural k): lane holds features 32 ks + 8 g + {0..7}.
 template <int HT>
-__device__ __forceinline__ void big_l2(const char* item, int lane, bf16x8 b0, bf16x8 b1, f32x16 (&acc)[HT]) {
-  const bf16x8* w = reinterpret_cast<const bf16x8*>(item) + lane;
+__device__ __forceinline__ void load_bfrags(const T* __restrict__ row, bool on, int h, int g, bf16x8 (&f)[HT]) {
 #pragma unroll
-  for (int t = 0; t < HT; ++t) {
-    acc[t] = P::mma(w[(2 * t) * 64], b0, acc[t]);
-    acc[t] = P::mma(w[(2 * t + 1) * 64], b1, acc[t]);
+  for (int ks = 0; ks < HT; ++ks) {
+    const int ft = 32 * ks + 8 * g;
+    u16x8 raw = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (on && ft < h) raw = *reinterpret_cast<const u16x8*>(row + ft);
+    f[ks] = __builtin_bit_cast(bf16x8, raw);
   }
 }
+// accumulator layout: tile v holds features 16 v + 4 g + {0..3}
+template <int NT>
+__device__ __forceinline__ void load_tiles(const T* __restrict__ row, bool on, int h, int g, f32x4 (&x)[NT]) {
+#pragma unroll
+  for (int v = 0; v < NT; ++v) {
+    const int ft = 16 * v + 4 * g;
+    float t4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (on && ft < h) RowIO<T, 4>::load(row + ft, t4);
+    x[v] = f32x4{t4[0], t4[1], t4[2], t4[3]};
+  }
+}
+template <int NT>
+__device__ __forceinline__ void store_tiles(T* __restrict__ row, bool on, int h, int g, const f32x4 (&x)[NT]) {
+#pragma unroll
+  for (int v = 0; v < NT; ++v) {
+    const int ft = 16 * v + 4 * g;
+    const float t4[4] = {x[v][0], x[v][1], x[v][2], x[v][3]};
+    if (on && ft < h) RowIO<T, 4>::store(row + ft, t4);
+  }
+}
+// activation of the two tiles of a 32-wide hidden chunk (handled as one 8-register vector)
+typedef float f32x8v __attribute__((ext_vector_type(8)));
+template <int ACT>
+__device__ __forceinline__ void act_pair(int act, f32x4& lo, f32x4& hi) {
+  if constexpr (ACT == ACT_GELU) {
+    f32x8v x = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}, a, q;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) a[r] = __builtin_amdgcn_fmed3f(fabsf(x[r]), 0.f, 5.0f);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) q[r] = fmaf(kGq3, a[r], kGq2);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) q[r] = fmaf(q[r], a[r], kGq1);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) q[r] = fmaf(q[r], a[r], kGq0);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) q[r] = __builtin_amdgcn_exp2f(fmaf(q[r], a[r], -1.0f));
+#pragma unroll
+    for (int r = 0; r < 8; ++r) x[r] = fmaf(-fabsf(x[r]), q[r], relu1(x[r]));
+    lo = f32x4{x[0], x[1], x[2], x[3]}; hi = f32x4{x[4], x[5], x[6], x[7]};
+  } else {
+    f32x16 t;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { t[r] = lo[r]; t[4 + r] = hi[r]; t[8 + r] = 0.f; t[12 + r] = 0.f; }
+    act_tile<-1, true>(act, t);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { lo[r] = t[r]; hi[r] = t[4 + r]; }
+  }
+}
+// derivative of the activation at the pre-activations (lo, hi) -> (dlo, dhi)
+template <int ACT>
+__device__ __forceinline__ void act_pair_d(int act, const f32x4& lo, const f32x4& hi, f32x4& dlo, f32x4& dhi) {
+  if constexpr (ACT == ACT_GELU) {
+    f32x8v x = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}, a, q, e, d;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) a[r] = __builtin_amdgcn_fmed3f(fabsf(x[r]), 0.f, 5.0f);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) q[r] = fmaf(kGq3, a[r], kGq2);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) e[r] = x[r] * x[r];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) q[r] = fmaf(q[r], a[r], kGq1);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) e[r] = __builtin_amdgcn_exp2f(e[r] * -0.72134752044448170f);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) q[r] = fmaf(q[r], a[r], kGq0);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) q[r] = __builtin_amdgcn_exp2f(fmaf(q[r], a[r], -1.0f));   // Phi(-|x|)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) e[r] *= x[r] * kInvSqrt2Pi;                                 // x phi(x)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) d[r] = (x[r] > 0.f ? 1.0f - q[r] : q[r]) + e[r];
+    dlo = f32x4{d[0], d[1], d[2], d[3]}; dhi = f32x4{d[4], d[5], d[6], d[7]};
+  } else {
+    f32x16 t, d;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { t[r] = lo[r]; t[4 + r] = hi[r]; t[8 + r] = 0.f; t[12 + r] = 0.f; }
+    act_tile_fd<-1, true>(act, t, d);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { dlo[r] = d[r]; dhi[r] = d[4 + r]; }
+  }
+}
+// four consecutive floats from LDS (biases of features 16 v + 4 g + {0..3})
+__device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
 template <int HT, int MODE, int ACT>
-__global__ void __launch_bounds__(256) k_big_chain(BigArgs a) {
+__global__ void __launch_bounds__(512) k_big_chain(BigArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NKS = 2 * HT;
-  constexpr int ITEM = NKS * 1024;
-  constexpr int R = RingCfg<HT>::R;
+  constexpr int NF = 2 * HT;           // fragments per item; also accumulator tiles of the h features
+  constexpr int ITEM = NF * 1024;
+  constexpr int G = RingCfg<HT>::G2;
+  typedef Ring<ITEM, 2 * G, 2> RingT;
+  constexpr int R = RingT::R;
   constexpr int NETS = MODE == M_CHAIN ? 1 : 2;
   const int lane = threadIdx.x & 63;
-  const int r32 = lane & 31, hh = lane >> 5;
+  const int tk = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = a.h, HC = a.HC;
-  const int64_t tok = ((int64_t)blockIdx.x * 4 + wave) * 32 + r32;
+  const int64_t tok = ((int64_t)blockIdx.x * 8 + wave) * 16 + tk;
   const bool valid = tok < a.N;
   float m = 0.f, dl = 0.f;
   if (valid) {
@@ -321,241 +482,247 @@ __global__ void __launch_bounds__(256) k_big_chain(BigArgs a) {
     }
     if (MODE == M_CHAIN && a.dlogp) dl = a.dlogp[tok] * m;
   }
-  const bool live = __any(m != 0.f) != 0;
+  const bool live = (__any(m != 0.f) != 0) && !(a.dbg & 2);
   if (!block_live(a.mask, a.N, a.S, a.mask_div, lane)) {
     // the whole block is padding: outputs are zeros; the history / d s, d t rows of masked tokens are never read
     if (valid) {
       const u16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
       if (MODE == M_CHAIN) {
         T* drow = a.dz_in + tok * a.D + h;
-        for (int f = 8 * hh; f < h; f += 16) *reinterpret_cast<u16x8*>(drow + f) = zero;
+        for (int f = 8 * g; f < h; f += 32) *reinterpret_cast<u16x8*>(drow + f) = zero;
       } else {
         T* orow = a.z_out + tok * a.D;
-        for (int f = 8 * hh; f < a.D; f += 16) *reinterpret_cast<u16x8*>(orow + f) = zero;
-        if (hh == 0 && a.tok_val) a.tok_val[tok] = 0.f;
+        for (int f = 8 * g; f < a.D; f += 32) *reinterpret_cast<u16x8*>(orow + f) = zero;
+        if (g == 0 && a.tok_val) a.tok_val[tok] = 0.f;
       }
     }
     return;
   }
   const bool on = valid && m != 0.f;   // masked tokens are computed on zeros (their outputs are multiplied by the mask)
   const T* zrow = a.z_in + tok * a.D;
-  bf16x8 x0f[NKS];
-  load_x0_bf16<T, true, NKS>(zrow, on, h, hh, x0f);
-  f32x16 x1[HT];   // FWD / INV: the transformed half; CHAIN: d loss / d x1
+  bf16x8 x0f[HT];
+  load_bfrags<HT>(zrow, on, h, g, x0f);
+  f32x4 x1[NF];   // FWD / INV: the transformed half; CHAIN: d loss / d x1
   if constexpr (MODE == M_CHAIN) {
-    if (a.dz_out) load_acc<T, true, HT>(a.dz_out + tok * a.D + h, valid, h, hh, x1);
-    else {
-#pragma unroll
-      for (int t = 0; t < HT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x1[t][r] = 0.f;
-    }
+    load_tiles<NF>(a.dz_out ? a.dz_out + tok * a.D + h : zrow, valid && a.dz_out != nullptr, h, g, x1);
     if (a.base && a.dlogp) {   // d/dz_K of the base log-prob: dl * -(z_K - mu) / std^2
-      f32x16 zk[HT];
+      f32x4 zk[NF];
       const float c2 = 2.0f * a.inv2var;
-      load_acc<T, true, HT>(a.z_out + tok * a.D + h, valid, h, hh, zk);
+      load_tiles<NF>(a.z_out + tok * a.D + h, valid, h, g, zk);
 #pragma unroll
-      for (int t = 0; t < HT; ++t)
+      for (int v = 0; v < NF; ++v)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          x1[t][r] += (32 * t + acc_row(r, hh) < h) ? -dl * (zk[t][r] - a.mu) * c2 : 0.f;
+        for (int r = 0; r < 4; ++r) x1[v][r] += (16 * v + 4 * g + r < h) ? -dl * (zk[v][r] - a.mu) * c2 : 0.f;
     }
   } else {
-    load_acc<T, true, HT>(zrow + h, on, h, hh, x1);
+    load_tiles<NF>(zrow + h, on, h, g, x1);
   }
   float ld = 0.f;
 
-  Ring<ITEM, R, 2, 2> ring;
+  RingT ring;
   float* bias_lds = reinterpret_cast<float*>(smem + R * ITEM);
   const int NJ = a.K * NETS;            // nets in stream order
   const int Tn = NJ * HC;               // tasks
-  // bias block of net-index j in stream order
-  auto bias_src = [&](int j) -> const char* {
+  auto bias_src = [&](int j) -> const char* {   // bias block of net-index j in stream order
     int k, net;
     if (MODE == M_CHAIN) { k = a.K - 1 - j; net = 0; }
     else if (MODE == M_FWD) { k = j >> 1; net = j & 1; }
     else { k = a.K - 1 - (j >> 1); net = 1 - (j & 1); }
     return reinterpret_cast<const char*>(a.bias + (int64_t)(k * 2 + net) * kBiasBlockFloats);
   };
-  auto issue_bias = [&](int j) {
-    __builtin_amdgcn_global_load_lds((glb_cvoid_t*)(bias_src(j) + wave * 1024 + lane * 16),
-                                     (lds_void_t*)((char*)bias_lds + (j & 3) * 4096 + wave * 1024), 16, 0, 0);
+  auto issue_bias = [&](int j) {   // 4 KiB = 4 pieces; waves 4-7 repeat pieces 0-3 (uniform DMA count per wave)
+    __builtin_amdgcn_global_load_lds((glb_cvoid_t*)(bias_src(j) + (wave & 3) * 1024 + lane * 16),
+                                     (lds_void_t*)((char*)bias_lds + (j & 3) * 4096 + (wave & 3) * 1024), 16, 0, 0);
   };
-  for (int j = 0; j < kBiasSlots && j < NJ; ++j) issue_bias(j);   // oldest DMA: complete before any ring item
-  ring.init(a.stream, smem, 2 * Tn + 2, wave, lane);
+  int nbias = 0;
+  for (; nbias < kBiasSlots && nbias < NJ; ++nbias) issue_bias(nbias);
+  ring.init(a.stream, smem, (a.dbg & 1) ? 0 : 2 * Tn + 2, wave, lane);
 
-  f32x16 acc[HT];
+  f32x4 acc[NF];
 #pragma unroll
-  for (int t = 0; t < HT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  for (int v = 0; v < NF; ++v) acc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- prologue: L1(0) -> act -> hid(0); L1(1) -> a1
-  ring.enter_prologue();
-  bf16x8 hb0, hb1;
-  f32x16 a1;
-  {
-    f32x16 a0 = big_l1<HT>(ring.item(0), bias_lds, lane, hh, x0f);
-    big_act<ACT>(a.act, a0);
-    hb0 = P::from_acc<0>(a0); hb1 = P::from_acc<1>(a0);
-    // task 1: chunk 1 of net 0 (HC >= 2)
-    a1 = big_l1<HT>(ring.item(1), bias_lds + 32, lane, hh, x0f);
-  }
-  int j = 0, c = 0;   // net-index and chunk of task i
-  for (int i = 0; i < Tn; ++i) {
-    ring.enter(i);
-    if (i > 0 && c == 0 && j - 1 + kBiasSlots < NJ) issue_bias(j - 1 + kBiasSlots);   // slot of the net folded in body i-1
-    const char* it2 = ring.item(2 + 2 * i);
-    const char* it1 = ring.item(3 + 2 * i);
-    // task i + 2
-    int c2 = c + 2, j2 = j;
-    if (c2 >= HC) { c2 -= HC; ++j2; }
-    if (live) {
-      f32x16 a2 = a1;
-      if (i + 2 < Tn) a2 = big_l1<HT>(it1, bias_lds + (j2 & 3) * kBiasBlockFloats + 32 * c2, lane, hh, x0f);
-      big_l2<HT>(it2, lane, hb0, hb1, acc);
-      if (i + 1 < Tn) {
-        big_act<ACT>(a.act, a1);
-        hb0 = P::from_acc<0>(a1); hb1 = P::from_acc<1>(a1);
-      }
-      a1 = a2;
+  // first layer of one chunk: tiles (lo, hi) = b1 + W1[c] . x0^T
+  auto l1 = [&](const char* item, const float* b1c, f32x4& lo, f32x4& hi) {
+    const bf16x8* w = reinterpret_cast<const bf16x8*>(item) + lane;
+    lo = lds4(b1c + 4 * g); hi = lds4(b1c + 16 + 4 * g);
+#pragma unroll
+    for (int ks = 0; ks < HT; ++ks) {
+      lo = mma16(w[ks * 64], x0f[ks], lo);
+      hi = mma16(w[(HT + ks) * 64], x0f[ks], hi);
     }
-    if (c == HC - 1) {
+  };
+  // ---- prologue: L1(0) -> act -> hid(0); L1(1) -> (a1l, a1h)
+  ring.enter_prologue();
+  bf16x8 hb;
+  f32x4 a1l, a1h;
+  {
+    f32x4 l, hi2;
+    l1(ring.item(0), bias_lds, l, hi2);
+    act_pair<ACT>(a.act, l, hi2);
+    hb = pair_to_b(l, hi2);
+    l1(ring.item(1), bias_lds + 32, a1l, a1h);   // task 1: chunk 1 of net 0 (HC >= 2)
+  }
+  // The loop nest is written twice -- with and without the arithmetic -- so that the live path carries its register
+  // tiles through straight-line loops without conditional merges.
+  if (!live) {
+    int i = 0;
+    for (int j = 0; j < NJ; ++j)
+      for (int c = 0; c < HC; ++c, ++i) {
+        if (i % G == 0) {
+          ring.enter_group(i / G);
+          while (nbias < j + kBiasSlots && nbias < NJ) issue_bias(nbias++);
+        }
+      }
+  } else {
+    int i = 0;
+#pragma unroll 1
+    for (int j = 0; j < NJ; ++j) {
+#pragma unroll 1
+      for (int c = 0; c < HC; ++c, ++i) {
+        if (i % G == 0) {
+          ring.enter_group(i / G);
+          // nets below j are folded by every wave: their bias slots are free
+          while (nbias < j + kBiasSlots && nbias < NJ) issue_bias(nbias++);
+        }
+        const char* it2 = ring.item(2 + 2 * i);
+        const char* it1 = ring.item(3 + 2 * i);
+        int c2 = c + 2, j2 = j;       // task i + 2
+        if (c2 >= HC) { c2 -= HC; ++j2; }
+        // three independent streams in one basic block (tasks past the end run on the stream's zero padding):
+        //   L2(i): acc[v] += W2 frags . hid(i);  L1(i+2): (a2l, a2h) = b1 + W1 frags . x0;  act(i+1) -> hid(i+1)
+        const bf16x8* w2 = reinterpret_cast<const bf16x8*>(it2) + lane;
+        f32x4 a2l, a2h;
+#pragma unroll
+        for (int v = 0; v < NF; ++v) acc[v] = mma16(w2[v * 64], hb, acc[v]);
+        l1(it1, bias_lds + (j2 & 3) * kBiasBlockFloats + 32 * c2, a2l, a2h);
+        act_pair<ACT>(a.act, a1l, a1h);
+        hb = pair_to_b(a1l, a1h);
+        a1l = a2l; a1h = a2h;
+      }
       // ---- fold the finished net into the chain
-      if (live) {
-        const float* b2 = bias_lds + (j & 3) * kBiasBlockFloats + HC * 32;
+      {
+        const float* b2 = bias_lds + (j & 3) * kBiasBlockFloats + HC * 32 + 4 * g;
         const int nn = MODE == M_CHAIN ? 0 : (j & 1);
         const int k = MODE == M_FWD ? (j >> 1) : a.K - 1 - (MODE == M_CHAIN ? j : (j >> 1));
         if constexpr (MODE == M_FWD) {
           if (nn == 0) {
-            if (a.x1_hist) store_acc<T, true, HT>(a.x1_hist + ((int64_t)k * a.N + tok) * h, valid, h, hh, x1);
+            if (a.x1_hist) store_tiles<NF>(a.x1_hist + ((int64_t)k * a.N + tok) * h, valid, h, g, x1);
 #pragma unroll
-            for (int t = 0; t < HT; ++t) {
-              const f32x16 bt = lds_bias_tile(b2 + 32 * t, hh);
+            for (int v = 0; v < NF; ++v) {
+              const f32x4 bt = lds4(b2 + 16 * v);
 #pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                const float s = acc[t][r] + bt[r];
-                x1[t][r] *= fast_exp(s);
+              for (int r = 0; r < 4; ++r) {
+                const float s = acc[v][r] + bt[r];
+                x1[v][r] *= fast_exp(s);
                 ld += s;
-                acc[t][r] = 0.f;
+                acc[v][r] = 0.f;
               }
             }
           } else {
 #pragma unroll
-            for (int t = 0; t < HT; ++t) {
-              const f32x16 bt = lds_bias_tile(b2 + 32 * t, hh);
+            for (int v = 0; v < NF; ++v) {
+              const f32x4 bt = lds4(b2 + 16 * v);
 #pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                x1[t][r] = (x1[t][r] + (acc[t][r] + bt[r])) * m;
-                acc[t][r] = 0.f;
+              for (int r = 0; r < 4; ++r) {
+                x1[v][r] = (x1[v][r] + (acc[v][r] + bt[r])) * m;
+                acc[v][r] = 0.f;
               }
             }
           }
         } else if constexpr (MODE == M_INV) {
           if (nn == 0) {   // t first: x1 -= t
 #pragma unroll
-            for (int t = 0; t < HT; ++t) {
-              const f32x16 bt = lds_bias_tile(b2 + 32 * t, hh);
+            for (int v = 0; v < NF; ++v) {
+              const f32x4 bt = lds4(b2 + 16 * v);
 #pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                x1[t][r] -= acc[t][r] + bt[r];
-                acc[t][r] = 0.f;
+              for (int r = 0; r < 4; ++r) {
+                x1[v][r] -= acc[v][r] + bt[r];
+                acc[v][r] = 0.f;
               }
             }
           } else {         // then x1 = x1 exp(-s) m
 #pragma unroll
-            for (int t = 0; t < HT; ++t) {
-              const f32x16 bt = lds_bias_tile(b2 + 32 * t, hh);
+            for (int v = 0; v < NF; ++v) {
+              const f32x4 bt = lds4(b2 + 16 * v);
 #pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                const float s = acc[t][r] + bt[r];
-                x1[t][r] = (x1[t][r] * fast_exp(-s)) * m;
+              for (int r = 0; r < 4; ++r) {
+                const float s = acc[v][r] + bt[r];
+                x1[v][r] = (x1[v][r] * fast_exp(-s)) * m;
                 ld -= s;
-                acc[t][r] = 0.f;
+                acc[v][r] = 0.f;
               }
             }
           }
         } else {           // CHAIN: x1 holds d loss / d x1_k; emit d s_k, d t_k and step back
           T* dS = a.dSdT + ((int64_t)(k * 2) * a.N + tok) * h;
           T* dT = dS + a.N * (int64_t)h;
-          const T* hrow = a.x1_hist + ((int64_t)k * a.N + tok) * h;
+          f32x4 xp[NF], ds[NF], dt[NF];
+          // masked tokens read as zeros (the forward does not write the history of all-padding blocks)
+          load_tiles<NF>(a.x1_hist + ((int64_t)k * a.N + tok) * h, on, h, g, xp);
 #pragma unroll
-          for (int t = 0; t < HT; ++t) {
-            const f32x16 bt = lds_bias_tile(b2 + 32 * t, hh);
-            f32x16 xp[1], ds[1], dt[1];
-            // masked tokens read as zeros (the forward does not write the history of all-padding blocks)
-            load_acc<T, true, 1>(hrow + 32 * t, on && 32 * t < h, h - 32 * t, hh, xp);
+          for (int v = 0; v < NF; ++v) {
+            const f32x4 bt = lds4(b2 + 16 * v);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const bool in = 32 * t + acc_row(r, hh) < h;
-              const float g1 = x1[t][r] * m;
-              const float ge = g1 * fast_exp(acc[t][r] + bt[r]);
-              dt[0][r] = g1;
-              ds[0][r] = in ? ge * xp[0][r] + dl : 0.f;
-              x1[t][r] = ge;
-              acc[t][r] = 0.f;
+            for (int r = 0; r < 4; ++r) {
+              const bool in = 16 * v + 4 * g + r < h;
+              const float g1 = x1[v][r] * m;
+              const float ge = g1 * fast_exp(acc[v][r] + bt[r]);
+              dt[v][r] = g1;
+              ds[v][r] = in ? ge * xp[v][r] + dl : 0.f;
+              x1[v][r] = ge;
+              acc[v][r] = 0.f;
             }
-            store_acc<T, true, 1>(dS + 32 * t, valid && 32 * t < h, h - 32 * t, hh, ds);
-            store_acc<T, true, 1>(dT + 32 * t, valid && 32 * t < h, h - 32 * t, hh, dt);
           }
+          store_tiles<NF>(dS, valid, h, g, ds);
+          store_tiles<NF>(dT, valid, h, g, dt);
         }
       }
-      c = 0; ++j;
-    } else {
-      ++c;
     }
   }
 
   // ---- outputs ---------------------------------------------------------------------------------------------
+  if (!live) {   // an all-padding tile of a live block: zeros
+#pragma unroll
+    for (int v = 0; v < NF; ++v) x1[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   if constexpr (MODE == M_CHAIN) {
-    if (!live) {   // an all-padding tile of a live block: its gradient is zero
-#pragma unroll
-      for (int t = 0; t < HT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x1[t][r] = 0.f;
-    }
-    store_acc<T, true, HT>(a.dz_in + tok * a.D + h, valid, h, hh, x1);
+    store_tiles<NF>(a.dz_in + tok * a.D + h, valid, h, g, x1);
     return;
   } else {
     T* orow = a.z_out + tok * a.D;
-    if (!live) {
-#pragma unroll
-      for (int t = 0; t < HT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x1[t][r] = 0.f;
-    }
-    store_acc<T, true, HT>(orow + h, valid, h, hh, x1);
+    store_tiles<NF>(orow + h, valid, h, g, x1);
     float base = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {   // x0 half: out = x0 * m (x0f is already masked), fragment layout
-      const int f = 16 * ks + 8 * hh;
+    for (int ks = 0; ks < HT; ++ks) {   // x0 half: out = x0 * m (x0f is already masked), fragment layout
+      const int f = 32 * ks + 8 * g;
       const u16x8 raw = __builtin_bit_cast(u16x8, x0f[ks]);
-      if (valid && f < h) *reinterpret_cast<u16x8*>(orow + f) = raw;
+      if (valid && f < h) {
+        *reinterpret_cast<u16x8*>(orow + f) = raw;
 #pragma unroll
-      for (int jj = 0; jj < 8; ++jj)
-        if (valid && f + jj < h) {
+        for (int jj = 0; jj < 8; ++jj) {
           const float d = bf16_to_f32(raw[jj]) - a.mu;
           base += -(d * d) * a.inv2var - a.cst;
         }
+      }
     }
     if (a.base) {
 #pragma unroll
-      for (int t = 0; t < HT; ++t)
+      for (int v = 0; v < NF; ++v)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int f = 32 * t + acc_row(r, hh);
-          if (f < h) {
-            const float v = bf16_to_f32(f32_to_bf16(x1[t][r]));   // what the stored z_K holds
-            const float d = v - a.mu;
+        for (int r = 0; r < 4; ++r)
+          if (16 * v + 4 * g + r < h) {
+            const float vv = bf16_to_f32(f32_to_bf16(x1[v][r]));   // what the stored z_K holds
+            const float d = vv - a.mu;
             base += -(d * d) * a.inv2var - a.cst;
           }
-        }
     } else {
       base = 0.f;
     }
     float tv = (ld + base) * m;
+    tv += __shfl_xor(tv, 16, 64);
     tv += __shfl_xor(tv, 32, 64);
-    if (valid && hh == 0 && a.tok_val) a.tok_val[tok] = tv;
+    if (valid && g == 0 && a.tok_val) a.tok_val[tok] = tv;
   }
 }
 
@@ -577,16 +744,18 @@ struct NetsArgs {
 };
 
 template <int HT, int ACT>
-__global__ void __launch_bounds__(256) k_big_nets(NetsArgs a) {
+__global__ void __launch_bounds__(512) k_big_nets(NetsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NKS = 2 * HT;
-  constexpr int ITEM = NKS * 1024;
-  constexpr int R = RingCfg<HT>::R;
+  constexpr int NF = 2 * HT;
+  constexpr int ITEM = NF * 1024;
+  constexpr int G = RingCfg<HT>::G3;
+  typedef Ring<ITEM, 3 * G, 4> RingT;
+  constexpr int R = RingT::R;
   const int lane = threadIdx.x & 63;
-  const int r32 = lane & 31, hh = lane >> 5;
+  const int tk = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = a.h, HC = a.HC;
-  const int64_t tok = ((int64_t)blockIdx.x * 4 + wave) * 32 + r32;
+  const int64_t tok = ((int64_t)blockIdx.x * 8 + wave) * 16 + tk;
   const bool valid = tok < a.N;
   float m = 0.f, dl = 0.f;
   if (valid) {
@@ -602,114 +771,116 @@ __global__ void __launch_bounds__(256) k_big_nets(NetsArgs a) {
     if (valid) {
       const u16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
       T* drow = a.dz_in + tok * a.D;
-      for (int f = 8 * hh; f < h; f += 16) *reinterpret_cast<u16x8*>(drow + f) = zero;
+      for (int f = 8 * g; f < h; f += 32) *reinterpret_cast<u16x8*>(drow + f) = zero;
     }
     return;
   }
   const bool on = valid && m != 0.f;
-  bf16x8 x0f[NKS];
-  load_x0_bf16<T, true, NKS>(a.z_in + tok * a.D, on, h, hh, x0f);
-  f32x16 dx0[HT];
-  if (a.dz_out) load_acc<T, true, HT>(a.dz_out + tok * a.D, valid, h, hh, dx0);
-  else {
-#pragma unroll
-    for (int t = 0; t < HT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dx0[t][r] = 0.f;
-  }
+  bf16x8 x0f[HT];
+  load_bfrags<HT>(a.z_in + tok * a.D, on, h, g, x0f);
+  f32x4 dx0[NF];
+  load_tiles<NF>(a.dz_out ? a.dz_out + tok * a.D : a.z_in, valid && a.dz_out != nullptr, h, g, dx0);
   if (a.base && a.dlogp && a.z_out) {
-    f32x16 zk[HT];
+    f32x4 zk[NF];
     const float c2 = 2.0f * a.inv2var;
-    load_acc<T, true, HT>(a.z_out + tok * a.D, valid, h, hh, zk);
+    load_tiles<NF>(a.z_out + tok * a.D, valid, h, g, zk);
 #pragma unroll
-    for (int t = 0; t < HT; ++t)
+    for (int v = 0; v < NF; ++v)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        dx0[t][r] += (32 * t + acc_row(r, hh) < h) ? -dl * (zk[t][r] - a.mu) * c2 : 0.f;
+      for (int r = 0; r < 4; ++r) dx0[v][r] += (16 * v + 4 * g + r < h) ? -dl * (zk[v][r] - a.mu) * c2 : 0.f;
   }
 #pragma unroll
-  for (int t = 0; t < HT; ++t)
+  for (int v = 0; v < NF; ++v)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dx0[t][r] *= m;
+    for (int r = 0; r < 4; ++r) dx0[v][r] *= m;
 
-  Ring<ITEM, R, 4, 3> ring;
+  RingT ring;
   float* bias_lds = reinterpret_cast<float*>(smem + R * ITEM);
   const int NJ = a.K * 2;
   const int Tn = NJ * HC;
   auto kn_of = [&](int j) { return (a.K - 1 - (j >> 1)) * 2 + (j & 1); };
   auto issue_bias = [&](int j) {
     const char* src = reinterpret_cast<const char*>(a.bias + (int64_t)kn_of(j) * kBiasBlockFloats);
-    __builtin_amdgcn_global_load_lds((glb_cvoid_t*)(src + wave * 1024 + lane * 16),
-                                     (lds_void_t*)((char*)bias_lds + (j & 3) * 4096 + wave * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_cvoid_t*)(src + (wave & 3) * 1024 + lane * 16),
+                                     (lds_void_t*)((char*)bias_lds + (j & 3) * 4096 + (wave & 3) * 1024), 16, 0, 0);
   };
   // d out of net-index j as B fragments (natural k order over the out features)
-  bf16x8 dob[NKS];
-  auto load_dout = [&](int j) {
-    load_x0_bf16<T, true, NKS>(a.dSdT + ((int64_t)kn_of(j) * a.N + tok) * h, on, h, hh, dob);
-  };
+  bf16x8 dob[HT];
+  auto load_dout = [&](int j) { load_bfrags<HT>(a.dSdT + ((int64_t)kn_of(j) * a.N + tok) * h, on, h, g, dob); };
   load_dout(0);
-  for (int j = 0; j < kBiasSlots && j < NJ; ++j) issue_bias(j);
+  int nbias = 0;
+  for (; nbias < kBiasSlots && nbias < NJ; ++nbias) issue_bias(nbias);
   ring.init(a.stream, smem, 3 * Tn + 4, wave, lane);
 
-  // stage A of a task: pre = b1 + W1 x0, dh = W2^T d out
-  auto stage_a = [&](const char* itW1, const char* itW2T, const float* b1c, f32x16& pre, f32x16& dh) {
+  // stage A of a task: pre = b1 + W1 x0, dh = W2^T d out   (two 16-row tiles each)
+  auto stage_a = [&](const char* itW1, const char* itW2T, const float* b1c, f32x4 (&pre)[2], f32x4 (&dh)[2]) {
     const bf16x8* w1 = reinterpret_cast<const bf16x8*>(itW1) + lane;
     const bf16x8* w2 = reinterpret_cast<const bf16x8*>(itW2T) + lane;
-    pre = lds_bias_tile(b1c, hh);
+    pre[0] = lds4(b1c + 4 * g); pre[1] = lds4(b1c + 16 + 4 * g);
+    dh[0] = f32x4{0.f, 0.f, 0.f, 0.f}; dh[1] = dh[0];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dh[r] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-      pre = P::mma(w1[ks * 64], x0f[ks], pre);
-      dh = P::mma(w2[ks * 64], dob[ks], dh);
+    for (int ks = 0; ks < HT; ++ks) {
+      pre[0] = mma16(w1[ks * 64], x0f[ks], pre[0]);
+      pre[1] = mma16(w1[(HT + ks) * 64], x0f[ks], pre[1]);
+      dh[0] = mma16(w2[ks * 64], dob[ks], dh[0]);
+      dh[1] = mma16(w2[(HT + ks) * 64], dob[ks], dh[1]);
     }
   };
-  ring.enter_prologue();
-  f32x16 pre1, dh1;
-  bf16x8 gb0, gb1;   // d pre of task i as B fragments
-  {
-    f32x16 pre0, dh0, dact;
-    stage_a(ring.item(0), ring.item(1), bias_lds, pre0, dh0);
-    big_act_fd<ACT>(a.act, pre0, dact);
+  // stage B: d pre = dh * act'(pre) -> B fragment
+  auto stage_b = [&](const f32x4 (&pre)[2], const f32x4 (&dh)[2]) -> bf16x8 {
+    f32x4 dlo, dhi;
+    act_pair_d<ACT>(a.act, pre[0], pre[1], dlo, dhi);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dh0[r] *= dact[r];
-    gb0 = P::from_acc<0>(dh0); gb1 = P::from_acc<1>(dh0);
+    for (int r = 0; r < 4; ++r) { dlo[r] *= dh[0][r]; dhi[r] *= dh[1][r]; }
+    return pair_to_b(dlo, dhi);
+  };
+  ring.enter_prologue();
+  f32x4 pre1[2], dh1[2];
+  bf16x8 gb;   // d pre of task i as B fragment
+  {
+    f32x4 pre0[2], dh0[2];
+    stage_a(ring.item(0), ring.item(1), bias_lds, pre0, dh0);
+    gb = stage_b(pre0, dh0);
     stage_a(ring.item(2), ring.item(3), bias_lds + 32, pre1, dh1);
   }
-  int j = 0, c = 0;
-  for (int i = 0; i < Tn; ++i) {
-    ring.enter(i);
-    if (i > 0 && c == 0 && j - 1 + kBiasSlots < NJ) issue_bias(j - 1 + kBiasSlots);
-    const char* itT = ring.item(4 + 3 * i);
-    const char* itA = ring.item(5 + 3 * i);
-    const char* itB = ring.item(6 + 3 * i);
-    int c2 = c + 2, j2 = j;
-    if (c2 >= HC) { c2 -= HC; ++j2; }
-    if (live) {
-      // the first task of the next net enters stage A here: switch the d out fragments
-      if (c2 == 0 && j2 < NJ) load_dout(j2);
-      f32x16 pre2 = pre1, dh2 = dh1;
-      if (i + 2 < Tn) stage_a(itA, itB, bias_lds + (j2 & 3) * kBiasBlockFloats + 32 * c2, pre2, dh2);
-      {   // stage C of task i: dx0[t] += W1T[t] . d pre
-        const bf16x8* w = reinterpret_cast<const bf16x8*>(itT) + lane;
-#pragma unroll
-        for (int t = 0; t < HT; ++t) {
-          dx0[t] = P::mma(w[(2 * t) * 64], gb0, dx0[t]);
-          dx0[t] = P::mma(w[(2 * t + 1) * 64], gb1, dx0[t]);
+  if (!live) {
+    int i = 0;
+    for (int j = 0; j < NJ; ++j)
+      for (int c = 0; c < HC; ++c, ++i) {
+        if (i % G == 0) {
+          ring.enter_group(i / G);
+          while (nbias < j + kBiasSlots && nbias < NJ) issue_bias(nbias++);
         }
       }
-      if (i + 1 < Tn) {   // stage B of task i + 1
-        f32x16 dact;
-        big_act_fd<ACT>(a.act, pre1, dact);
+  } else {
+    int i = 0;
+#pragma unroll 1
+    for (int j = 0; j < NJ; ++j) {
+#pragma unroll 1
+      for (int c = 0; c < HC; ++c, ++i) {
+        if (i % G == 0) {
+          ring.enter_group(i / G);
+          while (nbias < j + kBiasSlots && nbias < NJ) issue_bias(nbias++);
+        }
+        const char* itT = ring.item(4 + 3 * i);
+        const char* itA = ring.item(5 + 3 * i);
+        const char* itB = ring.item(6 + 3 * i);
+        int c2 = c + 2, j2 = j;
+        if (c2 >= HC) { c2 -= HC; ++j2; }
+        // the first task of the next net enters stage A here: switch the d out fragments
+        if (c2 == 0 && j2 < NJ) load_dout(j2);
+        // C(i): dx0 += W1T frags . d pre(i);  A(i+2);  B(i+1) -> d pre(i+1)   (tasks past the end: zero padding)
+        const bf16x8* wt = reinterpret_cast<const bf16x8*>(itT) + lane;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dh1[r] *= dact[r];
-        gb0 = P::from_acc<0>(dh1); gb1 = P::from_acc<1>(dh1);
+        for (int v = 0; v < NF; ++v) dx0[v] = mma16(wt[v * 64], gb, dx0[v]);
+        f32x4 pre2[2], dh2[2];
+        stage_a(itA, itB, bias_lds + (j2 & 3) * kBiasBlockFloats + 32 * c2, pre2, dh2);
+        gb = stage_b(pre1, dh1);
+        pre1[0] = pre2[0]; pre1[1] = pre2[1]; dh1[0] = dh2[0]; dh1[1] = dh2[1];
       }
-      pre1 = pre2; dh1 = dh2;
     }
-    if (c == HC - 1) { c = 0; ++j; } else ++c;
   }
-  store_acc<T, true, HT>(a.dz_in + tok * a.D, valid, h, hh, dx0);
+  store_tiles<NF>(a.dz_in + tok * a.D, valid, h, g, dx0);
 }
 
 // ---- weight gradients (weight-stationary, recompute) -----------------------------------------------------------
@@ -717,7 +888,7 @@ struct DwBigArgs {
   const T* z_in;        // (N, D): x0 = z_in[:, :h]
   const T* dSdT;        // (K, 2, N, h)
   const int64_t* mask;
-  const char* stream;   // ST_NETS (W1 and W2T fragments are read straight from it)
+  const int64_t* ptrs;  // device table [K][8] of the fp32 parameters (mivae_nice_pack's order)
   const float* bias;
   float* part;          // [kn][c][slab][2][HT][64][16]
   float* partb1;        // [kn][c][slab][32]
@@ -755,7 +926,6 @@ template <int HT, int ACT>
 __global__ void __launch_bounds__(256) k_big_dw(DwBigArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NKS = 2 * HT;
-  constexpr int ITEM = NKS * 1024;
   constexpr int HPB = HT * 64;              // bytes per tile row
   constexpr int TILE = 32 * HPB;            // bytes per operand tile
   constexpr int CPT = TILE / 16 / 256;      // 16-byte chunks per thread and operand tile (HT/2)
@@ -770,12 +940,24 @@ __global__ void __launch_bounds__(256) k_big_dw(DwBigArgs a) {
   bf16x8 w1f[NKS], w2f[NKS];
   float b1v = 0.f;
   if (wave_on) {
-    const int64_t task = ((int64_t)(a.K - 1 - k) * 2 + net) * HC + c;
-    const int64_t q1 = task < 2 ? 2 * task : 4 + 3 * (task - 2) + 1;
-    const bf16x8* p1 = reinterpret_cast<const bf16x8*>(a.stream + q1 * ITEM) + lane;
-    const bf16x8* p2 = reinterpret_cast<const bf16x8*>(a.stream + (q1 + 1) * ITEM) + lane;
+    // stationary operands as B fragments (col = hidden unit 32c + r32, k natural): W1[hid][16ks + 8hh + j] and
+    // W2[16ks + 8hh + j][hid], rounded to bf16 exactly like the packed streams of the other kernels
+    const float* W1 = reinterpret_cast<const float*>(a.ptrs[k * 8 + net * 4 + 0]);
+    const float* W2 = reinterpret_cast<const float*>(a.ptrs[k * 8 + net * 4 + 2]);
+    const int hid = 32 * c + r32;
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) { w1f[ks] = p1[ks * 64]; w2f[ks] = p2[ks * 64]; }
+    for (int ks = 0; ks < NKS; ++ks) {
+      u16x8 r1 = {0, 0, 0, 0, 0, 0, 0, 0}, r2 = r1;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const int f = 16 * ks + 8 * hh + jj;
+        if (hid < a.H && f < h) {
+          r1[jj] = f32_to_bf16(W1[(int64_t)hid * h + f]);
+          r2[jj] = f32_to_bf16(W2[(int64_t)f * a.H + hid]);
+        }
+      }
+      w1f[ks] = __builtin_bit_cast(bf16x8, r1); w2f[ks] = __builtin_bit_cast(bf16x8, r2);
+    }
     b1v = a.bias[(int64_t)kn * kBiasBlockFloats + 32 * c + r32];
   }
   f32x16 dW1[HT], dW2[HT];
@@ -802,11 +984,14 @@ __global__ void __launch_bounds__(256) k_big_dw(DwBigArgs a) {
       const int row = id / (HPB / 16), ch = id % (HPB / 16);
       const int64_t tk = tile * 32 + row;
       u16x8 vx = {0, 0, 0, 0, 0, 0, 0, 0}, vg = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (tk < a.N && ch * 8 < h) {
+      if (tile - tile0 < ntiles && tk < a.N && ch * 8 < h) {
         bool keep = true;
         if (a.mask) {
-          const int64_t bn = tk / a.S;
-          keep = a.mask[(bn / a.mask_div) * a.S + (tk - bn * a.S)] != 0;
+          if (a.mask_div == 1) keep = a.mask[tk] != 0;       // (B, S) mask of a (B, S, D) latent: row-major == token index
+          else {
+            const int bn = (int)tk / a.S;
+            keep = a.mask[(int64_t)(bn / a.mask_div) * a.S + ((int)tk - bn * a.S)] != 0;
+          }
         }
         if (keep) {
           vx = *reinterpret_cast<const u16x8*>(a.z_in + tk * a.D + ch * 8);
@@ -828,36 +1013,61 @@ __global__ void __launch_bounds__(256) k_big_dw(DwBigArgs a) {
       *reinterpret_cast<u16x8*>(bg + off) = sg[u];
     }
   };
-  if (ntiles > 0) {
-    gload(tile0);
-    lwrite(0);
+  // Software pipeline over token tiles (4 LDS buffers): body n runs, in ONE basic block,
+  //   A(n+1): pre = x0 . W1^T + b1, dh = d out . W2        4 HT MFMAs on tile n+1 (row reads)
+  //   C(n-1): dW1 += x0^T . d pre, dW2 += d out^T . hid    4 HT MFMAs on tile n-1 (transposing reads)
+  //   B(n):   hid, act', d pre of tile n -> bf16 fragments  ~300 VALU
+  // while tile n+2 travels global -> registers -> LDS.  Tiles outside the slab are zeros (zero contributions), so
+  // the loop needs no peeling: bodies 0 .. ntiles.
+  {
+    const u16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < 2 * CPT; ++u)
+      *reinterpret_cast<u16x8*>(smem + 3 * 2 * TILE + (threadIdx.x + 256 * u) * 16) = zero;
   }
+  gload(tile0);
+  lwrite(0);
+  gload(tile0 + 1);
+  lwrite(1);
   __syncthreads();
-  for (int64_t n = 0; n < ntiles; ++n) {
-    const int buf = (int)(n & 1);
-    if (n + 1 < ntiles) gload(tile0 + n + 1);
+  const int rowoff = r32 * HPB, sw = swz(r32);
+  auto stage_a = [&](int buf, f32x16& pre, f32x16& dh) {
+    const char* bx = smem + buf * 2 * TILE;
+    const char* bg = bx + TILE;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { pre[r] = b1v; dh[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int ch = 2 * ks + hh;
+      const bf16x8 ax = *reinterpret_cast<const bf16x8*>(bx + rowoff + ((ch ^ sw) << 4));
+      const bf16x8 ag = *reinterpret_cast<const bf16x8*>(bg + rowoff + ((ch ^ sw) << 4));
+      pre = P::mma(ax, w1f[ks], pre);
+      dh = P::mma(ag, w2f[ks], dh);
+    }
+  };
+  f32x16 pre_c, dh_c;
+  if (wave_on) stage_a(0, pre_c, dh_c);
+  const u16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  bf16x8 hb0 = __builtin_bit_cast(bf16x8, z8), hb1 = hb0, gb0 = hb0, gb1 = hb0;   // fragments of tile n-1
+#pragma unroll 1
+  for (int64_t n = 0; n <= ntiles; ++n) {
+    gload(tile0 + n + 2);
     if (wave_on) {
-      const char* bx = smem + buf * 2 * TILE;
+      const int bufc = (int)((n + 3) & 3);
+      const char* bx = smem + bufc * 2 * TILE;
       const char* bg = bx + TILE;
-      // preT (tokens x hidden) = x0 . W1^T ; dhT = d out . W2
-      f32x16 pre, dh;
+      if (want_b2) {   // db2 = sum over tokens of d out (one wave per (slab, step, net))
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { pre[r] = b1v; dh[r] = 0.f; }
-      const int rowoff = r32 * HPB, sw = swz(r32);
+        for (int t = 0; t < HT; ++t) {
+          const bf16x8 g0a = tr_frag<HPB>(bg, t, 0, lane), g0b = tr_frag<HPB>(bg, t, 1, lane);
+          float s = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        const int ch = 2 * ks + hh;
-        const bf16x8 ax = *reinterpret_cast<const bf16x8*>(bx + rowoff + ((ch ^ sw) << 4));
-        const bf16x8 ag = *reinterpret_cast<const bf16x8*>(bg + rowoff + ((ch ^ sw) << 4));
-        pre = P::mma(ax, w1f[ks], pre);
-        dh = P::mma(ag, w2f[ks], dh);
+          for (int jj = 0; jj < 8; ++jj) s += (float)g0a[jj] + (float)g0b[jj];
+          db2[t] += s;
+        }
       }
-      f32x16 dact;
-      big_act_fd<ACT>(a.act, pre, dact);   // pre := hidden activations
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { dh[r] *= dact[r]; db1 += dh[r]; }
-      const bf16x8 hb0 = P::from_acc<0>(pre), hb1 = P::from_acc<1>(pre);
-      const bf16x8 gb0 = P::from_acc<0>(dh), gb1 = P::from_acc<1>(dh);
+      f32x16 pre_n, dh_n;
+      stage_a((int)((n + 1) & 3), pre_n, dh_n);
 #pragma unroll
       for (int t = 0; t < HT; ++t) {
         const bf16x8 x0a = tr_frag<HPB>(bx, t, 0, lane), x0b = tr_frag<HPB>(bx, t, 1, lane);
@@ -866,15 +1076,27 @@ __global__ void __launch_bounds__(256) k_big_dw(DwBigArgs a) {
         dW1[t] = P::mma(x0b, gb1, dW1[t]);
         dW2[t] = P::mma(g0a, hb0, dW2[t]);
         dW2[t] = P::mma(g0b, hb1, dW2[t]);
-        if (want_b2) {
-          float s = 0.f;
+      }
+      f32x16 dact;
+      big_act_fd<ACT>(a.act, pre_c, dact);   // pre_c := hidden activations of tile n
 #pragma unroll
-          for (int jj = 0; jj < 8; ++jj) s += (float)g0a[jj] + (float)g0b[jj];
-          db2[t] += s;
-        }
+      for (int r = 0; r < 16; ++r) { dh_c[r] *= dact[r]; db1 += dh_c[r]; }
+      hb0 = P::from_acc<0>(pre_c); hb1 = P::from_acc<1>(pre_c);
+      gb0 = P::from_acc<0>(dh_c); gb1 = P::from_acc<1>(dh_c);
+      pre_c = pre_n; dh_c = dh_n;
+      constexpr int VPM = HT <= 4 ? 9 : 5;
+      __builtin_amdgcn_sched_group_barrier(SG_DS_READ, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_VALU, 16, 0);
+#pragma unroll
+      for (int q = 0; q < 4 * HT; ++q) {
+        __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(SG_DS_READ, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(SG_VALU, VPM, 0);
+        __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(SG_VALU, VPM, 0);
       }
     }
-    if (n + 1 < ntiles) lwrite(buf ^ 1);
+    lwrite((int)((n + 2) & 3));
     __syncthreads();
   }
   if (!wave_on) return;
@@ -967,7 +1189,7 @@ __global__ void __launch_bounds__(256) k_big_dw_reduce(DwRedArgs a) {
 // ---- host side ---------------------------------------------------------------------------------------------------
 static bool big_shape_ok(int64_t h, int64_t H) {
   const int64_t hp = (h + 31) / 32 * 32, Hp = (H + 31) / 32 * 32;
-  return h >= 97 && h <= 256 && h % 8 == 0 && H >= 33 && Hp + hp <= kBiasBlockFloats;
+  return h >= 97 && h <= 256 && h % 8 == 0 && H >= 65 && Hp + hp <= kBiasBlockFloats;
 }
 static int big_ht(int64_t h) { return h <= 128 ? 4 : 8; }
 // geometry with hp rounded up to the instantiated tile counts (HT = 4 or 8)
@@ -982,14 +1204,14 @@ static BigGeom big_geom_inst(int h, int H, int K) {
 template <int HT, int ACT>
 static void launch_chain(int mode, const BigArgs& a, unsigned grid, size_t lds, hipStream_t st) {
   auto opt = [&](const void* fn) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); };
-  if (mode == M_FWD) { opt((const void*)k_big_chain<HT, M_FWD, ACT>); k_big_chain<HT, M_FWD, ACT><<<grid, 256, lds, st>>>(a); }
-  else if (mode == M_INV) { opt((const void*)k_big_chain<HT, M_INV, ACT>); k_big_chain<HT, M_INV, ACT><<<grid, 256, lds, st>>>(a); }
-  else { opt((const void*)k_big_chain<HT, M_CHAIN, ACT>); k_big_chain<HT, M_CHAIN, ACT><<<grid, 256, lds, st>>>(a); }
+  if (mode == M_FWD) { opt((const void*)k_big_chain<HT, M_FWD, ACT>); k_big_chain<HT, M_FWD, ACT><<<grid, 512, lds, st>>>(a); }
+  else if (mode == M_INV) { opt((const void*)k_big_chain<HT, M_INV, ACT>); k_big_chain<HT, M_INV, ACT><<<grid, 512, lds, st>>>(a); }
+  else { opt((const void*)k_big_chain<HT, M_CHAIN, ACT>); k_big_chain<HT, M_CHAIN, ACT><<<grid, 512, lds, st>>>(a); }
 }
 template <int HT, int ACT>
 static void launch_nets(const NetsArgs& a, unsigned grid, size_t lds, hipStream_t st) {
   (void)hipFuncSetAttribute((const void*)k_big_nets<HT, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  k_big_nets<HT, ACT><<<grid, 256, lds, st>>>(a);
+  k_big_nets<HT, ACT><<<grid, 512, lds, st>>>(a);
 }
 template <int HT, int ACT>
 static void launch_dw(const DwBigArgs& a, dim3 grid, size_t lds, hipStream_t st) {
@@ -1002,7 +1224,12 @@ static void launch_dw(const DwBigArgs& a, dim3 grid, size_t lds, hipStream_t st)
     else { if ((actv) == ACT_GELU) { CALL(8, ACT_GELU); } else { CALL(8, -1); } }            \
   } while (0)
 
-static size_t ring_lds(int HT) { return (size_t)(HT <= 4 ? RingCfg<4>::R : RingCfg<8>::R) * 2 * HT * 1024 + kBiasSlots * 4096; }
+static size_t ring_lds(int HT, int ipb) {
+  const int g = ipb == 2 ? (HT <= 4 ? RingCfg<4>::G2 : RingCfg<8>::G2) : (HT <= 4 ? RingCfg<4>::G3 : RingCfg<8>::G3);
+  const int gi = g * ipb, p0 = ipb == 2 ? 2 : 4;
+  const int r = 2 * gi > p0 + gi ? 2 * gi : p0 + gi;
+  return (size_t)r * 2 * HT * 1024 + kBiasSlots * 4096;
+}
 
 static void dw_big_geom(int64_t N, const BigGeom& g, int& nslab, int& slab_tiles) {
   const int64_t ntiles = (N + 31) / 32;
@@ -1070,10 +1297,11 @@ extern "C" int mivae_nice_big_fwd(const void* z_in, void* z_out, void* x1_hist, 
   a.stream = (const char*)packed_stream; a.bias = (const float*)packed_bias; a.tok_val = tok_val;
   a.N = Bn * S; a.S = (int)S; a.mask_div = (int)mask_div; a.D = (int)D; a.K = (int)K; a.h = g.h; a.H = g.H; a.HC = g.HC;
   a.act = act; a.base = base; a.mu = mu;
+  { const char* e = getenv("MIVAE_DBG"); a.dbg = e ? atoi(e) : 0; }
   a.inv2var = base ? 1.0f / (2.0f * std * std) : 0.f;
   a.cst = base ? logf(std) + 0.5f * kLog2Pi : 0.f;
   const unsigned grid = (unsigned)((a.N + 127) / 128);
-  const size_t lds = ring_lds(g.HT);
+  const size_t lds = ring_lds(g.HT, 2);
   const int mode = inverse ? M_INV : M_FWD;
 #define CALL(HTc, ACTc) launch_chain<HTc, ACTc>(mode, a, grid, lds, (hipStream_t)stream)
   BIG_DISPATCH(g.HT, act, CALL);
@@ -1096,15 +1324,16 @@ extern "C" int64_t mivae_nice_big_dw_workspace_floats(int64_t N, int64_t h, int6
 //   gradients go to dW1 (K,2,H,h), db1 (K,2,H), dW2 (K,2,h,H), db2 (K,2,h), or, when grad_ptrs (device int64[K][8] in
 //   mivae_nice_pack's order) is given, are ADDED into those buffers.
 extern "C" int mivae_nice_big_bwd(const void* z_in, const void* z_out, const void* x1_hist, const int64_t* mask,
-                                  const void* packed_chain, const void* packed_nets, const void* packed_bias,
-                                  const void* dz_out, const float* dlogp, void* dz_in, void* dSdT, float* workspace,
+                                  const int64_t* ptr_table, const void* packed_chain, const void* packed_nets,
+                                  const void* packed_bias, const void* dz_out, const float* dlogp, void* dz_in,
+                                  void* dSdT, float* workspace,
                                   float* dW1, float* db1, float* dW2, float* db2, const int64_t* grad_ptrs,
                                   int64_t Bn, int64_t mask_div, int64_t S, int64_t D, int64_t H, int64_t K, int act,
                                   int base, float mu, float std, void* stream) {
   int rc = big_common_checks("nice_big_bwd", Bn, S, D, H, K, act, mask_div);
   if (rc) return rc;
   if (Bn == 0) return MIVAE_OK;
-  MIVAE_REQUIRE(z_in && x1_hist && packed_chain && packed_nets && packed_bias && dz_in && dSdT && workspace,
+  MIVAE_REQUIRE(z_in && x1_hist && ptr_table && packed_chain && packed_nets && packed_bias && dz_in && dSdT && workspace,
                 "nice_big_bwd: null pointer");
   MIVAE_REQUIRE(grad_ptrs || (dW1 && db1 && dW2 && db2), "nice_big_bwd: no gradient destination");
   MIVAE_REQUIRE(!base || (std > 0.f && z_out), "nice_big_bwd: base log-prob needs z_out and std > 0");
@@ -1115,7 +1344,7 @@ extern "C" int mivae_nice_big_bwd(const void* z_in, const void* z_out, const voi
   hipStream_t st = (hipStream_t)stream;
   const int64_t N = Bn * S;
   const unsigned grid = (unsigned)((N + 127) / 128);
-  const size_t lds = ring_lds(g.HT);
+  const size_t lds = ring_lds(g.HT, 2), lds_nets = ring_lds(g.HT, 3);
   {
     BigArgs a = {};
     a.z_in = (const T*)z_in; a.z_out = (T*)const_cast<void*>(z_out); a.x1_hist = (T*)const_cast<void*>(x1_hist);
@@ -1135,14 +1364,14 @@ extern "C" int mivae_nice_big_bwd(const void* z_in, const void* z_out, const voi
     a.dz_in = (T*)dz_in; a.N = N; a.S = (int)S; a.mask_div = (int)mask_div; a.D = (int)D; a.K = (int)K;
     a.h = g.h; a.H = g.H; a.HC = g.HC; a.act = act; a.base = base; a.mu = mu;
     a.inv2var = base ? 1.0f / (2.0f * std * std) : 0.f;
-#define CALL(HTc, ACTc) launch_nets<HTc, ACTc>(a, grid, lds, st)
+#define CALL(HTc, ACTc) launch_nets<HTc, ACTc>(a, grid, lds_nets, st)
     BIG_DISPATCH(g.HT, act, CALL);
 #undef CALL
     MIVAE_CHECK_LAUNCH("nice_big_bwd_nets");
   }
   {
     DwBigArgs a = {};
-    a.z_in = (const T*)z_in; a.dSdT = (const T*)dSdT; a.mask = mask; a.stream = (const char*)packed_nets;
+    a.z_in = (const T*)z_in; a.dSdT = (const T*)dSdT; a.mask = mask; a.ptrs = ptr_table;
     a.bias = (const float*)packed_bias; a.N = N; a.S = (int)S; a.mask_div = (int)mask_div; a.D = (int)D; a.K = (int)K;
     a.h = g.h; a.H = g.H; a.HC = g.HC; a.act = act;
     dw_big_geom(N, g, a.nslab, a.slab_tiles);
@@ -1151,7 +1380,7 @@ extern "C" int mivae_nice_big_bwd(const void* z_in, const void* z_out, const voi
     a.partb1 = workspace + nitems * 2 * g.HT * 1024;
     a.partb2 = a.partb1 + nitems * 32;
     dim3 dgrid((unsigned)a.nslab, (unsigned)(K * 2), (unsigned)((g.HC + 3) / 4));
-    const size_t dlds = (size_t)4 * 32 * g.HT * 64;
+    const size_t dlds = (size_t)8 * 32 * g.HT * 64;   // 4 tile buffers x 2 operands
 #define CALL(HTc, ACTc) launch_dw<HTc, ACTc>(a, dgrid, dlds, st)
     BIG_DISPATCH(g.HT, act, CALL);
 #undef CALL

@@ -1056,7 +1056,8 @@ class _NiceStackBig(torch.autograd.Function):
             dW2 = torch.empty(K, 2, h, H, dtype=torch.float32, device=dev)
             db2 = torch.empty(K, 2, h, dtype=torch.float32, device=dev)
         with _timed("nice_stack_bwd"):
-            L.call("mivae_nice_big_bwd", L.ptr(z), L.ptr(z_out), L.ptr(hist), L.ptr(mask), L.ptr(pc), L.ptr(pn), L.ptr(pb),
+            L.call("mivae_nice_big_bwd", L.ptr(z), L.ptr(z_out), L.ptr(hist), L.ptr(mask), L.ptr(_ptr_table(params, dev)),
+                   L.ptr(pc), L.ptr(pn), L.ptr(pb),
                    L.ptr(dzo), L.ptr(dlog), L.ptr(dz_in), L.ptr(dsdt), L.ptr(ws), L.ptr(dW1), L.ptr(db1), L.ptr(dW2),
                    L.ptr(db2), L.ptr(table), Bn, 1, S, D, H, K, act, base, mu, std, L.stream())
         if sink:
