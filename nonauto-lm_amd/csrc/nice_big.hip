@@ -884,73 +884,116 @@ __global__ void __launch_bounds__(512) k_big_nets(NetsArgs a) {
 }
 
 // ---- weight gradients (weight-stationary, recompute) -----------------------------------------------------------
+// v_mfma_f32_16x16x32_bf16 again: a wave owns 16 hidden units of one (step, net) -- its rows of W1 and columns of W2
+// stay in registers as B fragments -- and a block of 8 waves (128 hidden units) walks a slab of 32-token tiles staged
+// in LDS.  For every tile it RECOMPUTES pre = x0 W1^T + b1 and dh = d out W2 (tokens x hidden), applies the
+// activation and its derivative, and accumulates dW1^T = x0^T d pre and dW2 = d out^T hid with the tokens as the
+// contraction (transposing LDS reads give the [feature][token] fragments).  ~150 registers: two waves per SIMD.
 struct DwBigArgs {
   const T* z_in;        // (N, D): x0 = z_in[:, :h]
   const T* dSdT;        // (K, 2, N, h)
   const int64_t* mask;
   const int64_t* ptrs;  // device table [K][8] of the fp32 parameters (mivae_nice_pack's order)
   const float* bias;
-  float* part;          // [kn][c][slab][2][HT][64][16]
-  float* partb1;        // [kn][c][slab][32]
+  float* part;          // [kn][hw][slab][2][2 HT][64][4]     hw = 16-wide hidden group
+  float* partb1;        // [kn][hw][slab][16]
   float* partb2;        // [kn][slab][hp]
   int64_t N;
-  int S, mask_div, D, K, h, H, HC, act;
+  int S, mask_div, D, K, h, H, HW, act;   // HW = Hp / 16
   int nslab, slab_tiles;
 };
 
-// LDS tile image: row-major [32 tokens][hp] bf16 with the 16-byte chunks of a row XOR-swizzled so that both the
-// row reads (ds_read_b128, k = features) and the transposing reads (ds_read_b64_tr_b16, k = tokens) are conflict free.
-__device__ __forceinline__ int swz(int row) { return ((row >> 2) & 3) | ((row & 3) << 2); }
+// LDS tile image: row-major [32 tokens][hp] bf16, the 16-byte chunks of a row XOR-swizzled by the row so that the
+// transposing reads (ds_read_b64_tr_b16: 4 token rows x 16 features per 16-lane group) are conflict free.
+__device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | (((row >> 2) & 1) << 1) | ((row >> 3) & 1); }
 
 typedef __bf16 bf16x4v __attribute__((__vector_size__(4 * sizeof(__bf16))));
 #define BIG_LDS __attribute__((address_space(3)))
 
-// A fragment with k = tokens in the order from_acc() gives the other operand:
-// f[j] = tile[16 s + 8 (j >> 2) + 4 hh + (j & 3)][32 t + r32]
-template <int HPB>   // row bytes
-__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int t, int s, int lane) {
+// byte offsets (within a tile) of the two transposing reads of A fragment v: A[feature 16 v + (lane & 15)][k-slot]
+// with k = tokens in pair_to_b()'s order: slot (g, j) = token (j < 4 ? 4 g + j : 16 + 4 g + j - 4)
+template <int HPB>
+__device__ __forceinline__ void tr_offsets(int v, int lane, int& o0, int& o1) {
   const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-  const int hh = g >> 1;
-  const int row0 = 16 * s + 4 * hh + q;          // rows row0 and row0 + 8
-  const int chunk = 4 * t + 2 * (g & 1) + (p >> 1);
-  const int sub = 8 * (p & 1);
-  const char* a0 = tile + row0 * HPB + ((chunk ^ swz(row0)) << 4) + sub;
-  const char* a1 = tile + (row0 + 8) * HPB + ((chunk ^ swz(row0 + 8)) << 4) + sub;
-  const bf16x4v v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((BIG_LDS bf16x4v*)(a0));
-  const bf16x4v v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((BIG_LDS bf16x4v*)(a1));
+  const int row0 = 4 * g + q, row1 = 16 + 4 * g + q;
+  const int chunk = 2 * v + (p >> 1), sub = 8 * (p & 1);
+  o0 = row0 * HPB + ((chunk ^ swz(row0)) << 4) + sub;
+  o1 = row1 * HPB + ((chunk ^ swz(row1)) << 4) + sub;
+}
+__device__ __forceinline__ bf16x8 tr_read(const char* tile, int o0, int o1) {
+  const bf16x4v v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((BIG_LDS bf16x4v*)(tile + o0));
+  const bf16x4v v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((BIG_LDS bf16x4v*)(tile + o1));
   const auto v = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
   return __builtin_bit_cast(bf16x8, v);
 }
+// value and derivative of the activation on the two token sub-tiles of a (32 tokens x 16 hidden) block
+template <int ACT>
+__device__ __forceinline__ void act_pair_fd(int act, f32x4& lo, f32x4& hi, f32x4& dlo, f32x4& dhi) {
+  if constexpr (ACT == ACT_GELU) {
+    f32x8v x = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}, a, q, e, d;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) a[r] = __builtin_amdgcn_fmed3f(fabsf(x[r]), 0.f, 5.0f);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) q[r] = fmaf(kGq3, a[r], kGq2);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) e[r] = x[r] * x[r];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) q[r] = fmaf(q[r], a[r], kGq1);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) e[r] = __builtin_amdgcn_exp2f(e[r] * -0.72134752044448170f);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) q[r] = fmaf(q[r], a[r], kGq0);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) q[r] = __builtin_amdgcn_exp2f(fmaf(q[r], a[r], -1.0f));   // Phi(-|x|)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) e[r] *= x[r] * kInvSqrt2Pi;                                 // x phi(x)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) d[r] = (x[r] > 0.f ? 1.0f - q[r] : q[r]) + e[r];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) x[r] = fmaf(-fabsf(x[r]), q[r], relu1(x[r]));
+    lo = f32x4{x[0], x[1], x[2], x[3]}; hi = f32x4{x[4], x[5], x[6], x[7]};
+    dlo = f32x4{d[0], d[1], d[2], d[3]}; dhi = f32x4{d[4], d[5], d[6], d[7]};
+  } else {
+    f32x16 t, d;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { t[r] = lo[r]; t[4 + r] = hi[r]; t[8 + r] = 0.f; t[12 + r] = 0.f; }
+    act_tile_fd<-1, true>(act, t, d);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { lo[r] = t[r]; hi[r] = t[4 + r]; dlo[r] = d[r]; dhi[r] = d[4 + r]; }
+  }
+}
 
 template <int HT, int ACT>
-__global__ void __launch_bounds__(256) k_big_dw(DwBigArgs a) {
+__global__ void __launch_bounds__(HT <= 4 ? 512 : 256) k_big_dw(DwBigArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NKS = 2 * HT;
+  constexpr int NF = 2 * HT;                // 16-feature tiles of the h features
   constexpr int HPB = HT * 64;              // bytes per tile row
   constexpr int TILE = 32 * HPB;            // bytes per operand tile
-  constexpr int CPT = TILE / 16 / 256;      // 16-byte chunks per thread and operand tile (HT/2)
+  constexpr int NW = HT <= 4 ? 8 : 4;       // waves per block: two per SIMD when the accumulators leave room, else one
+  constexpr int NTH = 64 * NW;
+  constexpr int CPT = TILE / 16 / NTH;      // 16-byte chunks per thread and operand tile
+  static_assert(CPT >= 1, "tile too small for the block");
   const int lane = threadIdx.x & 63;
-  const int r32 = lane & 31, hh = lane >> 5;
+  const int r16 = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int slab = blockIdx.x, kn = blockIdx.y, c = blockIdx.z * 4 + wave;
-  const int h = a.h, HC = a.HC;
-  const bool wave_on = c < HC;
-  // my task in the ST_NETS stream: kk = K-1-k, task = (kk * 2 + net) * HC + c
+  const int slab = blockIdx.x, kn = blockIdx.y, hw = blockIdx.z * NW + wave;
+  const int h = a.h;
+  const bool wave_on = hw < a.HW;
   const int k = kn >> 1, net = kn & 1;
-  bf16x8 w1f[NKS], w2f[NKS];
+  const int hid = 16 * hw + r16;            // this lane's hidden unit (column of the products)
+  bf16x8 w1f[HT], w2f[HT];
   float b1v = 0.f;
   if (wave_on) {
-    // stationary operands as B fragments (col = hidden unit 32c + r32, k natural): W1[hid][16ks + 8hh + j] and
-    // W2[16ks + 8hh + j][hid], rounded to bf16 exactly like the packed streams of the other kernels
+    // stationary operands as B fragments (col = hidden unit, k natural): W1[hid][32ks + 8g + j], W2[32ks + 8g + j][hid],
+    // rounded to bf16 exactly like the packed streams of the other kernels
     const float* W1 = reinterpret_cast<const float*>(a.ptrs[k * 8 + net * 4 + 0]);
     const float* W2 = reinterpret_cast<const float*>(a.ptrs[k * 8 + net * 4 + 2]);
-    const int hid = 32 * c + r32;
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
+    for (int ks = 0; ks < HT; ++ks) {
       u16x8 r1 = {0, 0, 0, 0, 0, 0, 0, 0}, r2 = r1;
 #pragma unroll
       for (int jj = 0; jj < 8; ++jj) {
-        const int f = 16 * ks + 8 * hh + jj;
+        const int f = 32 * ks + 8 * g + jj;
         if (hid < a.H && f < h) {
           r1[jj] = f32_to_bf16(W1[(int64_t)hid * h + f]);
           r2[jj] = f32_to_bf16(W2[(int64_t)f * a.H + hid]);
@@ -958,44 +1001,53 @@ __global__ void __launch_bounds__(256) k_big_dw(DwBigArgs a) {
       }
       w1f[ks] = __builtin_bit_cast(bf16x8, r1); w2f[ks] = __builtin_bit_cast(bf16x8, r2);
     }
-    b1v = a.bias[(int64_t)kn * kBiasBlockFloats + 32 * c + r32];
+    b1v = a.bias[(int64_t)kn * kBiasBlockFloats + hid];   // zero beyond H (padded block)
   }
-  f32x16 dW1[HT], dW2[HT];
+  f32x4 dW1[NF], dW2[NF];
 #pragma unroll
-  for (int t = 0; t < HT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { dW1[t][r] = 0.f; dW2[t][r] = 0.f; }
+  for (int v = 0; v < NF; ++v) { dW1[v] = f32x4{0.f, 0.f, 0.f, 0.f}; dW2[v] = dW1[v]; }
   float db1 = 0.f;
-  float db2[HT];
+  float db2[NF];
 #pragma unroll
-  for (int t = 0; t < HT; ++t) db2[t] = 0.f;
+  for (int v = 0; v < NF; ++v) db2[v] = 0.f;
   const bool want_b2 = blockIdx.z == 0 && wave == 0;
 
-  // staging: thread -> (row, chunk) of each operand tile
-  const T* dO = a.dSdT + (int64_t)kn * a.N * h;
+  // staging: thread -> (row, chunk) of each operand tile; source pointers advance by one tile per body
   const int64_t tile0 = (int64_t)slab * a.slab_tiles;
   int64_t ntiles = (a.N + 31) / 32 - tile0;
   if (ntiles > a.slab_tiles) ntiles = a.slab_tiles;
+  int soff[CPT], srow[CPT];
+  const T* px[CPT];
+  const T* pg[CPT];
+  bool sfeat[CPT];
+#pragma unroll
+  for (int u = 0; u < CPT; ++u) {
+    const int id = threadIdx.x + NTH * u;
+    const int row = id / (HPB / 16), ch = id % (HPB / 16);
+    srow[u] = row;
+    soff[u] = row * HPB + ((ch ^ swz(row)) << 4);
+    sfeat[u] = ch * 8 < h;
+    px[u] = a.z_in + (tile0 * 32 + row) * a.D + ch * 8;
+    pg[u] = a.dSdT + ((int64_t)kn * a.N + tile0 * 32 + row) * h + ch * 8;
+  }
   u16x8 sx[CPT], sg[CPT];
-  auto gload = [&](int64_t tile) {
+  auto gload = [&](int64_t n) {   // tile tile0 + n (zeros outside the slab / N / the mask)
 #pragma unroll
     for (int u = 0; u < CPT; ++u) {
-      const int id = threadIdx.x + 256 * u;
-      const int row = id / (HPB / 16), ch = id % (HPB / 16);
-      const int64_t tk = tile * 32 + row;
-      u16x8 vx = {0, 0, 0, 0, 0, 0, 0, 0}, vg = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (tile - tile0 < ntiles && tk < a.N && ch * 8 < h) {
+      const int64_t tk = (tile0 + n) * 32 + srow[u];
+      u16x8 vx = {0, 0, 0, 0, 0, 0, 0, 0}, vg = vx;
+      if (n < ntiles && tk < a.N && sfeat[u]) {
         bool keep = true;
         if (a.mask) {
-          if (a.mask_div == 1) keep = a.mask[tk] != 0;       // (B, S) mask of a (B, S, D) latent: row-major == token index
+          if (a.mask_div == 1) keep = a.mask[tk] != 0;       // (B, S) mask of a (B, S, D) latent: index == token
           else {
             const int bn = (int)tk / a.S;
             keep = a.mask[(int64_t)(bn / a.mask_div) * a.S + ((int)tk - bn * a.S)] != 0;
           }
         }
         if (keep) {
-          vx = *reinterpret_cast<const u16x8*>(a.z_in + tk * a.D + ch * 8);
-          vg = *reinterpret_cast<const u16x8*>(dO + tk * h + ch * 8);
+          vx = *reinterpret_cast<const u16x8*>(px[u] + n * 32 * (int64_t)a.D);
+          vg = *reinterpret_cast<const u16x8*>(pg[u] + n * 32 * (int64_t)h);
         }
       }
       sx[u] = vx; sg[u] = vg;
@@ -1003,122 +1055,108 @@ __global__ void __launch_bounds__(256) k_big_dw(DwBigArgs a) {
   };
   auto lwrite = [&](int buf) {
     char* bx = smem + buf * 2 * TILE;
-    char* bg = bx + TILE;
 #pragma unroll
     for (int u = 0; u < CPT; ++u) {
-      const int id = threadIdx.x + 256 * u;
-      const int row = id / (HPB / 16), ch = id % (HPB / 16);
-      const int off = row * HPB + ((ch ^ swz(row)) << 4);
-      *reinterpret_cast<u16x8*>(bx + off) = sx[u];
-      *reinterpret_cast<u16x8*>(bg + off) = sg[u];
+      *reinterpret_cast<u16x8*>(bx + soff[u]) = sx[u];
+      *reinterpret_cast<u16x8*>(bx + TILE + soff[u]) = sg[u];
     }
   };
-  // Software pipeline over token tiles (4 LDS buffers): body n runs, in ONE basic block,
-  //   A(n+1): pre = x0 . W1^T + b1, dh = d out . W2        4 HT MFMAs on tile n+1 (row reads)
-  //   C(n-1): dW1 += x0^T . d pre, dW2 += d out^T . hid    4 HT MFMAs on tile n-1 (transposing reads)
-  //   B(n):   hid, act', d pre of tile n -> bf16 fragments  ~300 VALU
-  // while tile n+2 travels global -> registers -> LDS.  Tiles outside the slab are zeros (zero contributions), so
-  // the loop needs no peeling: bodies 0 .. ntiles.
+  // per-lane fragment offsets inside a tile
+  // (the swizzle touches only the low four chunk bits: chunks 16 and up repeat the pattern 256 bytes further on)
+  int ro[2][4];        // row reads: A[token 16 tt + r16][features 32 ks + 8 g ..]
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int row = 16 * tt + r16;
+      ro[tt][ks] = row * HPB + (((4 * ks + g) ^ swz(row)) << 4);
+    }
+  int to0[8], to1[8];
+#pragma unroll
+  for (int v = 0; v < 8; ++v) tr_offsets<HPB>(v, lane, to0[v], to1[v]);
+
+  // Software pipeline over the token tiles (4 LDS buffers): body n runs A(n+1) (pre, dh of tile n+1: row reads),
+  // C(n-1) (the two weight-gradient products of tile n-1: transposing reads) and B(n) (activation, VALU) while tile
+  // n+2 travels global -> registers -> LDS.  Tiles outside the slab are zeros, so bodies 0 .. ntiles need no peeling.
   {
     const u16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int u = 0; u < 2 * CPT; ++u)
-      *reinterpret_cast<u16x8*>(smem + 3 * 2 * TILE + (threadIdx.x + 256 * u) * 16) = zero;
+      *reinterpret_cast<u16x8*>(smem + 3 * 2 * TILE + (threadIdx.x + NTH * u) * 16) = zero;
   }
-  gload(tile0);
+  gload(0);
   lwrite(0);
-  gload(tile0 + 1);
+  gload(1);
   lwrite(1);
   __syncthreads();
-  const int rowoff = r32 * HPB, sw = swz(r32);
-  auto stage_a = [&](int buf, f32x16& pre, f32x16& dh) {
-    const char* bx = smem + buf * 2 * TILE;
+  auto stage_a = [&](const char* bx, f32x4 (&pre)[2], f32x4 (&dh)[2]) {
     const char* bg = bx + TILE;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { pre[r] = b1v; dh[r] = 0.f; }
+    for (int tt = 0; tt < 2; ++tt) { pre[tt] = f32x4{b1v, b1v, b1v, b1v}; dh[tt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-      const int ch = 2 * ks + hh;
-      const bf16x8 ax = *reinterpret_cast<const bf16x8*>(bx + rowoff + ((ch ^ sw) << 4));
-      const bf16x8 ag = *reinterpret_cast<const bf16x8*>(bg + rowoff + ((ch ^ sw) << 4));
-      pre = P::mma(ax, w1f[ks], pre);
-      dh = P::mma(ag, w2f[ks], dh);
-    }
+    for (int ks = 0; ks < HT; ++ks)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const bf16x8 ax = *reinterpret_cast<const bf16x8*>(bx + ro[tt][ks & 3] + (ks >> 2) * 256);
+        const bf16x8 ag = *reinterpret_cast<const bf16x8*>(bg + ro[tt][ks & 3] + (ks >> 2) * 256);
+        pre[tt] = mma16(ax, w1f[ks], pre[tt]);
+        dh[tt] = mma16(ag, w2f[ks], dh[tt]);
+      }
   };
-  f32x16 pre_c, dh_c;
-  if (wave_on) stage_a(0, pre_c, dh_c);
+  f32x4 pre_c[2], dh_c[2];
+  if (wave_on) stage_a(smem, pre_c, dh_c);
   const u16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
-  bf16x8 hb0 = __builtin_bit_cast(bf16x8, z8), hb1 = hb0, gb0 = hb0, gb1 = hb0;   // fragments of tile n-1
+  bf16x8 hb = __builtin_bit_cast(bf16x8, z8), gb = hb;   // fragments of tile n-1
 #pragma unroll 1
   for (int64_t n = 0; n <= ntiles; ++n) {
-    gload(tile0 + n + 2);
+    gload(n + 2);
     if (wave_on) {
-      const int bufc = (int)((n + 3) & 3);
-      const char* bx = smem + bufc * 2 * TILE;
-      const char* bg = bx + TILE;
-      if (want_b2) {   // db2 = sum over tokens of d out (one wave per (slab, step, net))
+      const char* bxc = smem + (int)((n + 3) & 3) * 2 * TILE;   // tile n-1
+      const char* bgc = bxc + TILE;
+      f32x4 pre_n[2], dh_n[2];
+      stage_a(smem + (int)((n + 1) & 3) * 2 * TILE, pre_n, dh_n);
 #pragma unroll
-        for (int t = 0; t < HT; ++t) {
-          const bf16x8 g0a = tr_frag<HPB>(bg, t, 0, lane), g0b = tr_frag<HPB>(bg, t, 1, lane);
+      for (int v = 0; v < NF; ++v) {
+        const bf16x8 x0a = tr_read(bxc + (v >> 3) * 256, to0[v & 7], to1[v & 7]);
+        const bf16x8 g0a = tr_read(bgc + (v >> 3) * 256, to0[v & 7], to1[v & 7]);
+        dW1[v] = mma16(x0a, gb, dW1[v]);
+        dW2[v] = mma16(g0a, hb, dW2[v]);
+        if (want_b2) {   // db2 = sum over tokens of d out (one wave per (slab, step, net))
           float s = 0.f;
 #pragma unroll
-          for (int jj = 0; jj < 8; ++jj) s += (float)g0a[jj] + (float)g0b[jj];
-          db2[t] += s;
+          for (int jj = 0; jj < 8; ++jj) s += (float)g0a[jj];
+          db2[v] += s;
         }
       }
-      f32x16 pre_n, dh_n;
-      stage_a((int)((n + 1) & 3), pre_n, dh_n);
+      f32x4 dlo, dhi;
+      act_pair_fd<ACT>(a.act, pre_c[0], pre_c[1], dlo, dhi);   // pre_c := hidden activations of tile n
 #pragma unroll
-      for (int t = 0; t < HT; ++t) {
-        const bf16x8 x0a = tr_frag<HPB>(bx, t, 0, lane), x0b = tr_frag<HPB>(bx, t, 1, lane);
-        const bf16x8 g0a = tr_frag<HPB>(bg, t, 0, lane), g0b = tr_frag<HPB>(bg, t, 1, lane);
-        dW1[t] = P::mma(x0a, gb0, dW1[t]);
-        dW1[t] = P::mma(x0b, gb1, dW1[t]);
-        dW2[t] = P::mma(g0a, hb0, dW2[t]);
-        dW2[t] = P::mma(g0b, hb1, dW2[t]);
-      }
-      f32x16 dact;
-      big_act_fd<ACT>(a.act, pre_c, dact);   // pre_c := hidden activations of tile n
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { dh_c[r] *= dact[r]; db1 += dh_c[r]; }
-      hb0 = P::from_acc<0>(pre_c); hb1 = P::from_acc<1>(pre_c);
-      gb0 = P::from_acc<0>(dh_c); gb1 = P::from_acc<1>(dh_c);
-      pre_c = pre_n; dh_c = dh_n;
-      constexpr int VPM = HT <= 4 ? 9 : 5;
-      __builtin_amdgcn_sched_group_barrier(SG_DS_READ, 8, 0);
-      __builtin_amdgcn_sched_group_barrier(SG_VALU, 16, 0);
-#pragma unroll
-      for (int q = 0; q < 4 * HT; ++q) {
-        __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(SG_DS_READ, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(SG_VALU, VPM, 0);
-        __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(SG_VALU, VPM, 0);
-      }
+      for (int r = 0; r < 4; ++r) { dlo[r] *= dh_c[0][r]; dhi[r] *= dh_c[1][r]; db1 += dlo[r] + dhi[r]; }
+      hb = pair_to_b(pre_c[0], pre_c[1]);
+      gb = pair_to_b(dlo, dhi);
+      pre_c[0] = pre_n[0]; pre_c[1] = pre_n[1]; dh_c[0] = dh_n[0]; dh_c[1] = dh_n[1];
     }
     lwrite((int)((n + 2) & 3));
     __syncthreads();
   }
   if (!wave_on) return;
-  // dump: accumulator element (reg r, lane) of dW1[t] = d W1[hidden 32c + lane&31][in 32t + acc_row(r, hh)]
-  const int64_t item = ((int64_t)kn * HC + c) * a.nslab + slab;
-  float* out = a.part + (item * 2 * HT) * 1024 + lane * 16;
+  // dump: register r of lane of dW1[v] = d W1[hidden 16 hw + (lane & 15)][in 16 v + 4 (lane >> 4) + r]
+  const int64_t item = ((int64_t)kn * a.HW + hw) * a.nslab + slab;
+  float* out = a.part + item * (2 * NF * 256) + lane * 4;
 #pragma unroll
-  for (int t = 0; t < HT; ++t)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      f32x4 v1 = {dW1[t][4 * q], dW1[t][4 * q + 1], dW1[t][4 * q + 2], dW1[t][4 * q + 3]};
-      f32x4 v2 = {dW2[t][4 * q], dW2[t][4 * q + 1], dW2[t][4 * q + 2], dW2[t][4 * q + 3]};
-      *reinterpret_cast<f32x4*>(out + (int64_t)t * 1024 + 4 * q) = v1;
-      *reinterpret_cast<f32x4*>(out + (int64_t)(HT + t) * 1024 + 4 * q) = v2;
-    }
+  for (int v = 0; v < NF; ++v) {
+    *reinterpret_cast<f32x4*>(out + v * 256) = dW1[v];
+    *reinterpret_cast<f32x4*>(out + (NF + v) * 256) = dW2[v];
+  }
+  db1 += __shfl_xor(db1, 16, 64);
   db1 += __shfl_xor(db1, 32, 64);
-  if (hh == 0) a.partb1[item * 32 + r32] = db1;
+  if (g == 0) a.partb1[item * 16 + r16] = db1;
   if (want_b2) {
 #pragma unroll
-    for (int t = 0; t < HT; ++t) {
-      const float s = db2[t] + __shfl_xor(db2[t], 32, 64);
-      if (hh == 0) a.partb2[((int64_t)kn * a.nslab + slab) * (32 * HT) + 32 * t + r32] = s;
+    for (int v = 0; v < NF; ++v) {
+      float s = db2[v] + __shfl_xor(db2[v], 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      if (g == 0) a.partb2[((int64_t)kn * a.nslab + slab) * (16 * NF) + 16 * v + r16] = s;
     }
   }
 }
@@ -1127,32 +1165,32 @@ struct DwRedArgs {
   const float *part, *partb1, *partb2;
   float *dW1, *db1, *dW2, *db2;   // (K, 2, H, h), (K, 2, H), (K, 2, h, H), (K, 2, h)
   const int64_t* sink;            // optional device table [K*2][4] of fp32 gradient addresses {W1, b1, W2, b2}: +=
-  int K, h, H, HT, HC, nslab;
+  int K, h, H, HT, HW, nslab;
 };
 // One thread per dumped accumulator element: sums the slabs in slab order (fixed order => bit-reproducible).
 __global__ void __launch_bounds__(256) k_big_dw_reduce(DwRedArgs a) {
-  const int64_t n1 = (int64_t)a.K * 2 * a.HC * 2 * a.HT * 1024;
-  const int64_t nb1 = (int64_t)a.K * 2 * a.HC * 32, nb2 = (int64_t)a.K * 2 * a.HT * 32;
+  const int NF = 2 * a.HT;
+  const int64_t per_item = (int64_t)2 * NF * 256;
+  const int64_t n1 = (int64_t)a.K * 2 * a.HW * per_item;
+  const int64_t nb1 = (int64_t)a.K * 2 * a.HW * 16, nb2 = (int64_t)a.K * 2 * NF * 16;
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < n1) {
-    const int e = (int)(idx & 1023);
-    int64_t q = idx >> 10;
-    const int tt = (int)(q % (2 * a.HT)); q /= 2 * a.HT;
-    const int c = (int)(q % a.HC);
-    const int kn = (int)(q / a.HC);
-    const float* p = a.part + ((((int64_t)kn * a.HC + c) * a.nslab) * 2 * a.HT + tt) * 1024 + e;
-    const int64_t stride = (int64_t)2 * a.HT * 1024;
+    const int e = (int)(idx % per_item);
+    const int64_t q = idx / per_item;
+    const int hw = (int)(q % a.HW);
+    const int kn = (int)(q / a.HW);
+    const float* p = a.part + (((int64_t)kn * a.HW + hw) * a.nslab) * per_item + e;
     float s = 0.f;
-    for (int sl = 0; sl < a.nslab; ++sl) s += p[sl * stride];
-    const int r = e & 15, ln = e >> 4;
-    const int hid = 32 * c + (ln & 31);
-    const int t = tt % a.HT;
-    const int feat = 32 * t + acc_row(r, ln >> 5);
+    for (int sl = 0; sl < a.nslab; ++sl) s += p[sl * per_item];
+    const int tt = e >> 8, ln = (e >> 2) & 63, r = e & 3;
+    const int hid = 16 * hw + (ln & 15);
+    const int v = tt % NF;
+    const int feat = 16 * v + 4 * (ln >> 4) + r;
     if (hid >= a.H || feat >= a.h) return;
-    if (tt < a.HT) {   // dW1[hid][feat]
+    if (tt < NF) {   // dW1[hid][feat]
       if (a.sink) reinterpret_cast<float*>(a.sink[kn * 4 + 0])[(int64_t)hid * a.h + feat] += s;
       else a.dW1[((int64_t)kn * a.H + hid) * a.h + feat] = s;
-    } else {           // dW2[feat][hid]
+    } else {         // dW2[feat][hid]
       if (a.sink) reinterpret_cast<float*>(a.sink[kn * 4 + 2])[(int64_t)feat * a.H + hid] += s;
       else a.dW2[((int64_t)kn * a.h + feat) * a.H + hid] = s;
     }
@@ -1160,22 +1198,22 @@ __global__ void __launch_bounds__(256) k_big_dw_reduce(DwRedArgs a) {
   }
   idx -= n1;
   if (idx < nb1) {
-    const int col = (int)(idx & 31);
-    int64_t q = idx >> 5;
-    const int c = (int)(q % a.HC);
-    const int kn = (int)(q / a.HC);
-    const int hid = 32 * c + col;
+    const int col = (int)(idx & 15);
+    const int64_t q = idx >> 4;
+    const int hw = (int)(q % a.HW);
+    const int kn = (int)(q / a.HW);
+    const int hid = 16 * hw + col;
     if (hid >= a.H) return;
-    const float* p = a.partb1 + (((int64_t)kn * a.HC + c) * a.nslab) * 32 + col;
+    const float* p = a.partb1 + (((int64_t)kn * a.HW + hw) * a.nslab) * 16 + col;
     float s = 0.f;
-    for (int sl = 0; sl < a.nslab; ++sl) s += p[sl * 32];
+    for (int sl = 0; sl < a.nslab; ++sl) s += p[sl * 16];
     if (a.sink) reinterpret_cast<float*>(a.sink[kn * 4 + 1])[hid] += s;
     else a.db1[(int64_t)kn * a.H + hid] = s;
     return;
   }
   idx -= nb1;
   if (idx < nb2) {
-    const int hp = 32 * a.HT;
+    const int hp = 16 * NF;
     const int f = (int)(idx % hp);
     const int kn = (int)(idx / hp);
     if (f >= a.h) return;
@@ -1216,7 +1254,7 @@ static void launch_nets(const NetsArgs& a, unsigned grid, size_t lds, hipStream_
 template <int HT, int ACT>
 static void launch_dw(const DwBigArgs& a, dim3 grid, size_t lds, hipStream_t st) {
   (void)hipFuncSetAttribute((const void*)k_big_dw<HT, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  k_big_dw<HT, ACT><<<grid, 256, lds, st>>>(a);
+  k_big_dw<HT, ACT><<<grid, HT <= 4 ? 512 : 256, lds, st>>>(a);
 }
 #define BIG_DISPATCH(HTv, actv, CALL)                                           \
   do {                                                                          \
@@ -1233,7 +1271,8 @@ static size_t ring_lds(int HT, int ipb) {
 
 static void dw_big_geom(int64_t N, const BigGeom& g, int& nslab, int& slab_tiles) {
   const int64_t ntiles = (N + 31) / 32;
-  const int64_t blocks0 = (int64_t)g.K * 2 * ((g.HC + 3) / 4);
+  const int nw = g.HT <= 4 ? 8 : 4;                      // hidden 16-groups (waves) per block
+  const int64_t blocks0 = (int64_t)g.K * 2 * ((g.Hp / 16 + nw - 1) / nw);
   int64_t want = (768 + blocks0 - 1) / blocks0;          // ~3 blocks per CU in total
   const int64_t maxs = (ntiles + 15) / 16;               // at least 16 token tiles per slab
   if (want > maxs) want = maxs;
@@ -1315,7 +1354,7 @@ extern "C" int64_t mivae_nice_big_dw_workspace_floats(int64_t N, int64_t h, int6
   const BigGeom g = big_geom_inst((int)h, (int)H, (int)K);
   int nslab, slab_tiles;
   dw_big_geom(N, g, nslab, slab_tiles);
-  return (int64_t)K * 2 * g.HC * nslab * (2 * g.HT * 1024 + 32) + (int64_t)K * 2 * nslab * g.hp;
+  return (int64_t)K * 2 * (g.Hp / 16) * nslab * (4 * g.HT * 256 + 16) + (int64_t)K * 2 * nslab * g.hp;
 }
 
 // Backward of mivae_nice_big_fwd (forward direction): dz_in (N, D) and the parameter gradients.
@@ -1373,13 +1412,15 @@ extern "C" int mivae_nice_big_bwd(const void* z_in, const void* z_out, const voi
     DwBigArgs a = {};
     a.z_in = (const T*)z_in; a.dSdT = (const T*)dSdT; a.mask = mask; a.ptrs = ptr_table;
     a.bias = (const float*)packed_bias; a.N = N; a.S = (int)S; a.mask_div = (int)mask_div; a.D = (int)D; a.K = (int)K;
-    a.h = g.h; a.H = g.H; a.HC = g.HC; a.act = act;
+    a.h = g.h; a.H = g.H; a.act = act;
     dw_big_geom(N, g, a.nslab, a.slab_tiles);
-    const int64_t nitems = (int64_t)K * 2 * g.HC * a.nslab;
+    a.HW = g.Hp / 16;
+    const int64_t nitems = (int64_t)K * 2 * a.HW * a.nslab;
     a.part = workspace;
-    a.partb1 = workspace + nitems * 2 * g.HT * 1024;
-    a.partb2 = a.partb1 + nitems * 32;
-    dim3 dgrid((unsigned)a.nslab, (unsigned)(K * 2), (unsigned)((g.HC + 3) / 4));
+    a.partb1 = workspace + nitems * 4 * g.HT * 256;
+    a.partb2 = a.partb1 + nitems * 16;
+    const int nw = g.HT <= 4 ? 8 : 4;
+    dim3 dgrid((unsigned)a.nslab, (unsigned)(K * 2), (unsigned)((a.HW + nw - 1) / nw));
     const size_t dlds = (size_t)8 * 32 * g.HT * 64;   // 4 tile buffers x 2 operands
 #define CALL(HTc, ACTc) launch_dw<HTc, ACTc>(a, dgrid, dlds, st)
     BIG_DISPATCH(g.HT, act, CALL);
@@ -1387,11 +1428,11 @@ extern "C" int mivae_nice_big_bwd(const void* z_in, const void* z_out, const voi
     MIVAE_CHECK_LAUNCH("nice_big_dw");
     DwRedArgs r = {};
     r.part = a.part; r.partb1 = a.partb1; r.partb2 = a.partb2;
-    r.dW1 = dW1; r.db1 = db1; r.dW2 = dW2; r.db2 = db2; r.sink = nullptr;
-    r.K = (int)K; r.h = g.h; r.H = g.H; r.HT = g.HT; r.HC = g.HC; r.nslab = a.nslab;
+    r.dW1 = dW1; r.db1 = db1; r.dW2 = dW2; r.db2 = db2;
+    r.K = (int)K; r.h = g.h; r.H = g.H; r.HT = g.HT; r.HW = a.HW; r.nslab = a.nslab;
     // the sink table is [K][8] = {W1s,b1s,W2s,b2s,W1t,b1t,W2t,b2t}: exactly [kn][4] with kn = 2k + net
     r.sink = grad_ptrs;
-    const int64_t nthreads = (int64_t)K * 2 * g.HC * 2 * g.HT * 1024 + (int64_t)K * 2 * g.HC * 32 + (int64_t)K * 2 * g.HT * 32;
+    const int64_t nthreads = (int64_t)K * 2 * a.HW * 4 * g.HT * 256 + (int64_t)K * 2 * a.HW * 16 + (int64_t)K * 2 * 2 * g.HT * 16;
     k_big_dw_reduce<<<(unsigned)((nthreads + 255) / 256), 256, 0, st>>>(r);
     MIVAE_CHECK_LAUNCH("nice_big_dw_reduce");
   }
