@@ -15,6 +15,9 @@ LIB = os.path.join(LIBDIR, "libmivae.so")
 SOURCES = ["elementwise.hip", "nice_stack.hip", "nice_big.hip", "nll.hip", "optim.hip", "layernorm.hip", "linear.hip", "maf.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
          "-Wno-unused-result"]
+# The MFMA kernels keep their f32 VALU work single-issue: beside MFMAs a packed v_pk_*_f32 costs more than the two plain
+# instructions it replaces (MI355X_MICROARCH.md, "price of one filler beside MFMAs").
+EXTRA_FLAGS = {"nice_big.hip": ["-fno-slp-vectorize"]}
 
 
 def _newer(target, deps):
@@ -34,7 +37,7 @@ def build(force=False, verbose=True):
     def compile_one(pair):
         src, obj = pair
         if force or _newer(obj, [src] + headers):
-            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

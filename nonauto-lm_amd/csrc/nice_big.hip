@@ -21,6 +21,7 @@
 //      k_big_dw            weight-stationary: a block owns (step, net, 4 hidden chunks), streams token tiles through
 //                          LDS, RECOMPUTES hidden / d pre (two small products) and accumulates dW1, dW2, db1, db2
 //                          in registers; token slabs are summed in fixed order by k_big_dw_reduce (no atomics).
+#include <type_traits>
 #include "nice_common.hpp"
 #include <stdlib.h>
 
@@ -458,6 +459,15 @@ __device__ __forceinline__ void act_pair_d(int act, const f32x4& lo, const f32x4
 // four consecutive floats from LDS (biases of features 16 v + 4 g + {0..3})
 __device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
+// d s_k, d t_k of a padding token are zeros: the weight-gradient kernel reads every row below N unmasked
+__device__ __forceinline__ void zero_dsdt_rows(T* dSdT, int64_t N, int K, int h, int64_t tok, int g) {
+  const u16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int kn = 0; kn < 2 * K; ++kn) {
+    T* row = dSdT + ((int64_t)kn * N + tok) * h;
+    for (int f = 8 * g; f < h; f += 32) *reinterpret_cast<u16x8*>(row + f) = zero;
+  }
+}
+
 template <int HT, int MODE, int ACT>
 __global__ void __launch_bounds__(512) k_big_chain(BigArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -490,6 +500,7 @@ __global__ void __launch_bounds__(512) k_big_chain(BigArgs a) {
       if (MODE == M_CHAIN) {
         T* drow = a.dz_in + tok * a.D + h;
         for (int f = 8 * g; f < h; f += 32) *reinterpret_cast<u16x8*>(drow + f) = zero;
+        zero_dsdt_rows(a.dSdT, a.N, a.K, h, tok, g);
       } else {
         T* orow = a.z_out + tok * a.D;
         for (int f = 8 * g; f < a.D; f += 32) *reinterpret_cast<u16x8*>(orow + f) = zero;
@@ -566,6 +577,7 @@ __global__ void __launch_bounds__(512) k_big_chain(BigArgs a) {
   // The loop nest is written twice -- with and without the arithmetic -- so that the live path carries its register
   // tiles through straight-line loops without conditional merges.
   if (!live) {
+    if (MODE == M_CHAIN && valid) zero_dsdt_rows(a.dSdT, a.N, a.K, h, tok, g);
     int i = 0;
     for (int j = 0; j < NJ; ++j)
       for (int c = 0; c < HC; ++c, ++i) {
@@ -593,11 +605,37 @@ __global__ void __launch_bounds__(512) k_big_chain(BigArgs a) {
         //   L2(i): acc[v] += W2 frags . hid(i);  L1(i+2): (a2l, a2h) = b1 + W1 frags . x0;  act(i+1) -> hid(i+1)
         const bf16x8* w2 = reinterpret_cast<const bf16x8*>(it2) + lane;
         f32x4 a2l, a2h;
+        if constexpr (HT <= 4) {
+          // Phases pinned in program order: all fragment reads of the body first, the activation (VALU) while they
+          // are in flight, then the MFMAs back to back.  Left to itself the scheduler keeps the reads one MFMA ahead,
+          // which exposes the LDS latency at every other MFMA; the co-resident wave fills the VALU / MFMA phases.
+          const bf16x8* w1 = reinterpret_cast<const bf16x8*>(it1) + lane;
+          const float* b1c = bias_lds + (j2 & 3) * kBiasBlockFloats + 32 * c2;
+          bf16x8 f2[NF], f1[2 * HT];
 #pragma unroll
-        for (int v = 0; v < NF; ++v) acc[v] = mma16(w2[v * 64], hb, acc[v]);
-        l1(it1, bias_lds + (j2 & 3) * kBiasBlockFloats + 32 * c2, a2l, a2h);
-        act_pair<ACT>(a.act, a1l, a1h);
-        hb = pair_to_b(a1l, a1h);
+          for (int v = 0; v < NF; ++v) f2[v] = w2[v * 64];
+#pragma unroll
+          for (int u = 0; u < 2 * HT; ++u) f1[u] = w1[u * 64];
+          a2l = lds4(b1c + 4 * g); a2h = lds4(b1c + 16 + 4 * g);
+          __builtin_amdgcn_sched_barrier(0);
+          act_pair<ACT>(a.act, a1l, a1h);
+          const bf16x8 hbn = pair_to_b(a1l, a1h);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int v = 0; v < NF; ++v) acc[v] = mma16(f2[v], hb, acc[v]);
+#pragma unroll
+          for (int ks = 0; ks < HT; ++ks) {
+            a2l = mma16(f1[ks], x0f[ks], a2l);
+            a2h = mma16(f1[HT + ks], x0f[ks], a2h);
+          }
+          hb = hbn;
+        } else {
+#pragma unroll
+          for (int v = 0; v < NF; ++v) acc[v] = mma16(w2[v * 64], hb, acc[v]);
+          l1(it1, bias_lds + (j2 & 3) * kBiasBlockFloats + 32 * c2, a2l, a2h);
+          act_pair<ACT>(a.act, a1l, a1h);
+          hb = pair_to_b(a1l, a1h);
+        }
         a1l = a2l; a1h = a2h;
       }
       // ---- fold the finished net into the chain
@@ -905,7 +943,11 @@ struct DwBigArgs {
 
 // LDS tile image: row-major [32 tokens][hp] bf16, the 16-byte chunks of a row XOR-swizzled by the row so that the
 // transposing reads (ds_read_b64_tr_b16: 4 token rows x 16 features per 16-lane group) are conflict free.
-__device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | (((row >> 2) & 1) << 1) | ((row >> 3) & 1); }
+// Both read patterns are conflict free with it: a transposing read's 32-lane group covers rows 4 g + q (two g) x chunk
+// pairs, told apart by bits 3:1; a ds_read_b128's 16-lane group is lanes {0-3, 12-15} of one 16-lane quarter plus lanes
+// {4-11} of its neighbour (chunk index differing in bit 0), i.e. rows r with chunk bit 0 flipped for 4 <= r <= 11:
+// (r1, r0, r2, r2 ^ r3) is still a bijection of the 16 rows onto the 16 chunks.
+__device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | (((row >> 2) & 1) << 1); }
 
 typedef __bf16 bf16x4v __attribute__((__vector_size__(4 * sizeof(__bf16))));
 #define BIG_LDS __attribute__((address_space(3)))
@@ -963,25 +1005,37 @@ __device__ __forceinline__ void act_pair_fd(int act, f32x4& lo, f32x4& hi, f32x4
   }
 }
 
-template <int HT, int ACT>
-__global__ void __launch_bounds__(HT <= 4 ? 512 : 256) k_big_dw(DwBigArgs a) {
+// 16 bytes per lane global -> LDS (wave-uniform destination base, lanes land 16 bytes apart), issued behind the
+// compiler's back: after a __builtin_amdgcn_global_load_lds it cannot prove disjoint from a later LDS read, hipcc's
+// wait-count pass puts s_waitcnt vmcnt(0) in front of that read, which would expose the whole global latency in
+// every loop body here.  The kernel orders the DMA itself (finish_tile's wait + the block barrier).
+__device__ __forceinline__ void dma16(const void* src, void* lds_wave_base) {
+  const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_t*)lds_wave_base);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(src) : "memory", "m0");
+}
+
+// PART: 0 = both weight gradients in one pass (h <= 128); 1 = d W1, d b1; 2 = d W2, d b2 (h > 128: the accumulators of
+// one product fill the registers two waves per SIMD leave, so the products take a pass each).
+template <int HT, int ACT, int PART>
+__global__ void __launch_bounds__(512) k_big_dw(DwBigArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NF = 2 * HT;                // 16-feature tiles of the h features
   constexpr int HPB = HT * 64;              // bytes per tile row
+  constexpr int CPR = HPB / 16;             // 16-byte chunks per tile row
   constexpr int TILE = 32 * HPB;            // bytes per operand tile
-  constexpr int NW = HT <= 4 ? 8 : 4;       // waves per block: two per SIMD when the accumulators leave room, else one
-  constexpr int NTH = 64 * NW;
+  constexpr int NTH = 512;
   constexpr int CPT = TILE / 16 / NTH;      // 16-byte chunks per thread and operand tile
+  constexpr bool DO1 = PART != 2, DO2 = PART != 1;
   static_assert(CPT >= 1, "tile too small for the block");
   const int lane = threadIdx.x & 63;
   const int r16 = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int slab = blockIdx.x, kn = blockIdx.y, hw = blockIdx.z * NW + wave;
+  const int slab = blockIdx.x, kn = blockIdx.y, hw = blockIdx.z * 8 + wave;
   const int h = a.h;
   const bool wave_on = hw < a.HW;
   const int k = kn >> 1, net = kn & 1;
   const int hid = 16 * hw + r16;            // this lane's hidden unit (column of the products)
-  bf16x8 w1f[HT], w2f[HT];
+  bf16x8 w1f[HT], w2f[DO1 ? HT : 1];
   float b1v = 0.f;
   if (wave_on) {
     // stationary operands as B fragments (col = hidden unit, k natural): W1[hid][32ks + 8g + j], W2[32ks + 8g + j][hid],
@@ -996,69 +1050,83 @@ __global__ void __launch_bounds__(HT <= 4 ? 512 : 256) k_big_dw(DwBigArgs a) {
         const int f = 32 * ks + 8 * g + jj;
         if (hid < a.H && f < h) {
           r1[jj] = f32_to_bf16(W1[(int64_t)hid * h + f]);
-          r2[jj] = f32_to_bf16(W2[(int64_t)f * a.H + hid]);
+          if (DO1) r2[jj] = f32_to_bf16(W2[(int64_t)f * a.H + hid]);
         }
       }
-      w1f[ks] = __builtin_bit_cast(bf16x8, r1); w2f[ks] = __builtin_bit_cast(bf16x8, r2);
+      w1f[ks] = __builtin_bit_cast(bf16x8, r1);
+      if (DO1) w2f[ks] = __builtin_bit_cast(bf16x8, r2);
     }
     b1v = a.bias[(int64_t)kn * kBiasBlockFloats + hid];   // zero beyond H (padded block)
   }
-  f32x4 dW1[NF], dW2[NF];
+  f32x4 dW1[DO1 ? NF : 1], dW2[DO2 ? NF : 1];
 #pragma unroll
-  for (int v = 0; v < NF; ++v) { dW1[v] = f32x4{0.f, 0.f, 0.f, 0.f}; dW2[v] = dW1[v]; }
+  for (int v = 0; v < (DO1 ? NF : 1); ++v) dW1[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int v = 0; v < (DO2 ? NF : 1); ++v) dW2[v] = f32x4{0.f, 0.f, 0.f, 0.f};
   float db1 = 0.f;
-  float db2[NF];
+  float db2[DO2 ? NF : 1];
 #pragma unroll
-  for (int v = 0; v < NF; ++v) db2[v] = 0.f;
-  const bool want_b2 = blockIdx.z == 0 && wave == 0;
+  for (int v = 0; v < (DO2 ? NF : 1); ++v) db2[v] = 0.f;
+  const bool want_b2 = DO2 && blockIdx.z == 0 && wave == 0;
 
-  // staging: thread -> (row, chunk) of each operand tile; source pointers advance by one tile per body
+  // ---- staging: LDS-DMA, 16 bytes per lane, NBUF tile buffers: tiles n-1, n, n+1 are in use by body n and PD = NBUF - 3
+  // tiles are in flight (tile n+2 lands by the end of body n).  Chunk id = threadIdx.x + NTH u of a tile lands at LDS byte 16 id (lane linear); the XOR
+  // swizzle is applied on the SOURCE side: position (row, pc) receives the row's chunk pc ^ swz(row).  Every row
+  // below N is read as it is (the chain kernel writes zero d s / d t rows for padding tokens); rows beyond N or beyond
+  // the slab are fetched from a clamped valid address and their d out chunks overwritten with zeros once the DMA has
+  // landed (x0 stays: finite values times d out = 0).  No compiler-visible global load remains in the loop, so the
+  // only vmcnt waits are the counted ones below.
+  constexpr int NBUF = HT <= 4 ? 6 : 4;
+  constexpr int PD = NBUF - 3;
   const int64_t tile0 = (int64_t)slab * a.slab_tiles;
-  int64_t ntiles = (a.N + 31) / 32 - tile0;
+  int ntiles = (int)((a.N + 31) / 32 - tile0);
   if (ntiles > a.slab_tiles) ntiles = a.slab_tiles;
-  int soff[CPT], srow[CPT];
-  const T* px[CPT];
-  const T* pg[CPT];
-  bool sfeat[CPT];
+  // lane offsets of the chunks against a per-tile scalar base (32-bit: a tile spans < 2^31 bytes)
+  int srow[CPT], scol[CPT], vox[CPT], vog[CPT];
 #pragma unroll
   for (int u = 0; u < CPT; ++u) {
     const int id = threadIdx.x + NTH * u;
-    const int row = id / (HPB / 16), ch = id % (HPB / 16);
-    srow[u] = row;
-    soff[u] = row * HPB + ((ch ^ swz(row)) << 4);
-    sfeat[u] = ch * 8 < h;
-    px[u] = a.z_in + (tile0 * 32 + row) * a.D + ch * 8;
-    pg[u] = a.dSdT + ((int64_t)kn * a.N + tile0 * 32 + row) * h + ch * 8;
+    const int row = id / CPR;
+    int sc = (id % CPR) ^ swz(row);
+    if (sc * 8 >= h) sc = h / 8 - 1;      // padded feature chunks: any finite in-row data (their weights are zero)
+    srow[u] = row; scol[u] = sc * 16;
+    vox[u] = row * a.D * 2 + sc * 16;
+    vog[u] = row * h * 2 + sc * 16;
   }
-  u16x8 sx[CPT], sg[CPT];
-  auto gload = [&](int64_t n) {   // tile tile0 + n (zeros outside the slab / N / the mask)
+  const char* gx = reinterpret_cast<const char*>(a.z_in);
+  const char* gg = reinterpret_cast<const char*>(a.dSdT + (int64_t)kn * a.N * h);
+  auto rows_of = [&](int n) -> int {      // rows of tile n that count (0 for tiles beyond the slab)
+    if (n >= ntiles) return 0;
+    const int64_t left = a.N - (tile0 + n) * 32;
+    return left < 32 ? (int)left : 32;
+  };
+  auto issue_tile = [&](int n, int buf) {   // tile tile0 + n -> buffer buf
+    const int nn = n < ntiles ? n : ntiles - 1;
+    const int64_t t0 = (tile0 + nn) * 32;
+    const int64_t left = a.N - t0;
+    const int lastrow = left < 32 ? (int)left - 1 : 31;
+    char* bx = smem + buf * 2 * TILE + wave * 1024;
+    const char* tx = gx + t0 * a.D * 2;                       // wave-uniform bases
+    const char* tg = gg + t0 * h * 2;
 #pragma unroll
     for (int u = 0; u < CPT; ++u) {
-      const int64_t tk = (tile0 + n) * 32 + srow[u];
-      u16x8 vx = {0, 0, 0, 0, 0, 0, 0, 0}, vg = vx;
-      if (n < ntiles && tk < a.N && sfeat[u]) {
-        bool keep = true;
-        if (a.mask) {
-          if (a.mask_div == 1) keep = a.mask[tk] != 0;       // (B, S) mask of a (B, S, D) latent: index == token
-          else {
-            const int bn = (int)tk / a.S;
-            keep = a.mask[(int64_t)(bn / a.mask_div) * a.S + ((int)tk - bn * a.S)] != 0;
-          }
-        }
-        if (keep) {
-          vx = *reinterpret_cast<const u16x8*>(px[u] + n * 32 * (int64_t)a.D);
-          vg = *reinterpret_cast<const u16x8*>(pg[u] + n * 32 * (int64_t)h);
-        }
-      }
-      sx[u] = vx; sg[u] = vg;
+      const bool inrow = srow[u] <= lastrow;
+      const unsigned ox = inrow ? vox[u] : lastrow * a.D * 2 + scol[u];
+      const unsigned og = inrow ? vog[u] : lastrow * h * 2 + scol[u];
+      dma16(tx + ox, bx + u * NTH * 16);
+      dma16(tg + og, bx + TILE + u * NTH * 16);
     }
   };
-  auto lwrite = [&](int buf) {
-    char* bx = smem + buf * 2 * TILE;
+  auto finish_tile = [&](int n, int buf, auto pending) {  // tile n has landed once at most `pending` DMAs are in flight
+    __builtin_amdgcn_sched_barrier(0);   // the body's arithmetic stays above the wait
+    wait_vm<decltype(pending)::value>();
+    const int nrows = rows_of(n);
+    if (nrows < 32) {                    // zero the d out chunks of rows that do not count (wave-uniform branch)
+      char* bg = smem + buf * 2 * TILE + TILE + threadIdx.x * 16;
+      const u16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int u = 0; u < CPT; ++u) {
-      *reinterpret_cast<u16x8*>(bx + soff[u]) = sx[u];
-      *reinterpret_cast<u16x8*>(bx + TILE + soff[u]) = sg[u];
+      for (int u = 0; u < CPT; ++u)
+        if (srow[u] >= nrows) *reinterpret_cast<u16x8*>(bg + u * NTH * 16) = zero;
     }
   };
   // per-lane fragment offsets inside a tile
@@ -1076,18 +1144,19 @@ __global__ void __launch_bounds__(HT <= 4 ? 512 : 256) k_big_dw(DwBigArgs a) {
   for (int v = 0; v < 8; ++v) tr_offsets<HPB>(v, lane, to0[v], to1[v]);
 
   // Software pipeline over the token tiles (4 LDS buffers): body n runs A(n+1) (pre, dh of tile n+1: row reads),
-  // C(n-1) (the two weight-gradient products of tile n-1: transposing reads) and B(n) (activation, VALU) while tile
-  // n+2 travels global -> registers -> LDS.  Tiles outside the slab are zeros, so bodies 0 .. ntiles need no peeling.
-  {
+  // C(n-1) (the weight-gradient products of tile n-1: transposing reads) and B(n) (activation, VALU) while tile n+2
+  // travels global -> LDS.  Tiles outside the slab are zeros, so bodies 0 .. ntiles need no peeling.
+  {   // tile -1 (buffer NBUF - 1): zeros
     const u16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int u = 0; u < 2 * CPT; ++u)
-      *reinterpret_cast<u16x8*>(smem + 3 * 2 * TILE + (threadIdx.x + NTH * u) * 16) = zero;
+      *reinterpret_cast<u16x8*>(smem + (NBUF - 1) * 2 * TILE + (threadIdx.x + NTH * u) * 16) = zero;
   }
-  gload(0);
-  lwrite(0);
-  gload(1);
-  lwrite(1);
+  // tile t lives in buffer t % NBUF; prologue: tiles 0 .. PD issued, tiles 0 and 1 landed
+#pragma unroll
+  for (int t = 0; t < PD + 1; ++t) issue_tile(t, t);
+  finish_tile(0, 0, std::integral_constant<int, PD * 2 * CPT>{});
+  finish_tile(1, 1, std::integral_constant<int, (PD - 1) * 2 * CPT>{});
   __syncthreads();
   auto stage_a = [&](const char* bx, f32x4 (&pre)[2], f32x4 (&dh)[2]) {
     const char* bg = bx + TILE;
@@ -1098,59 +1167,79 @@ __global__ void __launch_bounds__(HT <= 4 ? 512 : 256) k_big_dw(DwBigArgs a) {
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
         const bf16x8 ax = *reinterpret_cast<const bf16x8*>(bx + ro[tt][ks & 3] + (ks >> 2) * 256);
-        const bf16x8 ag = *reinterpret_cast<const bf16x8*>(bg + ro[tt][ks & 3] + (ks >> 2) * 256);
         pre[tt] = mma16(ax, w1f[ks], pre[tt]);
-        dh[tt] = mma16(ag, w2f[ks], dh[tt]);
+        if (DO1) {
+          const bf16x8 ag = *reinterpret_cast<const bf16x8*>(bg + ro[tt][ks & 3] + (ks >> 2) * 256);
+          dh[tt] = mma16(ag, w2f[ks], dh[tt]);
+        }
       }
   };
   f32x4 pre_c[2], dh_c[2];
   if (wave_on) stage_a(smem, pre_c, dh_c);
   const u16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
   bf16x8 hb = __builtin_bit_cast(bf16x8, z8), gb = hb;   // fragments of tile n-1
+  int bm = NBUF - 1, bp = 1, bl = 2, bi = (1 + PD) % NBUF;
+  auto run = [&](auto with_b2) {   // (the d b2 sums of wave 0 live in their own copy of the loop: no branch per tile)
 #pragma unroll 1
-  for (int64_t n = 0; n <= ntiles; ++n) {
-    gload(n + 2);
+  for (int n = 0; n <= ntiles; ++n) {
+    // buffers: bm = tile n-1, bp = tile n+1, bl = tile n+2 (to land by the end of the body), bi = tile n+1+PD (issued
+    // now, into the buffer tile n-2 has left)
+    issue_tile(n + 1 + PD, bi);
     if (wave_on) {
-      const char* bxc = smem + (int)((n + 3) & 3) * 2 * TILE;   // tile n-1
+      const char* bxc = smem + bm * 2 * TILE;
       const char* bgc = bxc + TILE;
       f32x4 pre_n[2], dh_n[2];
-      stage_a(smem + (int)((n + 1) & 3) * 2 * TILE, pre_n, dh_n);
+      stage_a(smem + bp * 2 * TILE, pre_n, dh_n);
 #pragma unroll
       for (int v = 0; v < NF; ++v) {
-        const bf16x8 x0a = tr_read(bxc + (v >> 3) * 256, to0[v & 7], to1[v & 7]);
-        const bf16x8 g0a = tr_read(bgc + (v >> 3) * 256, to0[v & 7], to1[v & 7]);
-        dW1[v] = mma16(x0a, gb, dW1[v]);
-        dW2[v] = mma16(g0a, hb, dW2[v]);
-        if (want_b2) {   // db2 = sum over tokens of d out (one wave per (slab, step, net))
-          float s = 0.f;
+        if (DO1) {
+          const bf16x8 x0a = tr_read(bxc + (v >> 3) * 256, to0[v & 7], to1[v & 7]);
+          dW1[v] = mma16(x0a, gb, dW1[v]);
+        }
+        if (DO2) {
+          const bf16x8 g0a = tr_read(bgc + (v >> 3) * 256, to0[v & 7], to1[v & 7]);
+          dW2[v] = mma16(g0a, hb, dW2[v]);
+          if constexpr (decltype(with_b2)::value) {   // db2 = sum over tokens of d out (one wave per (slab, step, net))
+            float s = 0.f;
 #pragma unroll
-          for (int jj = 0; jj < 8; ++jj) s += (float)g0a[jj];
-          db2[v] += s;
+            for (int jj = 0; jj < 8; ++jj) s += (float)g0a[jj];
+            db2[v] += s;
+          }
         }
       }
-      f32x4 dlo, dhi;
-      act_pair_fd<ACT>(a.act, pre_c[0], pre_c[1], dlo, dhi);   // pre_c := hidden activations of tile n
+      if (DO1) {
+        f32x4 dlo, dhi;
+        act_pair_fd<ACT>(a.act, pre_c[0], pre_c[1], dlo, dhi);   // pre_c := hidden activations of tile n
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { dlo[r] *= dh_c[0][r]; dhi[r] *= dh_c[1][r]; db1 += dlo[r] + dhi[r]; }
-      hb = pair_to_b(pre_c[0], pre_c[1]);
-      gb = pair_to_b(dlo, dhi);
+        for (int r = 0; r < 4; ++r) { dlo[r] *= dh_c[0][r]; dhi[r] *= dh_c[1][r]; db1 += dlo[r] + dhi[r]; }
+        gb = pair_to_b(dlo, dhi);
+      } else {
+        act_pair<ACT>(a.act, pre_c[0], pre_c[1]);
+      }
+      if (DO2) hb = pair_to_b(pre_c[0], pre_c[1]);
       pre_c[0] = pre_n[0]; pre_c[1] = pre_n[1]; dh_c[0] = dh_n[0]; dh_c[1] = dh_n[1];
     }
-    lwrite((int)((n + 2) & 3));
+    finish_tile(n + 2, bl, std::integral_constant<int, (PD - 1) * 2 * CPT>{});
     __syncthreads();
+    bm = bm + 1 == NBUF ? 0 : bm + 1; bp = bp + 1 == NBUF ? 0 : bp + 1;
+    bl = bl + 1 == NBUF ? 0 : bl + 1; bi = bi + 1 == NBUF ? 0 : bi + 1;
   }
+  };
+  if (want_b2) run(std::true_type{}); else run(std::false_type{});
   if (!wave_on) return;
   // dump: register r of lane of dW1[v] = d W1[hidden 16 hw + (lane & 15)][in 16 v + 4 (lane >> 4) + r]
   const int64_t item = ((int64_t)kn * a.HW + hw) * a.nslab + slab;
   float* out = a.part + item * (2 * NF * 256) + lane * 4;
 #pragma unroll
   for (int v = 0; v < NF; ++v) {
-    *reinterpret_cast<f32x4*>(out + v * 256) = dW1[v];
-    *reinterpret_cast<f32x4*>(out + (NF + v) * 256) = dW2[v];
+    if (DO1) *reinterpret_cast<f32x4*>(out + v * 256) = dW1[v];
+    if (DO2) *reinterpret_cast<f32x4*>(out + (NF + v) * 256) = dW2[v];
   }
-  db1 += __shfl_xor(db1, 16, 64);
-  db1 += __shfl_xor(db1, 32, 64);
-  if (g == 0) a.partb1[item * 16 + r16] = db1;
+  if (DO1) {
+    db1 += __shfl_xor(db1, 16, 64);
+    db1 += __shfl_xor(db1, 32, 64);
+    if (g == 0) a.partb1[item * 16 + r16] = db1;
+  }
   if (want_b2) {
 #pragma unroll
     for (int v = 0; v < NF; ++v) {
@@ -1253,8 +1342,15 @@ static void launch_nets(const NetsArgs& a, unsigned grid, size_t lds, hipStream_
 }
 template <int HT, int ACT>
 static void launch_dw(const DwBigArgs& a, dim3 grid, size_t lds, hipStream_t st) {
-  (void)hipFuncSetAttribute((const void*)k_big_dw<HT, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  k_big_dw<HT, ACT><<<grid, HT <= 4 ? 512 : 256, lds, st>>>(a);
+  if constexpr (HT <= 4) {
+    (void)hipFuncSetAttribute((const void*)k_big_dw<HT, ACT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    k_big_dw<HT, ACT, 0><<<grid, 512, lds, st>>>(a);
+  } else {
+    (void)hipFuncSetAttribute((const void*)k_big_dw<HT, ACT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)k_big_dw<HT, ACT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    k_big_dw<HT, ACT, 1><<<grid, 512, lds, st>>>(a);
+    k_big_dw<HT, ACT, 2><<<grid, 512, lds, st>>>(a);
+  }
 }
 #define BIG_DISPATCH(HTv, actv, CALL)                                           \
   do {                                                                          \
@@ -1271,7 +1367,7 @@ static size_t ring_lds(int HT, int ipb) {
 
 static void dw_big_geom(int64_t N, const BigGeom& g, int& nslab, int& slab_tiles) {
   const int64_t ntiles = (N + 31) / 32;
-  const int nw = g.HT <= 4 ? 8 : 4;                      // hidden 16-groups (waves) per block
+  const int nw = 8;                                      // hidden 16-groups (waves) per block
   const int64_t blocks0 = (int64_t)g.K * 2 * ((g.Hp / 16 + nw - 1) / nw);
   int64_t want = (768 + blocks0 - 1) / blocks0;          // ~3 blocks per CU in total
   const int64_t maxs = (ntiles + 15) / 16;               // at least 16 token tiles per slab
@@ -1419,9 +1515,9 @@ extern "C" int mivae_nice_big_bwd(const void* z_in, const void* z_out, const voi
     a.part = workspace;
     a.partb1 = workspace + nitems * 4 * g.HT * 256;
     a.partb2 = a.partb1 + nitems * 16;
-    const int nw = g.HT <= 4 ? 8 : 4;
+    const int nw = 8;
     dim3 dgrid((unsigned)a.nslab, (unsigned)(K * 2), (unsigned)((a.HW + nw - 1) / nw));
-    const size_t dlds = (size_t)8 * 32 * g.HT * 64;   // 4 tile buffers x 2 operands
+    const size_t dlds = (size_t)(g.HT <= 4 ? 6 : 4) * 2 * 32 * g.HT * 64;   // NBUF tile buffers x 2 operands
 #define CALL(HTc, ACTc) launch_dw<HTc, ACTc>(a, dgrid, dlds, st)
     BIG_DISPATCH(g.HT, act, CALL);
 #undef CALL
