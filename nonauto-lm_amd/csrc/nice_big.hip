@@ -1179,45 +1179,97 @@ __global__ void __launch_bounds__(512) k_big_dw(DwBigArgs a) {
   const u16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
   bf16x8 hb = __builtin_bit_cast(bf16x8, z8), gb = hb;   // fragments of tile n-1
   int bm = NBUF - 1, bp = 1, bl = 2, bi = (1 + PD) % NBUF;
-  auto run = [&](auto with_b2) {   // (the d b2 sums of wave 0 live in their own copy of the loop: no branch per tile)
+  auto run = [&](auto with_b2) {   // (variants live in their own copies of the loop: no branch per tile)
 #pragma unroll 1
   for (int n = 0; n <= ntiles; ++n) {
     // buffers: bm = tile n-1, bp = tile n+1, bl = tile n+2 (to land by the end of the body), bi = tile n+1+PD (issued
     // now, into the buffer tile n-2 has left)
     issue_tile(n + 1 + PD, bi);
     if (wave_on) {
+      // Phases pinned in program order (sched_barrier): LDS reads are issued a whole phase ahead of the MFMAs that
+      // consume them -- left alone the scheduler keeps them one MFMA ahead and every other MFMA waits out the LDS
+      // latency.  reads of step 0 | reads 1 | [activation of tile n (VALU) before the first A chunk] MFMAs 0 | reads 2 | ...
+      const char* bxa = smem + bp * 2 * TILE;
+      const char* bga = bxa + TILE;
       const char* bxc = smem + bm * 2 * TILE;
       const char* bgc = bxc + TILE;
-      f32x4 pre_n[2], dh_n[2];
-      stage_a(smem + bp * 2 * TILE, pre_n, dh_n);
+      // steps: NKA chunks of A(n+1) (two k-steps each), then NCV chunks of C(n-1) (CV feature tiles each); the reads of
+      // step st+1 are issued before the MFMAs of step st, into the other half of fb
+      constexpr int KA = HT <= 4 ? 2 : 1;                       // k-steps per A chunk
+      constexpr int CV = (DO1 && DO2) ? 4 : (HT <= 4 ? 8 : 4);  // feature tiles per C chunk
+      constexpr int NCV = NF / CV, NKA = HT / KA, NST = NKA + NCV;
+      constexpr int QA = 2 * KA, FBN = HT <= 4 ? 8 : 4;         // fragments per chunk: x | g halves of fb[sl]
+      static_assert((DO1 ? 2 : 1) * QA <= FBN && ((DO1 && DO2) ? 2 : 1) * CV <= FBN, "fragment buffer too small");
+      bf16x8 fb[2][FBN];
+      auto reads = [&](int st, int sl) {
+        if (st < NKA) {
 #pragma unroll
-      for (int v = 0; v < NF; ++v) {
-        if (DO1) {
-          const bf16x8 x0a = tr_read(bxc + (v >> 3) * 256, to0[v & 7], to1[v & 7]);
-          dW1[v] = mma16(x0a, gb, dW1[v]);
-        }
-        if (DO2) {
-          const bf16x8 g0a = tr_read(bgc + (v >> 3) * 256, to0[v & 7], to1[v & 7]);
-          dW2[v] = mma16(g0a, hb, dW2[v]);
-          if constexpr (decltype(with_b2)::value) {   // db2 = sum over tokens of d out (one wave per (slab, step, net))
-            float s = 0.f;
+          for (int q = 0; q < QA; ++q) {
+            const int ks = KA * st + (q >> 1), off = ro[q & 1][ks & 3] + (ks >> 2) * 256;
+            fb[sl][q] = *reinterpret_cast<const bf16x8*>(bxa + off);
+            if (DO1) fb[sl][QA + q] = *reinterpret_cast<const bf16x8*>(bga + off);
+          }
+        } else {
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) s += (float)g0a[jj];
-            db2[v] += s;
+          for (int i = 0; i < CV; ++i) {
+            const int v = (st - NKA) * CV + i;
+            if (DO1) fb[sl][i] = tr_read(bxc + (v >> 3) * 256, to0[v & 7], to1[v & 7]);
+            if (DO2) fb[sl][(DO1 ? CV : 0) + i] = tr_read(bgc + (v >> 3) * 256, to0[v & 7], to1[v & 7]);
           }
         }
-      }
-      if (DO1) {
-        f32x4 dlo, dhi;
-        act_pair_fd<ACT>(a.act, pre_c[0], pre_c[1], dlo, dhi);   // pre_c := hidden activations of tile n
+      };
+      auto mfmas = [&](int st, int sl) {
+        if (st < NKA) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { dlo[r] *= dh_c[0][r]; dhi[r] *= dh_c[1][r]; db1 += dlo[r] + dhi[r]; }
-        gb = pair_to_b(dlo, dhi);
-      } else {
-        act_pair<ACT>(a.act, pre_c[0], pre_c[1]);
+          for (int q = 0; q < QA; ++q) {
+            const int ks = KA * st + (q >> 1);
+            pre_c[q & 1] = mma16(fb[sl][q], w1f[ks], pre_c[q & 1]);
+            if (DO1) dh_c[q & 1] = mma16(fb[sl][QA + q], w2f[ks], dh_c[q & 1]);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < CV; ++i) {
+            const int v = (st - NKA) * CV + i;
+            if (DO1) dW1[v] = mma16(fb[sl][i], gb, dW1[v]);
+            if (DO2) {
+              const bf16x8 gf = fb[sl][(DO1 ? CV : 0) + i];
+              dW2[v] = mma16(gf, hb, dW2[v]);
+              if constexpr (decltype(with_b2)::value) {   // db2 = sum over tokens of d out (one wave per (slab, step, net))
+                float sm = 0.f;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) sm += (float)gf[jj];
+                db2[v] += sm;
+              }
+            }
+          }
+        }
+      };
+      auto step_of = [](int i) { return i; };
+      bf16x8 hbn = hb, gbn = gb;
+      reads(step_of(0), 0);
+#pragma unroll
+      for (int i = 0; i < NST; ++i) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 1 < NST) reads(step_of(i + 1), (i + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (step_of(i) == 0) {   // the activation of tile n, right before the first A chunk overwrites pre_c / dh_c
+          if (DO1) {
+            f32x4 dlo, dhi;
+            act_pair_fd<ACT>(a.act, pre_c[0], pre_c[1], dlo, dhi);   // pre_c := hidden activations of tile n
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { dlo[r] *= dh_c[0][r]; dhi[r] *= dh_c[1][r]; db1 += dlo[r] + dhi[r]; }
+            gbn = pair_to_b(dlo, dhi);
+          } else {
+            act_pair<ACT>(a.act, pre_c[0], pre_c[1]);
+          }
+          if (DO2) hbn = pair_to_b(pre_c[0], pre_c[1]);
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) { pre_c[tt] = f32x4{b1v, b1v, b1v, b1v}; dh_c[tt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        mfmas(step_of(i), i & 1);
       }
-      if (DO2) hb = pair_to_b(pre_c[0], pre_c[1]);
-      pre_c[0] = pre_n[0]; pre_c[1] = pre_n[1]; dh_c[0] = dh_n[0]; dh_c[1] = dh_n[1];
+      hb = hbn; gb = gbn;
     }
     finish_tile(n + 2, bl, std::integral_constant<int, (PD - 1) * 2 * CPT>{});
     __syncthreads();
