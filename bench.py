@@ -28,6 +28,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 MFMA_BF16_PEAK_TFLOPS = 2500.0
+# dense MFMA peaks by compute dtype (MI355X_MICROARCH.md: bf16 ~2.5 PF; f32-input MFMA = the vector peak)
+MFMA_PEAK_TFLOPS = {"bf16": MFMA_BF16_PEAK_TFLOPS, "fp32": 157.3}
 
 CONFIGS = {
     #        B    S    D    H    K   dtype   ragged
@@ -120,19 +122,28 @@ def flow_kernel_times(model, tokens, dtype, reps=50, graph=True):
     z = torch.randn(B, S, D, device=dev).to(dtype)
     mask = ops.tokens_mask(tokens)
     spec = fused_stack_spec(prior._flows, z)
-    if spec is None:                # shape outside the fused stack kernel (D > 256): the step ran the composed path
+    if spec is None:                # not an all-NICE-FF stack the fused kernels take: the step ran the composed path
         return {}
     params, H, act = spec
     K = len(params) // 8
     code, N = L.dtype_code(dtype), B * S
+    big = ops.nice_big_supported(z, H)             # wide latents (97 <= D/2 <= 256, bf16): csrc/nice_big.hip
     hp, Hp = (h + 31) // 32 * 32, (H + 31) // 32 * 32
-    npad = L.query("mivae_nice_stack_npad", N)
-    packed = ops.nice_pack([p.detach() for p in params], K, h, H, dtype)
     e = lambda *shape, dt=dtype: torch.empty(*shape, dtype=dt, device=dev)
     z_out, hist, tok = e(B, S, D), e(K, N, h), e(N, dt=torch.float32)
     dz_out, dlog, dz_in = torch.randn(B, S, D, device=dev).to(dtype), torch.randn(N, device=dev), e(B, S, D)
-    Gt, Ht, dSt, x0t = e(K, 2, Hp, npad), e(K, 2, Hp, npad), e(K, 2, hp, npad), e(hp, npad)
-    ws = e(L.query("mivae_nice_dw_workspace_floats", N, h, H, K), dt=torch.float32)
+    plist = [p.detach() for p in params]
+    if big:
+        z = z * mask.unsqueeze(-1).to(dtype)       # what the posterior hands over: zeros at padding
+        pk_f, pk_b, pk_c, pk_n = (ops.nice_big_pack(plist, K, h, H, kind) for kind in ("fwd", "bias", "chain", "nets"))
+        ptab = ops._ptr_table(plist, dev)
+        dsdt = e(K, 2, N, h)
+        ws = e(L.query("mivae_nice_big_dw_workspace_floats", N, h, H, K), dt=torch.float32)
+    else:
+        npad = L.query("mivae_nice_stack_npad", N)
+        packed = ops.nice_pack(plist, K, h, H, dtype)
+        Gt, Ht, dSt, x0t = e(K, 2, Hp, npad), e(K, 2, Hp, npad), e(K, 2, hp, npad), e(hp, npad)
+        ws = e(L.query("mivae_nice_dw_workspace_floats", N, h, H, K), dt=torch.float32)
     dW1, db1, dW2, db2 = (e(K, 2, H, h, dt=torch.float32), e(K, 2, H, dt=torch.float32),
                           e(K, 2, h, H, dt=torch.float32), e(K, 2, h, dt=torch.float32))
     actid = ops.ACT_IDS[act]
@@ -170,14 +181,27 @@ def flow_kernel_times(model, tokens, dtype, reps=50, graph=True):
                                   L.ptr(aux[1]), L.ptr(aux[2]), B, S, V, 0.0, code, L.stream()),
         "nll_bwd": lambda: L.call("mivae_nll_bwd", L.ptr(logits), L.ptr(tokens), L.ptr(aux[0]), L.ptr(aux[1]), L.ptr(dper),
                                   L.ptr(dlogits), B, S, V, 0.0, code, L.stream()),
-        "nice_stack_fwd": lambda: L.call("mivae_nice_stack_fwd", L.ptr(z), L.ptr(z_out), L.ptr(hist), L.ptr(mask),
-                                         L.ptr(packed), L.ptr(tok), B, 1, S, D, H, K, actid, 0, 1, 0.0, 1.0, code, L.stream()),
-        "nice_stack_bwd": lambda: L.call("mivae_nice_stack_bwd", L.ptr(z), L.ptr(z_out), L.ptr(hist), L.ptr(mask),
-                                         L.ptr(packed), L.ptr(dz_out), L.ptr(dlog), L.ptr(dz_in), L.ptr(Gt), L.ptr(Ht),
-                                         L.ptr(dSt), L.ptr(x0t), N, 1, 1, D, H, K, actid, 1, 0.0, 1.0, code, L.stream()),
-        "nice_dw": lambda: L.call("mivae_nice_dw", L.ptr(Gt), L.ptr(Ht), L.ptr(dSt), L.ptr(x0t), L.ptr(ws), L.ptr(dW1),
-                                  L.ptr(db1), L.ptr(dW2), L.ptr(db2), N, h, H, K, code, L.stream()),
     })
+    if big:      # one entry point each: forward (k_big_chain<FWD>), backward (k_big_chain<CHAIN> + k_big_nets + k_big_dw + reduce)
+        calls.update({
+            "nice_stack_fwd": lambda: L.call("mivae_nice_big_fwd", L.ptr(z), L.ptr(z_out), L.ptr(hist), L.ptr(mask),
+                                             L.ptr(pk_f), L.ptr(pk_b), L.ptr(tok), B, 1, S, D, H, K, actid, 0, 1, 0.0, 1.0,
+                                             L.stream()),
+            "nice_stack_bwd": lambda: L.call("mivae_nice_big_bwd", L.ptr(z), L.ptr(z_out), L.ptr(hist), L.ptr(mask),
+                                             L.ptr(ptab), L.ptr(pk_c), L.ptr(pk_n), L.ptr(pk_b), L.ptr(dz_out), L.ptr(dlog),
+                                             L.ptr(dz_in), L.ptr(dsdt), L.ptr(ws), L.ptr(dW1), L.ptr(db1), L.ptr(dW2),
+                                             L.ptr(db2), None, B, 1, S, D, H, K, actid, 1, 0.0, 1.0, L.stream()),
+        })
+    else:
+        calls.update({
+            "nice_stack_fwd": lambda: L.call("mivae_nice_stack_fwd", L.ptr(z), L.ptr(z_out), L.ptr(hist), L.ptr(mask),
+                                             L.ptr(packed), L.ptr(tok), B, 1, S, D, H, K, actid, 0, 1, 0.0, 1.0, code, L.stream()),
+            "nice_stack_bwd": lambda: L.call("mivae_nice_stack_bwd", L.ptr(z), L.ptr(z_out), L.ptr(hist), L.ptr(mask),
+                                             L.ptr(packed), L.ptr(dz_out), L.ptr(dlog), L.ptr(dz_in), L.ptr(Gt), L.ptr(Ht),
+                                             L.ptr(dSt), L.ptr(x0t), N, 1, 1, D, H, K, actid, 1, 0.0, 1.0, code, L.stream()),
+            "nice_dw": lambda: L.call("mivae_nice_dw", L.ptr(Gt), L.ptr(Ht), L.ptr(dSt), L.ptr(x0t), L.ptr(ws), L.ptr(dW1),
+                                      L.ptr(db1), L.ptr(dW2), L.ptr(db2), N, h, H, K, code, L.stream()),
+        })
     out = {}
     for name, fn in calls.items():
         fn()                                   # eager once (module load, LDS opt-in), also produces the inputs of the next
@@ -230,9 +254,20 @@ def main():
     ap.add_argument("--eager", action="store_true", help="no HIP-graph replay of the step (hook-overlapped all-reduce)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher (it never touches the GPU) and starts one
+        # rank per GPU; under torch.distributed.run the ranks already exist and RANK is set
+        ndev = torch.cuda.device_count()           # does not initialise the GPU
+        if ndev < args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) visible")
+        from nonauto_lm_amd.dp import spawn_local_ranks
+        sys.exit(spawn_local_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(args.gpus, 1):
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     torch.cuda.set_device(local_rank)
@@ -318,21 +353,51 @@ def main():
         in_step = {"nll_fwd", "nll_bwd"} if not fused_lce else \
             {"lce_fwd", "lce_bwd_dh" if ops.LCE_FUSED_DH else "lce_bwd"}
         flops = {"nll_fwd": 0, "nll_bwd": 0, "lce_fwd": 2 * N * VOCAB * D, "lce_bwd": 2 * N * VOCAB * D,
-                 "lce_bwd_dh": 4 * N * VOCAB * D, "nice_stack_fwd": 4 * K * N * D * H, "nice_stack_bwd": 8 * K * N * D * H, "nice_dw": 4 * K * N * D * H}
+                 "lce_bwd_dh": 4 * N * VOCAB * D,
+                 # one step = 2 nets x 2 GEMMs x 2 h H flops per token; the backward's algorithmic count is twice the
+                 # forward's (d input + d weight per GEMM).  Small-latent path: mivae_nice_stack_bwd = d input half,
+                 # mivae_nice_dw = d weight half; wide path: mivae_nice_big_bwd does both (recomputed activations are
+                 # not counted).
+                 "nice_stack_fwd": 4 * K * N * D * H, "nice_stack_bwd": 4 * K * N * D * H, "nice_dw": 4 * K * N * D * H}
         kern = flow_kernel_times(model, tokens, torch.bfloat16 if dtype_name == "bf16" else torch.float32)
+        if "nice_stack_bwd" in kern and "nice_dw" not in kern:      # wide path: one entry point for the whole backward
+            flops["nice_stack_bwd"] = 8 * K * N * D * H
+            algo["nice_stack_bwd"] += 2 * w_bytes
         kernel_timing = ("each entry point (C ABI) captured 10x back to back in a HIP graph, the graph replayed 5x between "
                          "two HIP events on the launch stream; same process, bench shape, trained weights")
         roofline = None
+        roofline_flow = []
         if kern:
             # dominant = the slowest hand-written launch that the timed step actually runs
             skip = {"nll_fwd", "nll_bwd", "lce_fwd", "lce_bwd", "lce_bwd_dh"} - in_step
             dom = max((k for k in kern if k in algo and k not in skip), key=lambda k: kern[k]["avg_us"])
-            us = kern[dom]["avg_us"]
-            ach = algo[dom] / (us * 1e-6) / 1e9
-            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args.config, dom),
-                        "avg_us": round(us, 2), "algorithmic_bytes": algo[dom],
-                        "mfma_tflops": round(flops[dom] / (us * 1e-6) / 1e12, 2)}
+            mfma_peak = MFMA_PEAK_TFLOPS[dtype_name]
+
+            def roof(k, us_k, by, fl):
+                """roofline block of one kernel: bound = whichever of (algorithmic flops at the MFMA peak, algorithmic
+                bytes at the HBM peak) takes longer at this shape"""
+                if fl / (mfma_peak * 1e12) > by / (HBM_PEAK_GBS * 1e9):
+                    ach = fl / (us_k * 1e-6) / 1e12
+                    return {"kernel": k, "bound": "mfma", "achieved": round(ach, 1), "peak": mfma_peak, "unit": "TFLOP/s",
+                            "frac": round(ach / mfma_peak, 4), "traffic": pmc_traffic(args.config, k),
+                            "avg_us": round(us_k, 2), "algorithmic_flops": fl, "algorithmic_bytes": by}
+                ach = by / (us_k * 1e-6) / 1e9
+                return {"kernel": k, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args.config, k),
+                        "avg_us": round(us_k, 2), "algorithmic_bytes": by,
+                        "mfma_tflops": round(fl / (us_k * 1e-6) / 1e12, 2)}
+
+            roofline = roof(dom, kern[dom]["avg_us"], algo[dom], flops[dom])
+            # the north-star kernels: the fused flow stack forward / backward (the small-latent path's backward is
+            # the pair mivae_nice_stack_bwd + mivae_nice_dw)
+            for k in ("nice_stack_fwd", "nice_stack_bwd"):
+                if k not in kern:
+                    continue
+                pair = k == "nice_stack_bwd" and "nice_dw" in kern
+                roofline_flow.append(roof(k + ("+nice_dw" if pair else ""),
+                                          kern[k]["avg_us"] + (kern["nice_dw"]["avg_us"] if pair else 0.0),
+                                          algo[k] + (algo["nice_dw"] if pair else 0),
+                                          flops[k] + (flops["nice_dw"] if pair else 0)))
             for k in kern:
                 if k not in algo:
                     continue
@@ -350,8 +415,11 @@ def main():
                                    f"2+2 transformer layers, fwd+bwd+allreduce+clip+Adam",
                        "global_batch": world * B, "seq_len": S, "latent_dim": D, "flow_steps": K,
                        "parallelism": f"dp{world}"},
-            "roofline": roofline, "kernels": kern, "kernel_timing": kernel_timing,
-            "step_mode": "hipgraph-replay" if train_step.graph_a is not None else "eager", "cpu_baseline": cpu, "final_loss": round(loss, 4),
+            "roofline": roofline, "roofline_flow": roofline_flow, "kernels": kern, "kernel_timing": kernel_timing,
+            "step_mode": "hipgraph-replay" if train_step.graph_a is not None else "eager",
+            "allreduce": ("none (1 rank)" if world == 1 else "captured in graph A, overlapped with backward"
+                          if train_step.comm_in_graph else "between the graphs" if train_step.graph_a is not None
+                          else "from the grad hooks, overlapped with backward"), "cpu_baseline": cpu, "final_loss": round(loss, 4),
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -204,11 +204,14 @@ int mivae_kl_bwd(const float* logq, const float* logp, const float* dkl, float* 
                  int64_t n, int use_fb, float free_bits, void* stream);
 /* out3 = {batch-loss, batch-kl, batch-nll}: loss = wr*recon + wk*kl per (b, j); IWAE softmax-weighted
  * sum over the n samples (weights not detached); means.  Replaces VAELmModel.forward's tail,
- * models/base/model.py:171-193. */
+ * models/base/model.py:171-193.  weights_dev (may be NULL): device floats {recon weight, kl weight} read
+ * INSTEAD of the by-value weights -- the scheduler weights of nn/weight_scheduler.py:33-60 change every step, and a
+ * launch captured in a HIP graph would otherwise replay with the weights of the capture step. */
 int mivae_elbo_fwd(const float* recon, const float* kl, float* out3, int64_t B, int64_t n,
-                   float recon_weight, float kl_weight, int iwae, void* stream);
+                   float recon_weight, float kl_weight, int iwae, const float* weights_dev, void* stream);
 int mivae_elbo_bwd(const float* recon, const float* kl, const float* gout3, float* drecon, float* dkl,
-                   int64_t B, int64_t n, float recon_weight, float kl_weight, int iwae, void* stream);
+                   int64_t B, int64_t n, float recon_weight, float kl_weight, int iwae,
+                   const float* weights_dev, void* stream);
 
 /* ---- reconstruction term: label-smoothing NLL over the vocabulary ------------------------------ */
 /* per_seq[b] = sum_s w[b,s] * nll[b,s] / clamp(sum_s w[b,s], 1e-13) with
@@ -334,13 +337,15 @@ int64_t mivae_layernorm_bwd_partial(const void* dy, const void* x, const float* 
  * +-max_value (<= 0: off), applies Adam (torch formula, L2 weight_decay) with step count *step + 1, writes
  * p, m, v (and, when p_bf16 is not NULL, a bf16 copy of the new p: the shadow the bf16 forward reads, so no
  * per-layer weight casts are needed) and zeroes g.  *step is advanced separately with mivae_scalar_add(step, 1) after all buckets.
- * n must be a multiple of 4 floats, buffers 16-byte aligned.  norm_out may be NULL. */
+ * n must be a multiple of 4 floats, buffers 16-byte aligned.  norm_out may be NULL.  grad_scale (> 0) multiplies
+ * every gradient before anything else (and so the norm): 1 / world_size after a SUM all-reduce of the buckets, the
+ * averaging DistributedDataParallel does (trainer.py:51-60), without a pass of its own. */
 int64_t mivae_sumsq_blocks(int64_t n);
 int mivae_sumsq_partial(const float* g, float* partial, int64_t n, void* stream);
 int mivae_adam_clip_step(float* p, void* p_bf16, float* g, float* m, float* v, const float* partial, int64_t npartial,
                          const float* step, float* norm_out, int64_t n, double lr, double beta1,
                          double beta2, float eps, float weight_decay, float max_norm, float max_value,
-                         void* stream);
+                         float grad_scale, void* stream);
 int mivae_scalar_add(float* x, float delta, void* stream);
 
 /* ---- masked autoregressive flows ----------------------------------------------- */

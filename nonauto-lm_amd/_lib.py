@@ -41,8 +41,8 @@ SIGNATURES = {
     "mivae_colsum_static": [P, P, I64, I64, I32, P],
     "mivae_kl_fwd": [P, P, P, I64, I32, F32, P],
     "mivae_kl_bwd": [P, P, P, P, P, I64, I32, F32, P],
-    "mivae_elbo_fwd": [P, P, P, I64, I64, F32, F32, I32, P],
-    "mivae_elbo_bwd": [P, P, P, P, P, I64, I64, F32, F32, I32, P],
+    "mivae_elbo_fwd": [P, P, P, I64, I64, F32, F32, I32, P, P],
+    "mivae_elbo_bwd": [P, P, P, P, P, I64, I64, F32, F32, I32, P, P],
     "mivae_nll_fwd": [P, P, P, P, P, P, P, I64, I64, I64, F32, I32, P],
     "mivae_nll_bwd": [P, P, P, P, P, P, I64, I64, I64, F32, I32, P],
     "mivae_lce_workspace_floats": [I64, I64],
@@ -76,7 +76,7 @@ SIGNATURES = {
     "mivae_layernorm_bwd": [P, P, P, P, P, P, P, P, I64, I64, I32, I32, P],
     "mivae_sumsq_blocks": [I64],
     "mivae_sumsq_partial": [P, P, I64, P],
-    "mivae_adam_clip_step": [P, P, P, P, P, P, I64, P, P, I64, F64, F64, F64, F32, F32, F32, F32, P],
+    "mivae_adam_clip_step": [P, P, P, P, P, P, I64, P, P, I64, F64, F64, F64, F32, F32, F32, F32, F32, P],
     "mivae_scalar_add": [P, F32, P],
     "mivae_nice_pack_bytes": [I64, I64, I32],
     "mivae_nice_pack": [P, P, I64, I64, I64, I32, I32, P],

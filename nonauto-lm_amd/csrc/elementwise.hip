@@ -648,9 +648,13 @@ __device__ float block_sum_256(float v, float* red) {
   return t;
 }
 
+// wdev (optional): {recon weight, kl weight} in device memory, read instead of the by-value arguments -- a captured
+// HIP graph replays with whatever the host wrote there before the replay (annealed weight schedulers)
 __global__ void k_elbo_fwd(const float* __restrict__ recon, const float* __restrict__ kl,
-                           float* __restrict__ out, int B, int n, float wr, float wk, int iwae) {
+                           float* __restrict__ out, int B, int n, float wr, float wk, int iwae,
+                           const float* __restrict__ wdev) {
   __shared__ float red[8];
+  if (wdev) { wr = wdev[0]; wk = wdev[1]; }
   float a_loss = 0.f, a_kl = 0.f, a_nll = 0.f;
   for (int b = threadIdx.x; b < B; b += blockDim.x) {
     float mx = -INFINITY;
@@ -686,9 +690,11 @@ __global__ void k_elbo_fwd(const float* __restrict__ recon, const float* __restr
 // gout = {d batch-loss, d batch-kl, d batch-nll}
 __global__ void k_elbo_bwd(const float* __restrict__ recon, const float* __restrict__ kl,
                            const float* __restrict__ gout, float* __restrict__ drecon,
-                           float* __restrict__ dkl, int B, int n, float wr, float wk, int iwae) {
+                           float* __restrict__ dkl, int B, int n, float wr, float wk, int iwae,
+                           const float* __restrict__ wdev) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
+  if (wdev) { wr = wdev[0]; wk = wdev[1]; }
   float gl = gout[0], gk = gout[1] / ((float)B * n), gn = gout[2] / ((float)B * n);
   if (!iwae) {
     float c = gl / ((float)B * n);
@@ -1192,20 +1198,21 @@ extern "C" int mivae_kl_bwd(const float* logq, const float* logp, const float* d
 }
 
 extern "C" int mivae_elbo_fwd(const float* recon, const float* kl, float* out3, int64_t B, int64_t n,
-                              float recon_weight, float kl_weight, int iwae, void* stream) {
+                              float recon_weight, float kl_weight, int iwae, const float* weights_dev,
+                              void* stream) {
   MIVAE_REQUIRE(B > 0 && n > 0 && B * n < (1ll << 30), "elbo_fwd: bad shape B=%ld n=%ld", (long)B, (long)n);
   MIVAE_REQUIRE(recon && kl && out3, "elbo_fwd: null pointer");
-  k_elbo_fwd<<<1, kBlock, 0, S_(stream)>>>(recon, kl, out3, (int)B, (int)n, recon_weight, kl_weight, iwae);
+  k_elbo_fwd<<<1, kBlock, 0, S_(stream)>>>(recon, kl, out3, (int)B, (int)n, recon_weight, kl_weight, iwae, weights_dev);
   MIVAE_CHECK_LAUNCH("elbo_fwd");
   return MIVAE_OK;
 }
 
 extern "C" int mivae_elbo_bwd(const float* recon, const float* kl, const float* gout3, float* drecon,
                               float* dkl, int64_t B, int64_t n, float recon_weight, float kl_weight,
-                              int iwae, void* stream) {
+                              int iwae, const float* weights_dev, void* stream) {
   MIVAE_REQUIRE(B > 0 && n > 0 && B * n < (1ll << 30), "elbo_bwd: bad shape");
   MIVAE_REQUIRE(recon && kl && gout3 && drecon && dkl, "elbo_bwd: null pointer");
-  k_elbo_bwd<<<(unsigned)((B + kBlock - 1) / kBlock), kBlock, 0, S_(stream)>>>(recon, kl, gout3, drecon, dkl, (int)B, (int)n, recon_weight, kl_weight, iwae);
+  k_elbo_bwd<<<(unsigned)((B + kBlock - 1) / kBlock), kBlock, 0, S_(stream)>>>(recon, kl, gout3, drecon, dkl, (int)B, (int)n, recon_weight, kl_weight, iwae, weights_dev);
   MIVAE_CHECK_LAUNCH("elbo_bwd");
   return MIVAE_OK;
 }

@@ -58,6 +58,7 @@ struct AdamArgs {
   int npartial;
   double lr, b1, b2;
   float eps, wd, max_norm, max_value;
+  float gscale;           // every gradient (and so the norm) is multiplied by this first: 1 / world after a SUM all-reduce
 };
 
 __global__ __launch_bounds__(kBlock) void k_adam_clip(AdamArgs a) {
@@ -65,10 +66,11 @@ __global__ __launch_bounds__(kBlock) void k_adam_clip(AdamArgs a) {
   // total norm: every block sums the same partials in the same order -> the same coefficient everywhere
   float s = 0.f;
   for (int i = threadIdx.x; i < a.npartial; i += kBlock) s += a.partial[i];
-  const float norm = sqrtf(block_sum(s, red));
+  const float norm = sqrtf(block_sum(s, red)) * a.gscale;
   if (a.norm_out && blockIdx.x == 0 && threadIdx.x == 0) *a.norm_out = norm;
   float coef = 1.0f;
   if (a.max_norm > 0.f) coef = fminf(a.max_norm / (norm + 1e-6f), 1.0f);   // clip_grad_norm_
+  if (a.gscale != 1.0f) coef *= a.gscale;
   // bias corrections in double like the host arithmetic of torch.optim.Adam (1 - beta ** step)
   const double t = (double)*a.step + 1.0;
   const double bc1 = 1.0 - pow(a.b1, t), bc2 = 1.0 - pow(a.b2, t);
@@ -131,16 +133,17 @@ extern "C" int mivae_sumsq_partial(const float* g, float* partial, int64_t n, vo
 extern "C" int mivae_adam_clip_step(float* p, void* p_bf16, float* g, float* m, float* v, const float* partial,
                                     int64_t npartial, const float* step, float* norm_out, int64_t n, double lr,
                                     double beta1, double beta2, float eps, float weight_decay, float max_norm,
-                                    float max_value, void* stream) {
+                                    float max_value, float grad_scale, void* stream) {
   MIVAE_REQUIRE(n >= 0 && npartial >= 0 && npartial < (1 << 20), "adam_clip_step: bad sizes");
   if (n == 0) return MIVAE_OK;
   MIVAE_REQUIRE(p && g && m && v && step && (partial || npartial == 0), "adam_clip_step: null pointer");
   MIVAE_REQUIRE(n % 4 == 0 && aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v),
                 "adam_clip_step: buffers must be 16-byte aligned and padded to a multiple of 4 floats");
+  MIVAE_REQUIRE(grad_scale > 0.f, "adam_clip_step: grad_scale must be positive");
   MIVAE_REQUIRE(lr >= 0. && beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1. && eps >= 0.f,
                 "adam_clip_step: bad hyper-parameters");
   AdamArgs a = {p, g, m, v, static_cast<unsigned short*>(p_bf16), partial, step, norm_out, n, (int)npartial, lr, beta1, beta2, eps, weight_decay,
-                max_norm, max_value};
+                max_norm, max_value, grad_scale};
   int64_t blocks = (n / 4 + kBlock - 1) / kBlock;
   if (blocks > 2048) blocks = 2048;
   k_adam_clip<<<(unsigned)blocks, kBlock, 0, S_(stream)>>>(a);

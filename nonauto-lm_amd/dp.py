@@ -17,6 +17,7 @@ and the 2-per-metric scalar all-reduces (training/metrics.py:27-28) with:
 
 The path has no other exchange step: every op is per-sentence.
 """
+import contextlib
 from typing import Dict, Iterable, List, Optional
 
 import torch
@@ -87,12 +88,22 @@ class GradReducer:
         self._arrived = [0] * len(self.buckets)
         self._handles: List[Optional[object]] = [None] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
-        # overlap = True: buckets are all-reduced from the grad hooks while backward is still running.
-        # overlap = False (HIP-graph replay of the step, where Python hooks do not run): finish() issues
-        # every bucket after backward.
+        # overlap = True: a bucket is all-reduced as soon as its last contribution of the step has been enqueued, while
+        # backward is still running (from the grad hooks / sink notifications; under HIP-graph capture the same calls
+        # are captured into the graph).  overlap = False: finish() issues every bucket after backward.
         self.overlap = True
+        # Contributions per bucket and step = autograd accumulations (post-accumulate hooks) + gradient-sink writes that
+        # bypass autograd (notify_sink).  The count is LEARNED from the first finished step, during which nothing is
+        # launched early; call relearn() when the set of modules taking part in a step changes.
+        self._expected: Optional[List[int]] = None
+        self._gradptr_bucket = {p.grad.data_ptr(): self._bucket_of[id(p)] for p in self.params}
+        self.before_launch = None            # callable(lo, hi): fold deferred partials of the bucket's address range
+        # fold_average: finish() leaves the SUM in the buckets; the optimizer kernel multiplies by 1 / world
+        # (dp.FusedAdam, mivae_adam_clip_step grad_scale) instead of one div_ launch per bucket here
+        self.fold_average = False
+        self.compute_stream = None           # torch.cuda.Stream of the step (set by step.TrainStep); None: current stream
 
-    # -- hooks ------------------------------------------------------------------------------------
+    # -- arrivals ---------------------------------------------------------------------------------
     def _on_grad(self, p: torch.nn.Parameter) -> None:
         bi = self._bucket_of[id(p)]
         flat = self.buckets[bi]
@@ -100,33 +111,72 @@ class GradReducer:
             # someone replaced .grad (zero_grad(set_to_none=True)): copy back into the bucket view
             raise RuntimeError("GradReducer: parameter .grad was re-allocated; call reducer.zero_grad() "
                                "instead of optimizer.zero_grad(set_to_none=True)")
-        if not self.overlap:
-            return
+        self._arrive(bi)
+
+    def notify_sink(self, grad: torch.Tensor) -> None:
+        """A kernel that adds into `grad` (a view into a bucket) behind autograd's back has been enqueued."""
+        bi = self._gradptr_bucket.get(grad.data_ptr())
+        if bi is not None:
+            self._arrive(bi)
+
+    def _arrive(self, bi: int) -> None:
         self._arrived[bi] += 1
-        if self._arrived[bi] == self._bucket_size[bi]:
+        if self._launched[bi] and self.overlap:
+            if self.world > 1:
+                raise RuntimeError("GradReducer: a gradient contribution arrived after its bucket was all-reduced "
+                                   "(the modules taking part in the step changed: call reducer.relearn())")
+            import sys
+            print(f"[GradReducer] late contribution to bucket {bi} (arrived {self._arrived[bi]}, expected "
+                  f"{None if self._expected is None else self._expected[bi]}); counting again", file=sys.stderr)
+            self._expected = None            # single rank: nothing was exchanged, just count again
+            return
+        if self.overlap and self._expected is not None and self._arrived[bi] == self._expected[bi]:
             self._launch(bi)
+
+    def relearn(self) -> None:
+        self._expected = None
+
+    def reset(self) -> None:
+        self._arrived = [0] * len(self.buckets)
+        self._handles = [None] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
 
     def _launch(self, bi: int) -> None:
         if self._launched[bi]:
             return
         self._launched[bi] = True
-        if self.world > 1:
-            self._handles[bi] = dist.all_reduce(self.buckets[bi], op=dist.ReduceOp.SUM, group=self.group,
-                                                async_op=True)
+        # A grad hook runs on the stream of its AccumulateGrad node (the stream the parameter was created on), which need
+        # not be the stream the step's kernels -- the sink kernels in particular -- are enqueued on.  Everything issued
+        # here goes to the step's compute stream, after joining the hook's stream; under HIP-graph capture the two are
+        # separate branches of the graph and nothing else would order a bucket's fold after the partials it reads.
+        cs = self.compute_stream
+        ctx = contextlib.nullcontext()
+        if cs is not None:
+            cur = torch.cuda.current_stream(cs.device)
+            if cur != cs:
+                cs.wait_stream(cur)
+                ctx = torch.cuda.stream(cs)
+        with ctx:
+            if self.before_launch is not None:
+                flat = self.buckets[bi]
+                self.before_launch(flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size())
+            if self.world > 1:
+                self._handles[bi] = dist.all_reduce(self.buckets[bi], op=dist.ReduceOp.SUM, group=self.group,
+                                                    async_op=True)
 
     # -- step API ---------------------------------------------------------------------------------
     def finish(self) -> None:
-        """Call after loss.backward(): flushes incomplete buckets, waits, averages."""
+        """Call after loss.backward(): flushes incomplete buckets, waits, averages (unless fold_average)."""
         for bi in range(len(self.buckets)):
             self._launch(bi)
         for bi, h in enumerate(self._handles):
             if h is not None:
                 h.wait()
-            if self.world > 1:
+            if self.world > 1 and not self.fold_average:
                 self.buckets[bi].div_(self.world)
-        self._arrived = [0] * len(self.buckets)
-        self._handles = [None] * len(self.buckets)
-        self._launched = [False] * len(self.buckets)
+        if self._expected is None:
+            self._expected = list(self._arrived)
+        self.reset()
 
     def zero_grad(self) -> None:
         for flat in self.buckets:
@@ -201,6 +251,8 @@ class FusedAdam:
         gradient norm as a device scalar."""
         L = self._L
         st = L.stream()
+        # a reducer that leaves the rank SUM in the buckets (fold_average) gets its averaging here
+        gscale = 1.0 / self.reducer.world if (self.reducer.fold_average and self.reducer.world > 1) else 1.0
         off = 0
         for b, nb in zip(self.reducer.buckets, self._nblk):
             L.call("mivae_sumsq_partial", L.ptr(b), self._partial.data_ptr() + 4 * off, b.numel(), st)
@@ -210,7 +262,7 @@ class FusedAdam:
                    None if self.shadow is None else L.ptr(self.shadow[i]), L.ptr(b), L.ptr(self.exp_avg[i]),
                    L.ptr(self.exp_avg_sq[i]), L.ptr(self._partial), off, L.ptr(self.step_count),
                    L.ptr(self.grad_norm) if i == 0 else None, b.numel(), self.lr, self.betas[0], self.betas[1],
-                   self.eps, self.weight_decay, float(max_norm or 0.0), float(max_value or 0.0), st)
+                   self.eps, self.weight_decay, float(max_norm or 0.0), float(max_value or 0.0), gscale, st)
         L.call("mivae_scalar_add", L.ptr(self.step_count), 1.0, st)
         return self.grad_norm
 
@@ -227,20 +279,46 @@ class FusedAdam:
             dst.copy_(src)
         for dst, src in zip(self.exp_avg_sq, sd["exp_avg_sq"]):
             dst.copy_(src)
+        self.refresh_shadow()            # checkpoints are usually loaded together with new weights
 
 
 class PackedScalars:
-    """One all-reduce for every per-step global scalar (replaces ddp.py:25-26 + metrics.py:27-28)."""
+    """One all-reduce for every per-step global scalar (replaces ddp.py:25-26 + metrics.py:27-28).  Device scalars are
+    gathered with one stack + one index_copy_; host numbers sit in a device-side template that is re-uploaded only
+    when they change (synchronously, from pageable memory: a pinned staging buffer reused every step could be
+    overwritten while an earlier step's copy is still queued), so a steady-state step issues no host-to-device copy."""
 
     def __init__(self, names: List[str], device, group=None):
         self.names = list(names)
         self.group = group
+        device = torch.device(device)
         self.buf = torch.zeros(len(self.names) + 1, dtype=torch.float32, device=device)
+        self._tmpl = torch.zeros_like(self.buf)
+        self._tmpl_host: Optional[tuple] = None
+        self._idx_cache: Dict[tuple, torch.Tensor] = {}
 
     def reduce(self, values: Dict[str, torch.Tensor], count: float = 1.0, async_op: bool = False):
-        vals = [values[n].detach().float().reshape(()) if isinstance(values[n], torch.Tensor)
-                else torch.tensor(float(values[n]), device=self.buf.device) for n in self.names]
-        self.buf.copy_(torch.stack(vals + [torch.tensor(float(count), device=self.buf.device)]))
+        tens_i, tens_v, host = [], [], []
+        for i, n in enumerate(self.names):
+            v = values[n]
+            if isinstance(v, torch.Tensor):
+                tens_i.append(i)
+                tens_v.append(v.detach().float().reshape(()))
+                host.append(0.0)
+            else:
+                host.append(float(v))
+        host.append(float(count))
+        host = tuple(host)
+        if host != self._tmpl_host:
+            self._tmpl.copy_(torch.tensor(host, dtype=torch.float32))
+            self._tmpl_host = host
+        self.buf.copy_(self._tmpl)
+        if tens_i:
+            key = tuple(tens_i)
+            idx = self._idx_cache.get(key)
+            if idx is None:
+                idx = self._idx_cache[key] = torch.tensor(tens_i, dtype=torch.int64, device=self.buf.device)
+            self.buf.index_copy_(0, idx, torch.stack(tens_v).to(self.buf.device))
         if world_size(self.group) > 1:
             return dist.all_reduce(self.buf, group=self.group, async_op=async_op)
         return None
@@ -249,3 +327,39 @@ class PackedScalars:
         host = self.buf.tolist()                 # the only device->host sync
         cnt = max(host[-1], 1e-30)
         return {n: v / cnt for n, v in zip(self.names, host[:-1])}
+
+
+def spawn_local_ranks(argv: List[str], nranks: int, extra_env: Optional[Dict[str, str]] = None) -> int:
+    """Start `nranks` copies of `argv` on this node, one per GPU, with the torch.distributed environment
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) the reference's launcher sets up with mp.spawn
+    (training/ddp.py:14-15, train_worker.py).  Must be called BEFORE the calling process touches the GPU: the parent
+    only waits.  When a rank fails the others are terminated (by PID).  Returns the largest exit code."""
+    import os
+    import socket
+    import subprocess
+    import time
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(nranks):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(nranks), "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen(list(argv), env=env))
+    rc = 0
+    alive = set(range(nranks))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            rc = max(rc, abs(code))
+            if code != 0:                        # a dead rank would leave the others waiting in a collective
+                for o in alive:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return rc

@@ -92,6 +92,7 @@ class VAELmModel(torch.nn.Module, Registrable):
         self._end_index = self.vocab.token_to_index("<eos>")
         self.training_outputs_only = False   # skip probs/preds (unused by the loss) when True
         self.track_metrics = True            # False under HIP-graph capture (host-side accumulators)
+        self.device_weights = None           # optional fp32 device tensor {recon weight, kl weight}, see forward()
 
     @property
     def is_kl_used(self) -> bool:
@@ -117,11 +118,16 @@ class VAELmModel(torch.nn.Module, Registrable):
                   for k, v in self._kl_loss(posterior_log_prob, prior_log_prob, latent=latent.z).items()}
         kl_loss = kl_out.pop("batch-loss")
         w_r, w_kl = self._recon_scheduler.weight, self._kl_scheduler.weight
-        batch_loss, batch_kl, batch_nll = ops.elbo_tail(recon_error, kl_loss, batch, n, w_r, w_kl, self._iwae)
+        # device_weights (set by step.TrainStep): the two weights live in device memory, written by the host before
+        # every step, so that a HIP-graph replay of this forward does not freeze them at their capture-time values
+        batch_loss, batch_kl, batch_nll = ops.elbo_tail(recon_error, kl_loss, batch, n, w_r, w_kl, self._iwae,
+                                                        weights_dev=self.device_weights)
         if not manual_kl_step and self.training:
             self.kl_scheduler_step()
         if self.training:
             self._recon_scheduler.step()
+        # the reported weights are the schedulers' AFTER their step (models/base/model.py:180-189, 204-208)
+        w_r, w_kl = self._recon_scheduler.weight, self._kl_scheduler.weight
         out = {
             "loss_info": {"recon-weight": w_r, "kl-weight": w_kl, "batch-kl": batch_kl,
                           "batch-nll": batch_nll, "batch-loss": batch_loss,
@@ -129,11 +135,15 @@ class VAELmModel(torch.nn.Module, Registrable):
             "source": src_tokens, "target": tgt_tokens, "latent": latent.z, **decoded,
         }
         if self.track_metrics:
-            self._metrics["nll"].update(batch_nll)
-            self._metrics["avg-recon-weight"].update(w_r)
-            self._metrics["avg-kl-weight"].update(w_kl)
-            self._metrics["avg-kl"].update(batch_kl)
+            self.update_metrics(batch_nll, batch_kl, w_r, w_kl)
         return out
+
+    def update_metrics(self, batch_nll, batch_kl, w_r, w_kl) -> None:
+        """models/base/model.py:200-210 (device-side running sums; no host sync)."""
+        self._metrics["nll"].update(batch_nll)
+        self._metrics["avg-recon-weight"].update(w_r)
+        self._metrics["avg-kl-weight"].update(w_kl)
+        self._metrics["avg-kl"].update(batch_kl)
 
     def kl_scheduler_step(self) -> None:
         self._kl_scheduler.step()

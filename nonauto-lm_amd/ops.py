@@ -438,10 +438,12 @@ def layer_norm_bwd(dy2, x2, weight, stats, params):
             if nblk <= 0:
                 raise RuntimeError(f"mivae_layernorm_bwd_partial failed ({nblk}): {L.lib().mivae_last_error().decode()}")
             _DEFER[key] = (wsp[:nblk * 2 * D].view(nblk, 2 * D), gw, gb, D)
+            sink_arrived(gw, gb)
             return dx, None, None
         L.call("mivae_layernorm_bwd_sink", L.ptr(dy2), L.ptr(x2), L.ptr(weight), L.ptr(stats[0]), L.ptr(stats[1]),
                L.ptr(dx), L.ptr(gw), L.ptr(gb), L.ptr(ws), rows, D, L.dtype_code(x2.dtype), L.dtype_code(dy2.dtype),
                L.stream())
+        sink_arrived(gw, gb)
         return dx, None, None
     dgb = torch.empty(2, D, dtype=torch.float32, device=x2.device)
     L.call("mivae_layernorm_bwd", L.ptr(dy2), L.ptr(x2), L.ptr(weight), L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(dx),
@@ -501,15 +503,52 @@ _DEFER = None
 _PART_BUFS = {}
 _JOB_TABLES = {}
 
+# Device tables (pointer tables, job tables, partial buffers) whose ADDRESSES a captured HIP graph bakes in must never be
+# freed while that graph can still be replayed: the caching allocator would hand the memory to another tensor and the
+# replayed kernels would read garbage as gradient addresses.  step.TrainStep pins the caches (no eviction while any
+# captured step is alive) and keeps its own references to their entries.
+_PIN = 0
+
+
+def pin_tables(on: bool) -> None:
+    global _PIN
+    _PIN = max(_PIN + (1 if on else -1), 0)
+
+
+def pinned_tables():
+    """Strong references to every cached device table / partial buffer (held by the TrainStep that captured them)."""
+    return (list(_PTR_CACHE.values()), list(_JOB_TABLES.values()), list(_PART_BUFS.values()))
+
+
+# SINK_NOTIFY(grad_tensor): set by step.TrainStep to dp.GradReducer.notify_sink -- "a contribution to this .grad has been
+# enqueued on the current stream" (sinks bypass autograd's accumulation, so the reducer's grad hooks do not fire for them).
+SINK_NOTIFY = None
+
+
+def sink_arrived(*grads) -> None:
+    if SINK_NOTIFY is not None:
+        for g in grads:
+            if g is not None:
+                SINK_NOTIFY(g)
+
 
 def begin_deferred_sinks():
     global _DEFER
     _DEFER = {}
 
 
-def flush_grad_sinks():
+def flush_grad_sinks(lo: Optional[int] = None, hi: Optional[int] = None):
+    """Fold the queued [dW | db] partials into their gradient buffers.  With an address range only the jobs whose
+    gradient lies in [lo, hi) are folded and the queue stays open (the reducer flushes a bucket right before its
+    all-reduce); without one everything left is folded and deferred mode ends."""
     global _DEFER
-    jobs, _DEFER = _DEFER, None
+    if _DEFER is None:
+        return
+    if lo is None:
+        jobs, _DEFER = _DEFER, None
+    else:
+        keys = [k for k, j in _DEFER.items() if lo <= j[1].data_ptr() < hi]
+        jobs = {k: _DEFER.pop(k) for k in keys}
     if not jobs:
         return
     rows = [(part.data_ptr(), g0.data_ptr(), g1.data_ptr(), part.size(0), part.size(1), split)
@@ -523,7 +562,7 @@ def flush_grad_sinks():
                 L.call("mivae_colsum_sink", L.ptr(part), L.ptr(g0), L.ptr(g1), split, None, part.size(0), part.size(1), 0,
                        L.stream())
             return
-        if len(_JOB_TABLES) > 16:
+        if len(_JOB_TABLES) > 16 and _PIN == 0:
             _JOB_TABLES.clear()
         table = torch.tensor(rows, dtype=torch.int64).to(dev)
         _JOB_TABLES[key] = table
@@ -547,6 +586,7 @@ class _Embedding(torch.autograd.Function):
         idc = ids.contiguous().view(-1)
         if grad_sink_ok(w):
             L.call("mivae_embedding_bwd", L.ptr(dy2), L.ptr(idc), L.ptr(w.grad), idc.numel(), V, E, ctx.pad, 1, L.stream())
+            sink_arrived(w.grad)
             return None, None, None
         dw = torch.empty(V, E, dtype=torch.float32, device=dy.device)
         L.call("mivae_embedding_bwd", L.ptr(dy2), L.ptr(idc), L.ptr(dw), idc.numel(), V, E, ctx.pad, 0, L.stream())
@@ -644,6 +684,7 @@ def linear_wgrad_group_deferred(x2, gs, sinks) -> bool:
     L.call("mivae_linear_wgrad_group", L.ptr(x2), _ptr_array(gs), _ptr_array(parts), len(gs), N, Fi, Fo, L.stream())
     for k, part, (s0, s1) in zip(keys, parts, sinks):
         _DEFER[k] = (part, s0, s1, Fo * Fi)
+        sink_arrived(s0, s1)
     return True
 
 
@@ -670,6 +711,7 @@ def linear_wgrad(x2, g2, sink=None):
                 part = _PART_BUFS[key] = torch.empty(rows, Fo * Fi + Fo, dtype=torch.float32, device=x2.device)
             L.call("mivae_linear_wgrad", L.ptr(x2), L.ptr(g2), L.ptr(part), N, Fi, Fo, L.stream())
             _DEFER[key] = (part, sink[0], sink[1], Fo * Fi)
+            sink_arrived(sink[0], sink[1])
             return None
     part = torch.empty(rows, Fo * Fi + Fo, dtype=torch.float32, device=x2.device)
     L.call("mivae_linear_wgrad", L.ptr(x2), L.ptr(g2), L.ptr(part), N, Fi, Fo, L.stream())
@@ -677,6 +719,7 @@ def linear_wgrad(x2, g2, sink=None):
         D = Fo * Fi + Fo
         ws = torch.empty(L.query("mivae_col_workspace_floats", rows, D, 0), dtype=torch.float32, device=x2.device)
         L.call("mivae_colsum_sink", L.ptr(part), L.ptr(sink[0]), L.ptr(sink[1]), Fo * Fi, L.ptr(ws), rows, D, 0, L.stream())
+        sink_arrived(sink[0], sink[1])
         return None
     sums = colsum(part)
     return sums[:Fo * Fi].view(Fo, Fi), sums[Fo * Fi:]
@@ -725,12 +768,13 @@ def kl_default(logq, logp, free_bits: Optional[float] = None):
 
 class _Elbo(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, recon, kl, B, n, wr, wk, iwae):
+    def forward(ctx, recon, kl, B, n, wr, wk, iwae, wdev):
         r, k = recon.contiguous().float(), kl.contiguous().float()
         out = torch.empty(3, dtype=torch.float32, device=r.device)
-        L.call("mivae_elbo_fwd", L.ptr(r), L.ptr(k), L.ptr(out), B, n, float(wr), float(wk), int(iwae),
+        L.call("mivae_elbo_fwd", L.ptr(r), L.ptr(k), L.ptr(out), B, n, float(wr), float(wk), int(iwae), L.ptr(wdev),
                L.stream())
         ctx.save_for_backward(r, k)
+        ctx.wdev = wdev
         ctx.meta = (B, n, float(wr), float(wk), int(iwae))
         return out
 
@@ -740,14 +784,21 @@ class _Elbo(torch.autograd.Function):
         B, n, wr, wk, iwae = ctx.meta
         dr, dk = torch.empty_like(r), torch.empty_like(k)
         L.call("mivae_elbo_bwd", L.ptr(r), L.ptr(k), L.ptr(g.contiguous().float()), L.ptr(dr), L.ptr(dk),
-               B, n, wr, wk, iwae, L.stream())
-        return dr, dk, None, None, None, None, None
+               B, n, wr, wk, iwae, L.ptr(ctx.wdev), L.stream())
+        return dr, dk, None, None, None, None, None, None
 
 
-def elbo_tail(recon, kl, batch: int, samples: int, recon_weight: float, kl_weight: float, iwae: bool):
-    """a17: (batch-loss, batch-kl, batch-nll) of VAELmModel.forward (models/base/model.py:171-193)."""
+def elbo_tail(recon, kl, batch: int, samples: int, recon_weight: float, kl_weight: float, iwae: bool,
+              weights_dev: Optional[torch.Tensor] = None):
+    """a17: (batch-loss, batch-kl, batch-nll) of VAELmModel.forward (models/base/model.py:171-193).
+    weights_dev: optional fp32 device tensor {recon weight, kl weight} the kernels read instead of the two floats
+    (the step harness keeps the scheduler weights there so that a captured step replays with the current ones)."""
     L.require_gpu(recon, kl)
-    out = _Elbo.apply(recon.reshape(-1), kl.reshape(-1), batch, samples, recon_weight, kl_weight, iwae)
+    if weights_dev is not None:
+        L.require_gpu(weights_dev)
+        if weights_dev.dtype != torch.float32 or weights_dev.numel() < 2 or not weights_dev.is_contiguous():
+            raise ValueError("elbo_tail: weights_dev must be a contiguous fp32 tensor of 2 elements")
+    out = _Elbo.apply(recon.reshape(-1), kl.reshape(-1), batch, samples, recon_weight, kl_weight, iwae, weights_dev)
     return out[0], out[1], out[2]
 
 
@@ -895,7 +946,7 @@ def _ptr_table(params: Sequence[torch.Tensor], device) -> torch.Tensor:
     key = (device, tuple(p.data_ptr() for p in params))
     tab = _PTR_CACHE.get(key)
     if tab is None:
-        if len(_PTR_CACHE) > 64:
+        if len(_PTR_CACHE) > 64 and _PIN == 0:
             _PTR_CACHE.clear()
         tab = torch.tensor(key[1], dtype=torch.int64).to(device)
         _PTR_CACHE[key] = tab
@@ -971,6 +1022,7 @@ class _NiceStack(torch.autograd.Function):
             with _timed("nice_dw"):
                 L.call("mivae_nice_dw_sink", L.ptr(Gt), L.ptr(Ht), L.ptr(dSt), L.ptr(x0t), L.ptr(ws), L.ptr(table),
                        N, h, H, K, code, L.stream())
+            sink_arrived(*[p.grad for p in ctx.params])
             return (dz_in, None, None, None, None, None, None, None, *([None] * len(ctx.params)))
         dW1 = torch.empty(K, 2, H, h, dtype=torch.float32, device=z.device)
         db1 = torch.empty(K, 2, H, dtype=torch.float32, device=z.device)
@@ -1061,6 +1113,7 @@ class _NiceStackBig(torch.autograd.Function):
                    L.ptr(dzo), L.ptr(dlog), L.ptr(dz_in), L.ptr(dsdt), L.ptr(ws), L.ptr(dW1), L.ptr(db1), L.ptr(dW2),
                    L.ptr(db2), L.ptr(table), Bn, 1, S, D, H, K, act, base, mu, std, L.stream())
         if sink:
+            sink_arrived(*[p.grad for p in params])
             return (dz_in, None, None, None, None, None, None, None, *([None] * len(params)))
         grads = []
         for k in range(K):
