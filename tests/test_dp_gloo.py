@@ -146,3 +146,151 @@ def test_grad_reducer_single_process_is_identity():
         assert torch.equal(a, p.grad if p.grad is not None else torch.zeros_like(p))
     reducer.zero_grad()
     assert all(float(p.grad.abs().max()) == 0.0 for p in model.parameters())
+
+
+# ---------------------------------------------------------------------------- learned arrival counts, sink notifications
+def _sink_worker(rank, world, port, q):
+    """Gradient sinks (kernels that add into .grad behind autograd's back) simulated on the CPU: half of the parameters
+    get their gradient through `notify_sink` instead of a grad hook.  Step 1 learns the per-bucket contribution counts,
+    steps 2-3 launch every bucket as soon as its last contribution arrived (overlap), with the bucket's deferred work
+    folded by `before_launch` first; fold_average leaves the SUM for the optimizer."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nonauto_lm_amd import dp
+    torch.set_num_threads(1)
+    model = _make_model()
+    dp.broadcast_parameters(model)
+    reducer = dp.GradReducer(model.parameters(), bucket_bytes=4096, flatten_params=True)
+    reducer.fold_average = True
+    params = [p for p in model.parameters()]
+    sinked = [p for i, p in enumerate(params) if i % 2 == 1]           # "sink" parameters: biases
+    x, y = _data()
+    shard = slice(rank * 8, (rank + 1) * 8)
+    deferred, folded, launches = [], [], []
+    def before_launch(lo, hi):                                          # the bucket's deferred contributions
+        launches.append((lo, hi))
+        for item in [d for d in deferred if lo <= d[0].data_ptr() < hi]:
+            item[0].add_(item[1])
+            folded.append(item)
+            deferred.remove(item)
+    reducer.before_launch = before_launch
+    out = {"early": []}
+    for it in range(3):
+        launches.clear()
+        loss = ((model(x[shard]) - y[shard]) ** 2).mean()
+        # autograd for the hooked half; the sinked half is computed on the side and written straight into .grad
+        hooked = [p for p in params if all(p is not s for s in sinked) and p.requires_grad]
+        gs = torch.autograd.grad(loss, sinked, retain_graph=True, allow_unused=True)
+        loss.backward(inputs=[p for p in hooked if p is not model.unused.weight and p is not model.unused.bias])
+        early = len(launches)
+        for p, g in zip(sinked, gs):
+            if g is None:
+                continue
+            if p.ndim == 1 and p.numel() == 3:                          # one contribution is deferred to the bucket flush
+                deferred.append((p.grad, g))
+            else:
+                p.grad.add_(g)
+            reducer.notify_sink(p.grad)
+        out["early"].append((early, len(launches)))
+        reducer.finish()
+        assert not deferred
+        out[f"grads{it}"] = [p.grad.clone() / world for p in params]    # fold_average: the buckets hold the SUM
+        reducer.zero_grad()
+    out["expected"] = list(reducer._expected)
+    def plain(v):
+        if isinstance(v, torch.Tensor):
+            return v.numpy().copy()
+        if isinstance(v, list):
+            return [plain(x) for x in v]
+        return v
+    q.put((rank, {k: plain(v) for k, v in out.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_grad_reducer_sinks_and_learned_counts_world2():
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sink_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        rank, out = q.get(timeout=100)
+        res[rank] = out
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    model = _make_model()
+    x, y = _data()
+    ((model(x) - y) ** 2).mean().backward()
+    ref = [p.grad.clone() if p.grad is not None else torch.zeros_like(p) for p in model.parameters()]
+    for rank in (0, 1):
+        r = res[rank]
+        for it in range(3):
+            for a, b in zip(r[f"grads{it}"], ref):
+                assert torch.allclose(torch.from_numpy(np.asarray(a)), b, rtol=1e-5, atol=1e-7)
+        assert sum(r["expected"]) > 0
+        # step 1 learns (nothing before finish()); steps 2, 3 launch buckets from the arrivals
+        assert r["early"][0][1] == 0
+        assert r["early"][1][1] >= 1 and r["early"][2][1] >= 1
+    for a, b in zip(res[0]["grads2"], res[1]["grads2"]):
+        assert np.array_equal(a, b)
+
+
+def test_grad_reducer_late_contribution_raises():
+    """world > 1 only matters for the exchange; the guard itself is rank-count independent: simulate world 2."""
+    sys.path.insert(0, ROOT)
+    from nonauto_lm_amd import dp
+    model = _make_model()
+    reducer = dp.GradReducer(model.parameters(), bucket_bytes=1 << 20)
+    x, y = _data()
+    ((model(x) - y) ** 2).mean().backward()
+    reducer.finish()                                  # learns the counts
+    reducer.zero_grad()
+    ((model(x) - y) ** 2).mean().backward()           # bucket complete -> launched from the last hook
+    assert all(reducer._launched)
+    reducer.world = 2                                 # pretend the bucket went out to another rank
+    with pytest.raises(RuntimeError, match="after its bucket was all-reduced"):
+        reducer.notify_sink(next(model.parameters()).grad)
+
+
+def test_packed_scalars_template_and_tensors():
+    sys.path.insert(0, ROOT)
+    from nonauto_lm_amd import dp
+    sc = dp.PackedScalars(["a", "b", "c"], "cpu")
+    for k in range(3):
+        sc.reduce({"a": torch.tensor(2.0 + k), "b": 5.0, "c": torch.tensor(1.0)}, count=2.0)
+        assert sc.means() == {"a": (2.0 + k) / 2, "b": 2.5, "c": 0.5}
+    sc.reduce({"a": 1.0, "b": 7.0, "c": torch.tensor(3.0)}, count=1.0)
+    assert sc.means() == {"a": 1.0, "b": 7.0, "c": 3.0}
+
+
+@pytest.mark.timeout(120)
+def test_spawn_local_ranks_env_and_failure(tmp_path):
+    """dp.spawn_local_ranks (what `bench.py --gpus N` uses to start its ranks): every child gets RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_*; the children can rendezvous over gloo; a failing rank's exit code is returned and the
+    surviving ranks are terminated."""
+    sys.path.insert(0, ROOT)
+    from nonauto_lm_amd import dp
+    script = tmp_path / "child.py"
+    script.write_text(
+        "import os, sys, torch, torch.distributed as dist\n"
+        "r, w = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+        "assert os.environ['LOCAL_RANK'] == str(r) and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+        "dist.init_process_group('gloo', rank=r, world_size=w)\n"
+        "t = torch.tensor([float(r + 1)]); dist.all_reduce(t)\n"
+        "open(sys.argv[1] + f'/rank{r}', 'w').write(str(t.item()))\n"
+        "dist.destroy_process_group()\n")
+    assert dp.spawn_local_ranks([sys.executable, str(script), str(tmp_path)], 2) == 0
+    assert (tmp_path / "rank0").read_text() == "3.0" and (tmp_path / "rank1").read_text() == "3.0"
+    bad = tmp_path / "bad.py"
+    bad.write_text("import os, sys, time\n"
+                   "if os.environ['RANK'] == '1': sys.exit(7)\n"
+                   "time.sleep(60)\n")
+    assert dp.spawn_local_ranks([sys.executable, str(bad)], 2) != 0
