@@ -331,6 +331,32 @@ def posterior_log_prob(z, mu, sigma, mask, samples: int):
     return lp.reshape(lp.size(0), -1).sum(dim=1)
 
 
+def prior_sample_from_noise(noise, lengths: Sequence[int], batch: int, samples: int, steps=None, mu=0.0, std=1.0):
+    """DefaultPrior.sample / FlowPrior.sample with the base draw injected.  nonauto_lm/priors/prior.py:105-131,
+    flow_prior.py:15-24.  noise (batch, samples, max_len, D) = base_dist.sample((batch, samples, max_len)).
+    Returns (z ((B n), L, D), log_prob (B n), mask ((B n), L)); steps = None: the base sample itself."""
+    mask = prefix_mask(lengths, batch)
+    eps = noise * mask[:, None, :, None]
+    eps = eps.reshape(batch * samples, *eps.shape[2:])
+    mask = mask.repeat_interleave(samples, dim=0)
+    if not steps:
+        return eps, masked_base_log_prob(eps, mask, mu, std), mask
+    z, logp = flow_prior_inverse(eps, steps, mask, mu, std)
+    return z, logp, mask
+
+
+def mutual_info(z, log_prob, mask, mu, sigma, samples: int):
+    """Posterior.calc_mutual_info.  nonauto_lm/posteriors/posterior.py:174-222: log q(z) of the aggregate posterior by
+    comparing every latent code with every sentence's (mu, sigma), logsumexp - log(B n)."""
+    mu_r = mu.repeat_interleave(samples, dim=0)
+    sg_r = sigma.repeat_interleave(samples, dim=0)
+    dens = -0.5 * ((z.unsqueeze(1) - mu_r).pow(2) * sg_r.pow(2).reciprocal() + 2 * sg_r.log() + LOG_2PI)
+    dens = dens * mask.to(dens.dtype)[:, None, :, None]
+    dens = dens.reshape(dens.size(0), dens.size(1), -1).sum(-1)
+    log_qz = torch.logsumexp(dens, dim=-1) - math.log(mu_r.size(0))
+    return (log_prob - log_qz).mean()
+
+
 # ----------------------------------------------------------------------------- KL / ELBO tail
 def kl_default(log_q, log_p, free_bits_alpha: Optional[float] = None):
     """DefaultKLLoss.  nn/kl_loss.py:38-49, free bits :14-21."""

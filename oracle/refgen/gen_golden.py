@@ -397,6 +397,54 @@ def gen_posterior(name, B, S, E, D, n, mask_kind, seed):
     save(name, **out)
 
 
+# ----------------------------------------------------------------------------- prior sampling / mutual information
+def gen_prior_sample(name, batch, lengths, samples, D, H, K, seed, mu=0.0, std=1.0):
+    """DefaultPrior.sample / FlowPrior.sample (nonauto prior.py:105-131, flow_prior.py:15-24): the prefix mask built
+    from lengths, the masked base draw, its log-prob, and (K > 0) the flow-inverted sample with its log-prob."""
+    gen = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    from vae_lm.models.nonauto_lm.priors import DefaultPrior as NADefaultPrior
+    if K > 0:
+        flows = [NICECoupling(FeedForwardCoupling(D // 2, [H], activation="gelu")) for _ in range(K)]
+        prior = NAFlowPrior(D, flows, mu=mu, std=std)
+        jitter(prior, gen)
+    else:
+        prior = NADefaultPrior(D, mu=mu, std=std)
+    out = {"batch": np.int64(batch), "lengths": np.asarray(lengths, dtype=np.int64), "samples": np.int64(samples),
+           "mu": np.float64(mu), "std": np.float64(std)}
+    out.update(state(prior, "sd."))
+    with torch.no_grad():
+        # the base draw is the first use of the global RNG inside sample(): replay it
+        torch.manual_seed(seed + 2000)
+        eps, base_logp, mask = NADefaultPrior.sample(prior, batch, lengths, samples)
+        out["eps"], out["base.logp"], out["mask"] = eps, base_logp, mask
+        torch.manual_seed(seed + 2000)
+        z, logp, mask2 = prior.sample(batch, lengths, samples)
+        assert torch.equal(mask, mask2)
+        out["z"], out["logp"] = z, logp
+    save(name, **out)
+
+
+def gen_mutual_info(name, B, S, E, D, n, mask_kind, seed):
+    """Posterior.calc_mutual_info (nonauto posterior.py:174-222) on the sample the posterior just drew."""
+    gen = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    post = NAPosterior(E, D, samples=n)
+    enc = torch.randn(B, S, E, generator=gen)
+    mask = make_mask(mask_kind, B, S, gen)
+    out = {"enc": enc, "mask": mask, "samples": np.int64(n)}
+    out.update(state(post, "sd."))
+    torch.manual_seed(seed + 1000)
+    eps = torch.distributions.Normal(torch.zeros(D), torch.ones(D)).sample((B, n, S))
+    torch.manual_seed(seed + 1000)
+    with torch.no_grad():
+        latent, logq = post(enc, mask)
+        rep_mask = mask.repeat_interleave(n, 0).float()
+        mi = post.calc_mutual_info(latent.z, logq, rep_mask)
+    out["eps"], out["z"], out["mu"], out["sigma"], out["logq"], out["mi"] = eps, latent.z, latent.mu, latent.sigma, logq, mi
+    save(name, **out)
+
+
 # ----------------------------------------------------------------------------- KL / NLL
 def gen_kl_nll(name, seed):
     gen = torch.Generator().manual_seed(seed)
@@ -583,6 +631,11 @@ if __name__ == "__main__":
     gen_maf("maf_auto_2d", "maf", 5, None, 16, [32], 2, None, 34)
     gen_maf("iaf_tiny_ragged", "iaf", 4, 6, 8, [16], 2, "ragged", 35)
     gen_maf("iaf_d16_natural", "iaf", 3, 5, 16, [24], 2, "full", 36, permute=False, activation="gelu")
+    gen_prior_sample("prior_sample_default", 4, [5, 2, 7, 1], 3, 8, 0, 0, 41, mu=0.25, std=1.5)
+    gen_prior_sample("prior_sample_one_length", 3, [6], 2, 8, 0, 0, 42)
+    gen_prior_sample("prior_sample_flow", 4, [9, 3, 1, 6], 2, 16, 32, 3, 43)
+    gen_mutual_info("mutual_info_n1", 5, 7, 12, 8, 1, "ragged", 44)
+    gen_mutual_info("mutual_info_n3", 4, 6, 12, 8, 3, "holes", 45)
     if only:
         sys.exit(0)
     gen_nice("nice_tiny_full", 4, 6, 8, 16, 4, "full", 13)

@@ -332,3 +332,41 @@ def test_maf_iaf_reverse_direction(name):
         z, ld = step(z, fn, bool((K - 1 - k) % 2), mask)
         assert rel_err(z, g[f"inv.z{k}"]) < TOL
         assert rel_err(ld, g[f"inv.ld{k}"]) < TOL
+
+
+# ----------------------------------------------------------------------------- prior sampling / mutual information
+PRIOR_SAMPLE_CASES = ["prior_sample_default", "prior_sample_one_length", "prior_sample_flow"]
+
+
+def _recover_noise(g):
+    """The recorded base sample is already masked; at real positions it IS the draw, elsewhere anything works."""
+    B, n = int(g["batch"]), int(g["samples"])
+    eps = g["eps"]
+    return eps.reshape(B, n, *eps.shape[1:])
+
+
+@pytest.mark.parametrize("name", PRIOR_SAMPLE_CASES)
+def test_prior_sample_mask_and_logprob(name):
+    """DefaultPrior.sample / FlowPrior.sample (prior.py:105-131, flow_prior.py:15-24) -- the prefix
+    mask from lengths is bit-exact, base / flow log-probs and the inverted sample match the recorded reference."""
+    g = load_golden(name)
+    B, n = int(g["batch"]), int(g["samples"])
+    lengths = g["lengths"].tolist()
+    mu, std = float(g["mu"]), float(g["std"])
+    eps, base_lp, mask = O.prior_sample_from_noise(_recover_noise(g), lengths, B, n, None, mu, std)
+    assert torch.equal(mask, g["mask"])
+    assert torch.equal(eps, g["eps"])
+    assert rel_err(base_lp, g["base.logp"]) < TOL
+    ps = nice_params(g)
+    z, lp, _ = O.prior_sample_from_noise(_recover_noise(g), lengths, B, n, O.nice_steps(ps) if ps else None, mu, std)
+    assert rel_err(z, g["z"]) < TOL and rel_err(lp, g["logp"]) < TOL
+    assert float((z * (1 - mask).unsqueeze(-1)).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("name", ["mutual_info_n1", "mutual_info_n3"])
+def test_mutual_info(name):
+    g = load_golden(name)
+    n = int(g["samples"])
+    mask = g["mask"].repeat_interleave(n, 0)
+    mi = O.mutual_info(g["z"], g["logq"], mask, g["mu"], g["sigma"], n)
+    assert rel_err(mi, g["mi"]) < TOL
