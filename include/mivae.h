@@ -195,6 +195,19 @@ int mivae_embedding_bwd(const float* dy, const int64_t* ids, float* dW, int64_t 
  * (trainer.py:284, loss.backward()).  max_D = the largest D in the table. */
 int mivae_colsum_sink_multi(const void* jobs, int64_t njobs, int64_t max_D, void* stream);
 
+/* ---- invertible linear flows (a14) ------------------------------------------------------------------- */
+/* Y (R, hs) = X (R, hs) M^T on the matrix cores, M (hs, hs) row major in the latent dtype, 1 <= hs <= 512.
+ * Replaces F.linear(z, W) of InvertibleLinearFlow.forward / .backward (models/base/flows/invertible_flows.py:29,
+ * :39; M = W or W^-1) and of InvertibleMultiHeadFlow (:61-63, :75-77: the rearrange to heads is the identity on the
+ * memory image, R = tokens x heads, hs = D / heads).  The input gradient d X = d Y M is the same call on M^T.
+ * fp32: v_mfma_f32_32x32x2_f32 (an exact fp32 fma chain); bf16: v_mfma_f32_32x32x16_bf16, fp32 accumulation. */
+int mivae_rowgemm(const void* x, const void* m, void* y, int64_t R, int64_t hs, int dtype, void* stream);
+/* d M of Y = X M^T as per-slab partial sums: part (mivae_rowgemm_wgrad_slabs(R, hs), hs, hs) fp32,
+ * part[s][o][i] = sum_{r in slab s} dY[r][o] X[r][i]; sum the slabs with mivae_colsum (fixed order).  This is the
+ * weight gradient autograd derives for F.linear in invertible_flows.py:29 / :61-63. */
+int64_t mivae_rowgemm_wgrad_slabs(int64_t R, int64_t hs);
+int mivae_rowgemm_wgrad(const void* x, const void* dy, float* part, int64_t R, int64_t hs, int dtype, void* stream);
+
 /* ---- KL / ELBO tail -------------------------------------------------------------------------------- */
 /* kl = clamp(logq - logp, min = free_bits) (clamp only if use_fb).  Replaces DefaultKLLoss.forward
  * nn/kl_loss.py:38-49 and _free_bits_kl :14-21. */

@@ -41,6 +41,9 @@ SIGNATURES = {
     "mivae_colsum_static": [P, P, I64, I64, I32, P],
     "mivae_kl_fwd": [P, P, P, I64, I32, F32, P],
     "mivae_kl_bwd": [P, P, P, P, P, I64, I32, F32, P],
+    "mivae_rowgemm": [P, P, P, I64, I64, I32, P],
+    "mivae_rowgemm_wgrad": [P, P, P, I64, I64, I32, P],
+    "mivae_rowgemm_wgrad_slabs": [I64, I64],
     "mivae_elbo_fwd": [P, P, P, I64, I64, F32, F32, I32, P, P],
     "mivae_elbo_bwd": [P, P, P, P, P, I64, I64, F32, F32, I32, P, P],
     "mivae_nll_fwd": [P, P, P, P, P, P, P, I64, I64, I64, F32, I32, P],
@@ -99,6 +102,7 @@ _RET = {
     "mivae_colsum_static_max_floats": I64,
     "mivae_nice_pack_bytes": I64,
     "mivae_sumsq_blocks": I64,
+    "mivae_rowgemm_wgrad_slabs": I64,
     "mivae_lce_workspace_floats": I64,
     "mivae_lce_pack_elems": I64,
     "mivae_layernorm_bwd_partial": I64,

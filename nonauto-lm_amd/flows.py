@@ -369,12 +369,11 @@ class _InvLinearBase(Flow):
         w = self._weight
         if inverse:
             w = torch.inverse(w.double()).float()        # invertible_flows.py:37
-        wz = w.to(z.dtype)
-        if heads > 1:
-            lead = z.shape[:-1]
-            out = torch.matmul(z.reshape(*lead, heads, z.size(-1) // heads), wz.t()).reshape(*lead, z.size(-1))
-        else:
-            out = torch.matmul(z, wz.t())                # dense D x D contraction: library MFMA GEMM
+        # the head split is the identity on the memory image: (N, D) == (N heads, D / heads) row major, so both flows
+        # are ONE product with a small square matrix on the matrix cores (csrc/invlinear.hip)
+        lead = z.shape[:-1]
+        hs = z.size(-1) // heads
+        out = ops.rowgemm(z.reshape(*lead, heads, hs), w).reshape(*lead, z.size(-1))
         logdet = torch.linalg.slogdet(w)[1]
         if z.dim() > 2:
             cnt = ops.mask_count(mask, z.size(0))        # integer token count (HIP), bit exact

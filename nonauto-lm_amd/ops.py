@@ -737,6 +737,55 @@ def colsum(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+# ----------------------------------------------------------------------------------- invertible linear flows
+class _RowGemm(torch.autograd.Function):
+    """Y = X M^T for X (R, hs) and a small square M (hs, hs): mivae_rowgemm forward, the same kernel on M^T for d X,
+    mivae_rowgemm_wgrad + fixed-order slab sum for d M."""
+
+    @staticmethod
+    def forward(ctx, x2, m):
+        R, hs = x2.shape
+        mk = m.detach().to(x2.dtype).contiguous()
+        y = torch.empty_like(x2)
+        L.call("mivae_rowgemm", L.ptr(x2), L.ptr(mk), L.ptr(y), R, hs, L.dtype_code(x2.dtype), L.stream())
+        ctx.save_for_backward(x2, mk)
+        ctx.mdtype = m.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, mk = ctx.saved_tensors
+        R, hs = x2.shape
+        dy = dy.contiguous()
+        dx = dm = None
+        code = L.dtype_code(x2.dtype)
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x2)
+            L.call("mivae_rowgemm", L.ptr(dy), L.ptr(mk.t().contiguous()), L.ptr(dx), R, hs, code, L.stream())
+        if ctx.needs_input_grad[1] and R > 0:
+            nslab = L.query("mivae_rowgemm_wgrad_slabs", R, hs)
+            part = torch.empty(nslab, hs * hs, dtype=torch.float32, device=x2.device)
+            L.call("mivae_rowgemm_wgrad", L.ptr(x2), L.ptr(dy), L.ptr(part), R, hs, code, L.stream())
+            dm = colsum(part).view(hs, hs).to(ctx.mdtype)
+        return dx, dm
+
+
+ROWGEMM_MAX = 512
+
+
+def rowgemm(x, m):
+    """x (..., hs) times m (hs, hs) transposed, on the matrix cores (a14: invertible_flows.py:29, :39, :61-63, :75-77).
+    x fp32 or bf16 on the GPU, hs <= 512; gradients for both."""
+    L.require_gpu(x, m)
+    hs = m.size(0)
+    if m.dim() != 2 or m.size(1) != hs or x.size(-1) != hs or hs > ROWGEMM_MAX:
+        raise ValueError(f"rowgemm: x (..., {x.size(-1)}) against m {tuple(m.shape)} (square, <= {ROWGEMM_MAX})")
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("rowgemm: fp32 or bf16 latents")
+    x2 = x.contiguous().view(-1, hs)
+    return _RowGemm.apply(x2, m).view(x.shape)
+
+
 # ----------------------------------------------------------------------------------- KL / ELBO
 class _KL(torch.autograd.Function):
     @staticmethod

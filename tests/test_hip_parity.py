@@ -1281,8 +1281,9 @@ def test_whole_model_bf16_c2_vs_fp32_oracle(M):
     """the bf16-autocast ELBO step bench.py times (BASELINE config 2: B=256, S=64, D=64, K=4 NICE-FF,
     V=8192) against the fp32 CPU oracle (oracle/latent_path.py for the latent path, stock PyTorch fp32 for the
     transformer bracket) with the posterior noise injected.  Tolerances (north_star's "stated looser tolerance in
-    bf16"): the three ELBO scalars <= 1e-2 relative; gradients, tensor-level max-norm: flow-prior and posterior-head
-    parameters <= 6e-2 (bf16 activations through 2 + 2 transformer layers and a V = 8192 softmax)."""
+    bf16"): the three ELBO scalars <= 1e-3 relative (measured 9e-5); gradients, tensor-level max-norm: flow-prior and
+    posterior-head parameters <= 2e-2 (measured 6e-3; bf16 activations through 2 + 2 transformer layers and a V = 8192
+    softmax)."""
     import bench
     B, S, D, H, K, V = 256, 64, 64, 64, 4, bench.VOCAB
     torch.manual_seed(13)
@@ -1317,7 +1318,7 @@ def test_whole_model_bf16_c2_vs_fp32_oracle(M):
     ref = O.elbo_tail(recon, O.kl_default(logq, logp), B, 1)
     ref["batch-loss"].backward()
     for k in ("batch-loss", "batch-kl", "batch-nll"):
-        assert rel_err(info[k], ref[k]) < 1e-2, (k, float(info[k]), float(ref[k]))
+        assert rel_err(info[k], ref[k]) < 1e-3, (k, float(info[k]), float(ref[k]))
     got = dict(model.named_parameters())
     worst = {}
     for name, p in m.named_parameters():
@@ -1325,4 +1326,42 @@ def test_whole_model_bf16_c2_vs_fp32_oracle(M):
             worst[name] = rel_err(got[name].grad, p.grad)
     print("whole-model bf16 vs fp32 oracle:", {k: rel_err(info[k], ref[k]) for k in ("batch-loss", "batch-kl", "batch-nll")},
           "worst gradient", max(worst.values()))
-    assert max(worst.values()) < 6e-2, sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+    assert max(worst.values()) < 2e-2, sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+
+
+# ------------------------------------------------------------------------------------ invertible linear kernels (a14)
+@pytest.mark.parametrize("N,D,heads,dtype", [
+    (1, 8, 1, torch.float32), (77, 24, 3, torch.float32), (4099, 64, 4, torch.float32), (300, 70, 1, torch.float32),
+    (513, 256, 1, torch.float32), (130, 512, 1, torch.float32), (16384, 64, 1, torch.bfloat16),
+    (1000, 512, 2, torch.bfloat16), (333, 40, 5, torch.bfloat16)])
+def test_rowgemm_vs_oracle(M, N, D, heads, dtype):
+    """mivae_rowgemm / mivae_rowgemm_wgrad through ops.rowgemm against oracle.invlinear_step (invertible_flows.py:26-83)
+    on seeded inputs: sizes off every tile boundary (hs not a multiple of 8 / 32, rows not a multiple of 32 / 128),
+    the largest supported width, multi-head row folding.  fp32: <= 1e-5 (outputs), 5e-5 (gradients); bf16 inputs and
+    weight rounded to bf16 on both sides: <= 1e-2 tensor-level."""
+    gen = torch.Generator().manual_seed(N + D)
+    hs = D // heads
+    w = torch.linalg.qr(torch.randn(hs, hs, generator=gen))[0] + 0.05 * torch.randn(hs, hs, generator=gen)
+    z = torch.randn(N, D, generator=gen)
+    cot = torch.randn(N, D, generator=gen)
+    if dtype == torch.bfloat16:
+        w, z, cot = (t.to(dtype).float() for t in (w, z, cot))
+    zr, wr = z.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ref, _ = O.invlinear_step(zr.unsqueeze(0), wr, torch.ones(1, N), inverse=False, num_heads=heads)
+    (ref[0] * cot).sum().backward()
+    zg, wg = dev(z).to(dtype).requires_grad_(True), dev(w).clone().requires_grad_(True)
+    out = M.ops.rowgemm(zg.view(N, heads, hs), wg).view(N, D)
+    assert out.dtype == dtype
+    (out.float() * dev(cot)).sum().backward()
+    tol, gtol = (1e-5, 5e-5) if dtype == torch.float32 else (1e-2, 1e-2)
+    assert rel_err(out.float(), ref[0]) < tol, rel_err(out.float(), ref[0])
+    assert rel_err(zg.grad.float(), zr.grad) < gtol, rel_err(zg.grad.float(), zr.grad)
+    assert rel_err(wg.grad, wr.grad) < gtol, rel_err(wg.grad, wr.grad)
+
+
+def test_rowgemm_rejects_wide_and_mismatched(M):
+    with pytest.raises(ValueError):
+        M.ops.rowgemm(torch.zeros(4, 520, device=DEV), torch.zeros(520, 520, device=DEV))
+    with pytest.raises(ValueError):
+        M.ops.rowgemm(torch.zeros(4, 16, device=DEV), torch.zeros(8, 8, device=DEV))
+    assert M.ops.rowgemm(torch.zeros(0, 16, device=DEV), torch.eye(16, device=DEV)).shape == (0, 16)
