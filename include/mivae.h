@@ -73,6 +73,21 @@ int mivae_reparam_logq_bwd(const void* dz, const float* dlogq, const void* sigma
                            const int64_t* mask, void* dmu, void* dsigma, int64_t B, int64_t n,
                            int64_t S, int64_t D, int dtype, void* stream);
 
+/* The same pair with eps drawn INSIDE the kernels (Posterior.sample draws it with base_dist.sample, nonauto
+ * posterior.py:115-118, auto :107-110): Philox4x32-10 keyed by the seed, counter = (element / 4, draw offset), two
+ * Box-Muller pairs per counter -- eps is a pure function of (seed, offset, element) and never touches HBM.
+ * rng_state: device int64 {seed, offset}; the forward copies it to rng_used (device int64[2], to be kept for the
+ * backward), draws with it and advances rng_state's offset by one, all stream ordered, so a captured HIP graph draws
+ * fresh noise at every replay.  The backward regenerates eps from rng_used.  mivae_philox_normal writes the first
+ * `count` fp32 values of the draw recorded in rng_used (what the kernels used; for tests). */
+int mivae_reparam_logq_fwd_rng(const void* mu, const void* sigma, int64_t* rng_state, int64_t* rng_used,
+                               const int64_t* mask, void* z, float* tok_logq, int64_t B, int64_t n, int64_t S,
+                               int64_t D, int dtype, void* stream);
+int mivae_reparam_logq_bwd_rng(const void* dz, const float* dlogq, const void* sigma, const int64_t* rng_used,
+                               const int64_t* mask, void* dmu, void* dsigma, int64_t B, int64_t n, int64_t S,
+                               int64_t D, int dtype, void* stream);
+int mivae_philox_normal(const int64_t* rng_used, float* out, int64_t count, void* stream);
+
 /* ---- base distribution ----------------------------------------------------------------------- */
 /* tok[bn, s] = mask * sum_d Normal(mu, std).log_prob(z).  Replaces DefaultPrior.masked_log_prob,
  * nonauto priors/prior.py:148-158; auto priors/prior.py:93. */

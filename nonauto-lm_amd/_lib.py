@@ -41,6 +41,9 @@ SIGNATURES = {
     "mivae_colsum_static": [P, P, I64, I64, I32, P],
     "mivae_kl_fwd": [P, P, P, I64, I32, F32, P],
     "mivae_kl_bwd": [P, P, P, P, P, I64, I32, F32, P],
+    "mivae_reparam_logq_fwd_rng": [P, P, P, P, P, P, P, I64, I64, I64, I64, I32, P],
+    "mivae_reparam_logq_bwd_rng": [P, P, P, P, P, P, P, I64, I64, I64, I64, I32, P],
+    "mivae_philox_normal": [P, P, I64, P],
     "mivae_rowgemm": [P, P, P, I64, I64, I32, P],
     "mivae_rowgemm_wgrad": [P, P, P, I64, I64, I32, P],
     "mivae_rowgemm_wgrad_slabs": [I64, I64],

@@ -91,13 +91,77 @@ __global__ void k_gather_last(const T* __restrict__ out, const int64_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// Counter-based standard-normal noise for the reparameterisation (posterior.py:115-118 draws eps with
+// base_dist.sample): Philox4x32-10 (Salmon et al., SC'11) keyed by the seed, counter = (element quad, draw offset);
+// the four 32-bit outputs of one counter give four normals through two Box-Muller pairs.  Element e of draw number
+// `offset` is a pure function of (seed, offset, e): the backward REGENERATES eps instead of reading it back.
+__device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1) {
+  const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+  const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1;
+  c[0] = n0; c[1] = (unsigned)p1; c[2] = n2; c[3] = (unsigned)p0;
+}
+__device__ __forceinline__ void philox_normal4(const int64_t* __restrict__ rng, int64_t quad, float (&out)[4]) {
+  const unsigned long long seed = (unsigned long long)rng[0], off = (unsigned long long)rng[1];
+  unsigned c[4] = {(unsigned)quad, (unsigned)((unsigned long long)quad >> 32), (unsigned)off, (unsigned)(off >> 32)};
+  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float u1 = ((float)c[2 * h] + 0.5f) * 2.3283064365386963e-10f;        // (0, 1]
+    const float u2 = ((float)c[2 * h + 1] + 0.5f) * 2.3283064365386963e-10f;
+    const float r = sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincospif(2.0f * u2, &sn, &cs);
+    out[2 * h] = r * cs; out[2 * h + 1] = r * sn;
+  }
+}
+// eps of the VEC elements starting at flat element index e0 (VEC = 1: any e0; VEC = 4, 8: e0 a multiple of 4)
+template <int VEC>
+__device__ __forceinline__ void philox_eps(const int64_t* __restrict__ rng, int64_t e0, float (&ve)[VEC]) {
+  if constexpr (VEC == 1) {
+    float q[4];
+    philox_normal4(rng, e0 >> 2, q);
+    ve[0] = q[e0 & 3];
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; i += 4) {
+      float q[4];
+      philox_normal4(rng, (e0 + i) >> 2, q);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ve[i + j] = q[j];
+    }
+  }
+}
+
+// take one draw number from the generator: used = state; state.offset += 1 (one thread; stream ordered)
+__global__ void k_rng_take(int64_t* __restrict__ state, int64_t* __restrict__ used) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const int64_t seed = state[0], off = state[1];
+    used[0] = seed; used[1] = off;
+    state[1] = off + 1;
+  }
+}
+__global__ void k_philox_normal(const int64_t* __restrict__ rng, float* __restrict__ out, int64_t count) {
+  const int64_t quad = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (quad * 4 >= count) return;
+  float q[4];
+  philox_normal4(rng, quad, q);
+  for (int j = 0; j < 4; ++j)
+    if (quad * 4 + j < count) out[quad * 4 + j] = q[j];
+}
+
+// ------------------------------------------------------------------------------------------------
 // a4 + a5: z = (mu + eps * sigma) * mask ; tok_logq = mask * sum_d -1/2 ((z-mu)^2 / sigma^2 + 2 log sigma + log 2pi)
 // rows over (b, j, s); mu/sigma are (B, S, D), eps/z are ((B n), S, D).  posterior.py:119-133,157-172.
 template <typename T, int VEC>
 __global__ void k_reparam_fwd(const T* __restrict__ mu, const T* __restrict__ sigma,
                               const T* __restrict__ eps, const int64_t* __restrict__ mask,
                               T* __restrict__ z, float* __restrict__ tok_logq, int64_t rows, int n,
-                              int S, int D, int L) {
+                              int S, int D, int L, const int64_t* __restrict__ rng) {
   int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int64_t row = tid / L;
   int lig = (int)(tid % L);
@@ -113,9 +177,10 @@ __global__ void k_reparam_fwd(const T* __restrict__ mu, const T* __restrict__ si
       RowIO<T, VEC>::load(mu + prow * D + c, vm);
       RowIO<T, VEC>::load(sigma + prow * D + c, vs);
       if (eps) RowIO<T, VEC>::load(eps + row * D + c, ve);
+      else if (rng) philox_eps<VEC>(rng, row * D + c, ve);          // in-kernel draw: eps never touches HBM
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
-        float e = eps ? ve[i] : 0.f;
+        float e = (eps || rng) ? ve[i] : 0.f;
         float zz = (vm[i] + e * vs[i]) * m;
         float d = zz - vm[i];
         float sg = vs[i];
@@ -136,7 +201,8 @@ template <typename T, int VEC>
 __global__ void k_reparam_bwd(const T* __restrict__ dz, const float* __restrict__ dlogq,
                               const T* __restrict__ sigma, const T* __restrict__ eps,
                               const int64_t* __restrict__ mask, T* __restrict__ dmu,
-                              T* __restrict__ dsigma, int64_t prows, int n, int S, int D, int L) {
+                              T* __restrict__ dsigma, int64_t prows, int n, int S, int D, int L,
+                              const int64_t* __restrict__ rng) {
   int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int64_t prow = tid / L;
   int lig = (int)(tid % L);
@@ -155,11 +221,12 @@ __global__ void k_reparam_bwd(const T* __restrict__ dz, const float* __restrict_
       float g[VEC], e[VEC];
       if (dz) RowIO<T, VEC>::load(dz + row * D + c, g);
       if (eps) RowIO<T, VEC>::load(eps + row * D + c, e);
+      else if (rng) philox_eps<VEC>(rng, row * D + c, e);           // the same draw as the forward
       float dq = dlogq ? dlogq[bn] : 0.f;
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         float gi = dz ? g[i] : 0.f;
-        float ei = eps ? e[i] : 0.f;
+        float ei = (eps || rng) ? e[i] : 0.f;
         am[i] += gi;
         as[i] += gi * ei - dq / vs[i];
       }
@@ -767,16 +834,16 @@ namespace {
 // ---- typed launchers (void* -> T*) ---------------------------------------------------------------
 template <typename T, int VEC>
 void l_reparam_fwd(const void* mu, const void* sigma, const void* eps, const int64_t* mask, void* z,
-                   float* tok, int64_t rows, int n, int S, int D, RowCfg c, hipStream_t st) {
+                   float* tok, int64_t rows, int n, int S, int D, RowCfg c, hipStream_t st, const int64_t* rng) {
   k_reparam_fwd<T, VEC><<<c.grid, kBlock, 0, st>>>((const T*)mu, (const T*)sigma, (const T*)eps, mask,
-                                                  (T*)z, tok, rows, n, S, D, c.L);
+                                                  (T*)z, tok, rows, n, S, D, c.L, rng);
 }
 template <typename T, int VEC>
 void l_reparam_bwd(const void* dz, const float* dlogq, const void* sigma, const void* eps,
                    const int64_t* mask, void* dmu, void* dsigma, int64_t prows, int n, int S, int D,
-                   RowCfg c, hipStream_t st) {
+                   RowCfg c, hipStream_t st, const int64_t* rng) {
   k_reparam_bwd<T, VEC><<<c.grid, kBlock, 0, st>>>((const T*)dz, dlogq, (const T*)sigma, (const T*)eps,
-                                                  mask, (T*)dmu, (T*)dsigma, prows, n, S, D, c.L);
+                                                  mask, (T*)dmu, (T*)dsigma, prows, n, S, D, c.L, rng);
 }
 template <typename T, int VEC>
 void l_gauss_fwd(const void* z, const int64_t* mask, float* tok, int64_t rows, int mask_div, int S,
@@ -853,39 +920,83 @@ static ColCfg col_cfg(int64_t rows, int64_t D, int dtype, bool aligned) {
 }
 }  // namespace
 
-extern "C" int mivae_reparam_logq_fwd(const void* mu, const void* sigma, const void* eps,
-                                      const int64_t* mask, void* z, float* tok_logq, int64_t B,
-                                      int64_t n, int64_t S, int64_t D, int dtype, void* stream) {
-  int rc = check_latent("reparam_logq_fwd", B * n, S, D, dtype);
+static int reparam_fwd_impl(const char* name, const void* mu, const void* sigma, const void* eps, const int64_t* rng,
+                            const int64_t* mask, void* z, float* tok_logq, int64_t B, int64_t n, int64_t S, int64_t D,
+                            int dtype, void* stream) {
+  int rc = check_latent(name, B * n, S, D, dtype);
   if (rc) return rc;
-  MIVAE_REQUIRE(n >= 1, "reparam_logq_fwd: samples must be >= 1");
+  MIVAE_REQUIRE(n >= 1, "%s: samples must be >= 1", name);
   if (B == 0) return MIVAE_OK;
-  MIVAE_REQUIRE(mu && sigma && z && tok_logq, "reparam_logq_fwd: null pointer");
+  MIVAE_REQUIRE(mu && sigma && z && tok_logq, "%s: null pointer", name);
   int64_t rows = B * n * S;
   bool al = aligned16(mu) && aligned16(sigma) && aligned16(z) && (!eps || aligned16(eps));
   RowCfg c = row_cfg(rows, D, dtype, al);
   DISPATCH(dtype, c.vec, l_reparam_fwd, mu, sigma, eps, mask, z, tok_logq, rows, (int)n, (int)S,
-           (int)D, c, S_(stream));
-  MIVAE_CHECK_LAUNCH("reparam_logq_fwd");
+           (int)D, c, S_(stream), rng);
+  MIVAE_CHECK_LAUNCH(name);
   return MIVAE_OK;
+}
+
+static int reparam_bwd_impl(const char* name, const void* dz, const float* dlogq, const void* sigma, const void* eps,
+                            const int64_t* rng, const int64_t* mask, void* dmu, void* dsigma, int64_t B, int64_t n,
+                            int64_t S, int64_t D, int dtype, void* stream) {
+  int rc = check_latent(name, B * n, S, D, dtype);
+  if (rc) return rc;
+  MIVAE_REQUIRE(n >= 1, "%s: samples must be >= 1", name);
+  if (B == 0) return MIVAE_OK;
+  MIVAE_REQUIRE(sigma && dmu && dsigma, "%s: null pointer", name);
+  int64_t prows = B * S;
+  bool al = aligned16(sigma) && aligned16(dmu) && aligned16(dsigma) && (!dz || aligned16(dz)) &&
+            (!eps || aligned16(eps));
+  RowCfg c = row_cfg(prows, D, dtype, al);
+  DISPATCH(dtype, c.vec, l_reparam_bwd, dz, dlogq, sigma, eps, mask, dmu, dsigma, prows, (int)n,
+           (int)S, (int)D, c, S_(stream), rng);
+  MIVAE_CHECK_LAUNCH(name);
+  return MIVAE_OK;
+}
+
+extern "C" int mivae_reparam_logq_fwd(const void* mu, const void* sigma, const void* eps,
+                                      const int64_t* mask, void* z, float* tok_logq, int64_t B,
+                                      int64_t n, int64_t S, int64_t D, int dtype, void* stream) {
+  return reparam_fwd_impl("reparam_logq_fwd", mu, sigma, eps, nullptr, mask, z, tok_logq, B, n, S, D, dtype, stream);
 }
 
 extern "C" int mivae_reparam_logq_bwd(const void* dz, const float* dlogq, const void* sigma,
                                       const void* eps, const int64_t* mask, void* dmu, void* dsigma,
                                       int64_t B, int64_t n, int64_t S, int64_t D, int dtype,
                                       void* stream) {
-  int rc = check_latent("reparam_logq_bwd", B * n, S, D, dtype);
-  if (rc) return rc;
-  MIVAE_REQUIRE(n >= 1, "reparam_logq_bwd: samples must be >= 1");
-  if (B == 0) return MIVAE_OK;
-  MIVAE_REQUIRE(sigma && dmu && dsigma, "reparam_logq_bwd: null pointer");
-  int64_t prows = B * S;
-  bool al = aligned16(sigma) && aligned16(dmu) && aligned16(dsigma) && (!dz || aligned16(dz)) &&
-            (!eps || aligned16(eps));
-  RowCfg c = row_cfg(prows, D, dtype, al);
-  DISPATCH(dtype, c.vec, l_reparam_bwd, dz, dlogq, sigma, eps, mask, dmu, dsigma, prows, (int)n,
-           (int)S, (int)D, c, S_(stream));
-  MIVAE_CHECK_LAUNCH("reparam_logq_bwd");
+  return reparam_bwd_impl("reparam_logq_bwd", dz, dlogq, sigma, eps, nullptr, mask, dmu, dsigma, B, n, S, D, dtype,
+                          stream);
+}
+
+// The same pair with eps drawn inside the kernels.  rng_state: device int64 {seed, offset} of the stream of draws
+// (the caller's generator); the forward COPIES it to rng_used (device int64[2], kept with the saved tensors), draws
+// eps = Normal(0, 1)(seed, offset, element) and then advances rng_state's offset by one, all on `stream`, so that a
+// captured HIP graph draws fresh noise at every replay.  The backward regenerates the draw from rng_used.
+extern "C" int mivae_reparam_logq_fwd_rng(const void* mu, const void* sigma, int64_t* rng_state, int64_t* rng_used,
+                                          const int64_t* mask, void* z, float* tok_logq, int64_t B, int64_t n,
+                                          int64_t S, int64_t D, int dtype, void* stream) {
+  MIVAE_REQUIRE(rng_state && rng_used, "reparam_logq_fwd_rng: null generator state");
+  k_rng_take<<<1, 64, 0, S_(stream)>>>(rng_state, rng_used);
+  MIVAE_CHECK_LAUNCH("reparam_logq_fwd_rng(take)");
+  return reparam_fwd_impl("reparam_logq_fwd_rng", mu, sigma, nullptr, rng_used, mask, z, tok_logq, B, n, S, D, dtype,
+                          stream);
+}
+
+extern "C" int mivae_reparam_logq_bwd_rng(const void* dz, const float* dlogq, const void* sigma,
+                                          const int64_t* rng_used, const int64_t* mask, void* dmu, void* dsigma,
+                                          int64_t B, int64_t n, int64_t S, int64_t D, int dtype, void* stream) {
+  MIVAE_REQUIRE(rng_used, "reparam_logq_bwd_rng: null generator state");
+  return reparam_bwd_impl("reparam_logq_bwd_rng", dz, dlogq, sigma, nullptr, rng_used, mask, dmu, dsigma, B, n, S, D,
+                          dtype, stream);
+}
+
+// eps ((B n), S, D) fp32 of the draw recorded in rng_used: what the two kernels above used (tests, debugging)
+extern "C" int mivae_philox_normal(const int64_t* rng_used, float* out, int64_t count, void* stream) {
+  MIVAE_REQUIRE(count >= 0 && (count == 0 || (rng_used && out)), "philox_normal: bad arguments");
+  if (count == 0) return MIVAE_OK;
+  k_philox_normal<<<(unsigned)((count + 4 * kBlock - 1) / (4 * kBlock)), kBlock, 0, S_(stream)>>>(rng_used, out, count);
+  MIVAE_CHECK_LAUNCH("philox_normal");
   return MIVAE_OK;
 }
 

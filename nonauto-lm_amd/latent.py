@@ -184,8 +184,11 @@ class Posterior(torch.nn.Module, Registrable):
         mu, pre = linear_group(encoded, [self._mu_net, self._sigma_net[0]])
         self._mu = mu
         self._sigma = self._sigma_net[2](self._sigma_net[1](pre))
-        noise = self._draw(self._mu, random, eps)
-        z, log_prob = ops.reparam_logq(self._mu, self._sigma, noise, mask, self.samples)
+        if random and eps is None and ops.PHILOX:        # eps drawn inside the kernel (Philox): no randn launch
+            z, log_prob = ops.reparam_logq_rng(self._mu, self._sigma, mask, self.samples)
+        else:                                            # injected eps (parity runs) / random=False
+            noise = self._draw(self._mu, random, eps)
+            z, log_prob = ops.reparam_logq(self._mu, self._sigma, noise, mask, self.samples)
         rep_mask = None if mask is None else mask.repeat_interleave(self.samples, dim=0)
         return z, rep_mask, log_prob
 

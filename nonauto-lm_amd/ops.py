@@ -145,6 +145,78 @@ class _ReparamLogQ(torch.autograd.Function):
         return dmu, dsg.to(ctx.sigma_dtype), None, None, None
 
 
+# In-kernel posterior noise (Philox): one generator state {seed, offset} per device, living in device memory (a captured
+# graph advances it by itself).  It follows torch's CUDA generator: whenever that generator's (seed, offset) is not
+# what this module left behind -- torch.manual_seed(), or any torch random op in between -- the device state is
+# re-based on it, so torch.manual_seed() makes runs reproducible; the seed is mixed with the rank so that every rank
+# draws different noise.  Every eager call also advances torch's offset (host-side bookkeeping only).
+PHILOX = True
+_PHILOX_STATE = {}
+
+
+def philox_state(device) -> torch.Tensor:
+    device = torch.device(device)
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    ent = _PHILOX_STATE.get(key)
+    if ent is not None and torch.cuda.is_current_stream_capturing():
+        return ent["state"]                 # no generator queries inside a capture: the device state carries on
+    gen = torch.cuda.default_generators[key]
+    cur = (gen.initial_seed(), gen.get_offset())
+    if ent is None or ent["next"] != cur:
+        import torch.distributed as dist
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        mixed = (cur[0] + rank * 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF
+        st = torch.tensor([mixed, cur[1] << 16], dtype=torch.int64).to(device)
+        if ent is None:
+            ent = _PHILOX_STATE[key] = {"state": st}
+        else:                               # keep the address (it may be baked into a captured graph)
+            ent["state"].copy_(st)
+    gen.set_offset(cur[1] + 4)
+    ent["next"] = (cur[0], cur[1] + 4)
+    return ent["state"]
+
+
+class _ReparamLogQRng(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mu, sigma, mask, n):
+        B, S, D = _shape3(mu)
+        mu_c, sg_c = mu.contiguous(), sigma.contiguous().to(mu.dtype)
+        ctx.sigma_dtype = sigma.dtype
+        z = torch.empty((B * n, *mu.shape[1:]), dtype=mu.dtype, device=mu.device)
+        tok = torch.empty(B * n * S, dtype=torch.float32, device=mu.device)
+        used = torch.empty(2, dtype=torch.int64, device=mu.device)
+        L.call("mivae_reparam_logq_fwd_rng", L.ptr(mu_c), L.ptr(sg_c), L.ptr(philox_state(mu.device)), L.ptr(used),
+               L.ptr(mask), L.ptr(z), L.ptr(tok), B, n, S, D, L.dtype_code(mu.dtype), L.stream())
+        logq = segment_sum(tok, B * n, S)
+        ctx.save_for_backward(sg_c, used, mask)
+        ctx.dims = (B, n, S, D)
+        return z, logq
+
+    @staticmethod
+    def backward(ctx, dz, dlogq):
+        sg, used, mask = ctx.saved_tensors
+        B, n, S, D = ctx.dims
+        dz = None if dz is None else dz.contiguous()
+        dlogq = None if dlogq is None else dlogq.contiguous().float()
+        dmu = torch.empty_like(sg)
+        dsg = torch.empty_like(sg)
+        L.call("mivae_reparam_logq_bwd_rng", L.ptr(dz), L.ptr(dlogq), L.ptr(sg), L.ptr(used), L.ptr(mask),
+               L.ptr(dmu), L.ptr(dsg), B, n, S, D, L.dtype_code(sg.dtype), L.stream())
+        return dmu, dsg.to(ctx.sigma_dtype), None, None
+
+
+def reparam_logq_rng(mu, sigma, mask, samples: int):
+    """reparam_logq with eps ~ N(0, 1) drawn inside the kernels (no randn launch, no eps tensor)."""
+    L.require_gpu(mu, sigma, mask)
+    return _ReparamLogQRng.apply(mu, sigma, _mask_i64(mask), int(samples))
+
+
+def philox_normal(used: torch.Tensor, count: int) -> torch.Tensor:
+    out = torch.empty(count, dtype=torch.float32, device=used.device)
+    L.call("mivae_philox_normal", L.ptr(used), L.ptr(out), count, L.stream())
+    return out
+
+
 def reparam_logq(mu, sigma, eps, mask, samples: int):
     """a4 + a5: z = (mu + eps * sigma) * mask (rearranged to (B n) ...), log q(z) per sample.
 

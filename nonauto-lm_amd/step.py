@@ -102,12 +102,14 @@ class TrainStep:
 
     # ---- snapshot of everything a warm-up / capture iteration touches ---------------------------
     def _snapshot(self):
+        from . import ops
         m = self.model
         snap = {
             "params": [p.detach().clone() for p in m.parameters()],
             "buffers": [b.detach().clone() for b in m.buffers()],
             "sched": (copy.deepcopy(m._recon_scheduler), copy.deepcopy(m._kl_scheduler)),
             "rng": torch.cuda.get_rng_state(self.tokens.device) if self.tokens.is_cuda else None,
+            "philox": ops.philox_state(self.tokens.device).clone() if self.tokens.is_cuda else None,
         }
         if isinstance(self.opt, dp.FusedAdam):
             snap["opt"] = {"step": self.opt.step_count.clone(), "m": [t.clone() for t in self.opt.exp_avg],
@@ -118,6 +120,7 @@ class TrainStep:
         return snap
 
     def _restore(self, snap):
+        from . import ops
         m = self.model
         with torch.no_grad():
             for p, s in zip(m.parameters(), snap["params"]):
@@ -140,6 +143,7 @@ class TrainStep:
         m._recon_scheduler, m._kl_scheduler = snap["sched"]
         if snap["rng"] is not None:
             torch.cuda.set_rng_state(snap["rng"], self.tokens.device)
+            ops.philox_state(self.tokens.device).copy_(snap["philox"])
         self.reducer.zero_grad()
 
     def _capture(self, warmup: int):

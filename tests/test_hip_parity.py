@@ -1365,3 +1365,72 @@ def test_rowgemm_rejects_wide_and_mismatched(M):
     with pytest.raises(ValueError):
         M.ops.rowgemm(torch.zeros(4, 16, device=DEV), torch.zeros(8, 8, device=DEV))
     assert M.ops.rowgemm(torch.zeros(0, 16, device=DEV), torch.eye(16, device=DEV)).shape == (0, 16)
+
+
+# ------------------------------------------------------------------------------------ in-kernel posterior noise (a4)
+@pytest.mark.parametrize("shape,n,dtype", [((6, 9, 16), 1, torch.float32), ((4, 7, 10), 3, torch.float32),
+                                           ((5, 24), 2, torch.float32), ((8, 33, 64), 2, torch.bfloat16)])
+def test_reparam_philox_matches_injected_eps(M, shape, n, dtype):
+    """mivae_reparam_logq_fwd_rng / _bwd_rng (eps drawn inside the kernels, Philox4x32-10 + Box-Muller) == the
+    injected-eps pair fed with the very draw the kernels used (mivae_philox_normal of the recorded state): z, log q and
+    both gradients, to fp32 rounding (bf16: eps stays fp32 in-kernel, the injected copy is rounded: 2e-2)."""
+    gen = torch.Generator().manual_seed(11)
+    B = shape[0]
+    mu = (torch.randn(*shape, generator=gen) * 0.7).to(DEV).to(dtype)
+    sigma = (torch.rand(*shape, generator=gen) + 0.3).to(DEV).to(dtype)
+    mask = None
+    if len(shape) == 3:
+        mask = (torch.rand(shape[0], shape[1], generator=gen) > 0.25).long().to(DEV)
+    torch.manual_seed(77)
+    st = M.ops.philox_state(DEV)
+    before = st.clone()
+    a, b = mu.clone().requires_grad_(True), sigma.clone().requires_grad_(True)
+    z, lq = M.ops.reparam_logq_rng(a, b, mask, n)
+    assert st.tolist() == [before[0].item(), before[1].item() + 1]          # one draw taken
+    eps = M.ops.philox_normal(before, B * n * mu[0].numel()).view(B, n, *shape[1:])
+    cz, cl = torch.randn(z.shape, device=DEV), torch.randn(lq.shape, device=DEV)
+    ((z.float() * cz).sum() + (lq * cl).sum()).backward()
+    a2, b2 = mu.clone().requires_grad_(True), sigma.clone().requires_grad_(True)
+    z2, lq2 = M.ops.reparam_logq(a2, b2, eps.to(dtype), mask, n)
+    ((z2.float() * cz).sum() + (lq2 * cl).sum()).backward()
+    tol = 1e-6 if dtype == torch.float32 else 2e-2
+    assert rel_err(z.float(), z2.float()) < tol and rel_err(lq, lq2) < tol
+    assert rel_err(a.grad.float(), a2.grad.float()) < tol and rel_err(b.grad.float(), b2.grad.float()) < tol
+    # and the CPU oracle on the same draw (fp32)
+    if dtype == torch.float32:
+        zr, mrep = O.posterior_sample(mu.cpu(), sigma.cpu(), eps.cpu(), None if mask is None else mask.cpu(), n)
+        assert rel_err(z, zr) < TOL
+        assert rel_err(lq, O.posterior_log_prob(zr, mu.cpu(), sigma.cpu(), mrep, n)) < TOL
+
+
+def test_philox_normal_statistics_and_determinism(M):
+    """The in-kernel draw is standard normal (moments, tails, no correlation between neighbours and between
+    successive draws) and a pure function of (seed, offset)."""
+    st = torch.tensor([1234, 5], dtype=torch.int64, device=DEV)
+    x = M.ops.philox_normal(st, 1 << 22)
+    assert torch.equal(x, M.ops.philox_normal(st.clone(), 1 << 22))
+    y = M.ops.philox_normal(torch.tensor([1234, 6], dtype=torch.int64, device=DEV), 1 << 22)
+    w = M.ops.philox_normal(torch.tensor([1235, 5], dtype=torch.int64, device=DEV), 1 << 22)
+    for t in (x, y, w):
+        assert abs(float(t.mean())) < 3e-3 and abs(float(t.var()) - 1) < 5e-3
+        assert abs(float((t ** 3).mean())) < 1e-2 and abs(float((t ** 4).mean()) - 3) < 3e-2
+        assert bool(torch.isfinite(t).all()) and float(t.abs().max()) > 4.0
+    corr = lambda a, b: abs(float((a * b).mean()))
+    assert corr(x, y) < 3e-3 and corr(x, w) < 3e-3 and corr(x[:-1], x[1:]) < 3e-3 and corr(x[:-2], x[2:]) < 3e-3
+    # an odd count (tail quad) and the ragged VEC = 1 path of the kernels read the same stream
+    assert torch.equal(M.ops.philox_normal(st, 1001), x[:1001])
+
+
+def test_posterior_module_uses_philox_and_is_seed_reproducible(M):
+    post = M.DefaultPosterior(12, 8, samples=2).to(DEV)
+    enc = torch.randn(4, 6, 12, device=DEV)
+    mask = torch.ones(4, 6, dtype=torch.long, device=DEV)
+    torch.manual_seed(5)
+    l1, q1 = post(enc, mask)
+    l1b, _ = post(enc, mask)
+    torch.manual_seed(5)
+    l2, q2 = post(enc, mask)
+    assert torch.equal(l1.z, l2.z) and torch.equal(q1, q2)          # torch.manual_seed controls the stream
+    assert not torch.equal(l1.z, l1b.z)                              # successive draws differ
+    eps = (l1.z.view(4, 2, 6, 8) - l1.mu.unsqueeze(1)) / l1.sigma.unsqueeze(1)
+    assert abs(float(eps.mean())) < 0.2 and abs(float(eps.std()) - 1) < 0.2
