@@ -695,25 +695,30 @@ __global__ void __launch_bounds__(512) k_big_chain(BigArgs a) {
         } else {           // CHAIN: x1 holds d loss / d x1_k; emit d s_k, d t_k and step back
           T* dS = a.dSdT + ((int64_t)(k * 2) * a.N + tok) * h;
           T* dT = dS + a.N * (int64_t)h;
-          f32x4 xp[NF], ds[NF], dt[NF];
+          // tile by tile (no NF-sized temporaries: at h = 256 they would not fit next to acc and x1);
           // masked tokens read as zeros (the forward does not write the history of all-padding blocks)
-          load_tiles<NF>(a.x1_hist + ((int64_t)k * a.N + tok) * h, on, h, g, xp);
+          const T* xh = a.x1_hist + ((int64_t)k * a.N + tok) * h;
 #pragma unroll
           for (int v = 0; v < NF; ++v) {
+            const int ft = 16 * v + 4 * g;
+            float xp[4] = {0.f, 0.f, 0.f, 0.f};
+            if (on && ft < h) RowIO<T, 4>::load(xh + ft, xp);
             const f32x4 bt = lds4(b2 + 16 * v);
+            float ds[4], dt[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const bool in = 16 * v + 4 * g + r < h;
               const float g1 = x1[v][r] * m;
               const float ge = g1 * fast_exp(acc[v][r] + bt[r]);
-              dt[v][r] = g1;
-              ds[v][r] = in ? ge * xp[v][r] + dl : 0.f;
+              dt[r] = g1;
+              ds[r] = ge * xp[r] + dl;
               x1[v][r] = ge;
               acc[v][r] = 0.f;
             }
+            if (valid && ft < h) {
+              RowIO<T, 4>::store(dS + ft, ds);
+              RowIO<T, 4>::store(dT + ft, dt);
+            }
           }
-          store_tiles<NF>(dS, valid, h, g, ds);
-          store_tiles<NF>(dT, valid, h, g, dt);
         }
       }
     }
@@ -1030,7 +1035,14 @@ __global__ void __launch_bounds__(512) k_big_dw(DwBigArgs a) {
   const int lane = threadIdx.x & 63;
   const int r16 = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int slab = blockIdx.x, kn = blockIdx.y, hw = blockIdx.z * 8 + wave;
+  // XCD-aware block order: consecutive block ids go round-robin over the 8 XCDs (each with its own L2), and the Z
+  // blocks that walk the SAME token tiles of the same (step, net) for different hidden units should share one L2:
+  // within an XCD (ids id % 8 equal) consecutive blocks are the Z siblings of one (slab, kn) group.
+  const int Z = (a.HW + 7) / 8;
+  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+  const int zb = jx % Z, grp = (jx / Z) * 8 + xcd;
+  if (grp >= a.nslab * 2 * a.K) return;
+  const int slab = grp % a.nslab, kn = grp / a.nslab, hw = zb * 8 + wave;
   const int h = a.h;
   const bool wave_on = hw < a.HW;
   const int k = kn >> 1, net = kn & 1;
@@ -1067,7 +1079,7 @@ __global__ void __launch_bounds__(512) k_big_dw(DwBigArgs a) {
   float db2[DO2 ? NF : 1];
 #pragma unroll
   for (int v = 0; v < (DO2 ? NF : 1); ++v) db2[v] = 0.f;
-  const bool want_b2 = DO2 && blockIdx.z == 0 && wave == 0;
+  const bool want_b2 = DO2 && zb == 0 && wave == 0;
 
   // ---- staging: LDS-DMA, 16 bytes per lane, NBUF tile buffers: tiles n-1, n, n+1 are in use by body n and PD = NBUF - 3
   // tiles are in flight (tile n+2 lands by the end of body n).  Chunk id = threadIdx.x + NTH u of a tile lands at LDS byte 16 id (lane linear); the XOR
@@ -1568,7 +1580,8 @@ extern "C" int mivae_nice_big_bwd(const void* z_in, const void* z_out, const voi
     a.partb1 = workspace + nitems * 4 * g.HT * 256;
     a.partb2 = a.partb1 + nitems * 16;
     const int nw = 8;
-    dim3 dgrid((unsigned)a.nslab, (unsigned)(K * 2), (unsigned)((a.HW + nw - 1) / nw));
+    const int64_t ngrp = (int64_t)a.nslab * K * 2, zsib = (a.HW + nw - 1) / nw;
+    dim3 dgrid((unsigned)(((ngrp + 7) / 8) * 8 * zsib));   // 1-D: see the block order in k_big_dw
     const size_t dlds = (size_t)(g.HT <= 4 ? 6 : 4) * 2 * 32 * g.HT * 64;   // NBUF tile buffers x 2 operands
 #define CALL(HTc, ACTc) launch_dw<HTc, ACTc>(a, dgrid, dlds, st)
     BIG_DISPATCH(g.HT, act, CALL);

@@ -37,8 +37,13 @@ def timed(fn, iters):
 
 
 def main():
-    names = [a for a in sys.argv[1:] if not a.startswith("--")] or ["c2", "c3"]
+    argv = sys.argv[1:]
     iters = 30
+    if "--iters" in argv:
+        i = argv.index("--iters")
+        iters = int(argv[i + 1])
+        del argv[i:i + 2]
+    names = [a for a in argv if not a.startswith("--")] or ["c2", "c3"]
     dev = torch.device("cuda")
     for name in names:
         B, S, D, H, K, dt = CONFIGS[name]
