@@ -914,11 +914,47 @@ __global__ void __launch_bounds__(512) k_big_nets(NetsArgs a) {
         if (c2 == 0 && j2 < NJ) load_dout(j2);
         // C(i): dx0 += W1T frags . d pre(i);  A(i+2);  B(i+1) -> d pre(i+1)   (tasks past the end: zero padding)
         const bf16x8* wt = reinterpret_cast<const bf16x8*>(itT) + lane;
-#pragma unroll
-        for (int v = 0; v < NF; ++v) dx0[v] = mma16(wt[v * 64], gb, dx0[v]);
         f32x4 pre2[2], dh2[2];
-        stage_a(itA, itB, bias_lds + (j2 & 3) * kBiasBlockFloats + 32 * c2, pre2, dh2);
-        gb = stage_b(pre1, dh1);
+        if constexpr (HT <= 4) {
+          // Phases pinned in program order: fragment reads a whole phase ahead of the MFMAs that consume them (left to
+          // itself the scheduler waits for every read right before its MFMA: 24 exposed LDS latencies per task).
+          //   reads C(i) + A(i+2) first layer | B(i+1) (VALU) | MFMAs C | reads A(i+2) second layer | MFMAs A
+          const bf16x8* w1 = reinterpret_cast<const bf16x8*>(itA) + lane;
+          const bf16x8* w2 = reinterpret_cast<const bf16x8*>(itB) + lane;
+          const float* b1c = bias_lds + (j2 & 3) * kBiasBlockFloats + 32 * c2;
+          bf16x8 ft[NF], f1[2 * HT], f2[2 * HT];
+#pragma unroll
+          for (int v = 0; v < NF; ++v) ft[v] = wt[v * 64];
+#pragma unroll
+          for (int u = 0; u < 2 * HT; ++u) f1[u] = w1[u * 64];
+          pre2[0] = lds4(b1c + 4 * g); pre2[1] = lds4(b1c + 16 + 4 * g);
+          __builtin_amdgcn_sched_barrier(0);
+          const bf16x8 gbn = stage_b(pre1, dh1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int v = 0; v < NF; ++v) dx0[v] = mma16(ft[v], gb, dx0[v]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < 2 * HT; ++u) f2[u] = w2[u * 64];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ks = 0; ks < HT; ++ks) {
+            pre2[0] = mma16(f1[ks], x0f[ks], pre2[0]);
+            pre2[1] = mma16(f1[HT + ks], x0f[ks], pre2[1]);
+          }
+          dh2[0] = f32x4{0.f, 0.f, 0.f, 0.f}; dh2[1] = dh2[0];
+#pragma unroll
+          for (int ks = 0; ks < HT; ++ks) {
+            dh2[0] = mma16(f2[ks], dob[ks], dh2[0]);
+            dh2[1] = mma16(f2[HT + ks], dob[ks], dh2[1]);
+          }
+          gb = gbn;
+        } else {
+#pragma unroll
+          for (int v = 0; v < NF; ++v) dx0[v] = mma16(wt[v * 64], gb, dx0[v]);
+          stage_a(itA, itB, bias_lds + (j2 & 3) * kBiasBlockFloats + 32 * c2, pre2, dh2);
+          gb = stage_b(pre1, dh1);
+        }
         pre1[0] = pre2[0]; pre1[1] = pre2[1]; dh1[0] = dh2[0]; dh1[1] = dh2[1];
       }
     }
