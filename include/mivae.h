@@ -408,6 +408,8 @@ int mivae_nice_big_supported(int64_t h, int64_t H, int dtype);
 int64_t mivae_nice_big_pack_bytes(int64_t K, int64_t h, int64_t H, int stream_kind);
 int mivae_nice_big_pack(const int64_t* ptr_table, void* out, int64_t K, int64_t h, int64_t H, int stream_kind,
                         void* stream);
+/* several streams in one launch: outs[kind] = destination of that stream or NULL (5 entries, host array) */
+int mivae_nice_big_pack_multi(const int64_t* ptr_table, void* const* outs, int64_t K, int64_t h, int64_t H, void* stream);
 /* z_out, x1_hist (K, N, h) or NULL, tok_val (N) exactly as mivae_nice_stack_fwd; packed_stream = kind 0 (inverse = 0)
  * or kind 1 (inverse = 1), packed_bias = kind 4. */
 int mivae_nice_big_fwd(const void* z_in, void* z_out, void* x1_hist, const int64_t* mask, const void* packed_stream,

@@ -258,8 +258,8 @@ __device__ __forceinline__ void task_of(const BigGeom& g, int st, int64_t i, int
   else if (st == ST_INV) { k = g.K - 1 - kk; net = 1 - nn; }
   else { k = g.K - 1 - kk; net = nn; }
 }
-__global__ void __launch_bounds__(256) k_big_pack(const int64_t* __restrict__ ptrs, char* __restrict__ out, BigGeom g, int st) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pack_elem(const int64_t* __restrict__ ptrs, char* __restrict__ out, const BigGeom& g, int st,
+                                          int64_t idx) {
   if (st == ST_BIAS) {
     if (idx >= (int64_t)g.K * 2 * kBiasBlockFloats) return;
     const int kn = (int)(idx / kBiasBlockFloats), e = (int)(idx % kBiasBlockFloats);
@@ -319,6 +319,21 @@ __global__ void __launch_bounds__(256) k_big_pack(const int64_t* __restrict__ pt
     }
   }
   reinterpret_cast<unsigned short*>(out)[idx] = f32_to_bf16(v);
+}
+__global__ void __launch_bounds__(256) k_big_pack(const int64_t* __restrict__ ptrs, char* __restrict__ out, BigGeom g, int st) {
+  pack_elem(ptrs, out, g, st, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+// several streams of the same weights in ONE launch: blocks [first[s], first[s + 1]) pack stream s
+struct PackMulti {
+  char* out[ST_BIAS + 1];
+  unsigned first[ST_BIAS + 2];
+};
+__global__ void __launch_bounds__(256) k_big_pack_multi(const int64_t* __restrict__ ptrs, PackMulti m, BigGeom g) {
+  int st = 0;
+#pragma unroll
+  for (int s2 = 1; s2 <= ST_BIAS; ++s2)
+    if (blockIdx.x >= m.first[s2]) st = s2;
+  pack_elem(ptrs, m.out[st], g, st, (int64_t)(blockIdx.x - m.first[st]) * blockDim.x + threadIdx.x);
 }
 
 // ---- forward / inverse / backward-chain kernel --------------------------------------------------------------
@@ -1501,6 +1516,30 @@ extern "C" int mivae_nice_big_pack(const int64_t* ptr_table, void* out, int64_t 
   const int64_t n = stream_kind == ST_BIAS ? K * 2 * kBiasBlockFloats : stream_items(g, stream_kind) * (g.item / 2);
   k_big_pack<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(ptr_table, (char*)out, g, stream_kind);
   MIVAE_CHECK_LAUNCH("nice_big_pack");
+  return MIVAE_OK;
+}
+
+// The same packing for several streams at once: outs[kind] (kind as above; NULL = skip), each
+// mivae_nice_big_pack_bytes(K, h, H, kind) bytes, 16-byte aligned.  One launch instead of one per stream.
+extern "C" int mivae_nice_big_pack_multi(const int64_t* ptr_table, void* const* outs, int64_t K, int64_t h, int64_t H,
+                                         void* stream) {
+  MIVAE_REQUIRE(ptr_table && outs, "nice_big_pack_multi: null pointer");
+  MIVAE_REQUIRE(K >= 1 && K <= 4096 && big_shape_ok(h, H), "nice_big_pack_multi: unsupported shape K=%ld h=%ld H=%ld", (long)K, (long)h, (long)H);
+  const BigGeom g = big_geom_inst((int)h, (int)H, (int)K);
+  PackMulti m = {};
+  unsigned total = 0;
+  for (int st = 0; st <= ST_BIAS; ++st) {
+    m.first[st] = total;
+    m.out[st] = (char*)outs[st];
+    if (!outs[st]) continue;
+    MIVAE_REQUIRE(aligned16(outs[st]), "nice_big_pack_multi: outputs must be 16-byte aligned");
+    const int64_t n = st == ST_BIAS ? K * 2 * kBiasBlockFloats : stream_items(g, st) * (g.item / 2);
+    total += (unsigned)((n + 255) / 256);
+  }
+  m.first[ST_BIAS + 1] = total;
+  if (total == 0) return MIVAE_OK;
+  k_big_pack_multi<<<total, 256, 0, (hipStream_t)stream>>>(ptr_table, m, g);
+  MIVAE_CHECK_LAUNCH("nice_big_pack_multi");
   return MIVAE_OK;
 }
 

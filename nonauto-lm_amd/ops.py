@@ -1179,6 +1179,20 @@ def nice_big_pack(params: Sequence[torch.Tensor], K: int, h: int, H: int, kind: 
     return out
 
 
+def nice_big_pack_multi(params: Sequence[torch.Tensor], K: int, h: int, H: int, kinds: Sequence[str]):
+    """Several packed streams of the same weights in ONE launch: {kind: uint8 tensor}."""
+    dev = params[0].device
+    for p in params:
+        if p.dtype != torch.float32 or not p.is_contiguous():
+            raise TypeError("NICE parameters must be contiguous float32 tensors")
+    outs = {k: torch.empty(L.query("mivae_nice_big_pack_bytes", K, h, H, BIG_STREAMS[k]), dtype=torch.uint8, device=dev)
+            for k in kinds}
+    by_code = {BIG_STREAMS[k]: t for k, t in outs.items()}
+    L.call("mivae_nice_big_pack_multi", L.ptr(_ptr_table(params, dev)), _ptr_array([by_code.get(c) for c in range(5)]),
+           K, h, H, L.stream())
+    return outs
+
+
 class _NiceStackBig(torch.autograd.Function):
     """K fused NICE-FF steps (+ optional base log-prob) on the wide-latent kernels.  params as _NiceStack."""
 
@@ -1189,9 +1203,11 @@ class _NiceStackBig(torch.autograd.Function):
         K = len(params) // 8
         z = z.contiguous()
         N = Bn * S
-        pk = nice_big_pack(params, K, h, H, "inv" if inverse else "fwd")
-        pb = nice_big_pack(params, K, h, H, "bias")
         need_grad = (not inverse) and any(ctx.needs_input_grad)
+        # every stream this call (and its backward) reads, packed in one launch
+        kinds = ["inv" if inverse else "fwd", "bias"] + (["chain", "nets"] if need_grad else [])
+        packed = nice_big_pack_multi(params, K, h, H, kinds)
+        pk, pb = packed[kinds[0]], packed["bias"]
         z_out = torch.empty_like(z)
         hist = torch.empty(K, N, h, dtype=z.dtype, device=z.device) if need_grad else None
         tok = torch.empty(N, dtype=torch.float32, device=z.device)
@@ -1201,18 +1217,16 @@ class _NiceStackBig(torch.autograd.Function):
         ctx.meta = (Bn, S, D, H, K, act, int(base), float(mu), float(std))
         ctx.params = params
         if need_grad:
-            ctx.save_for_backward(z, z_out, hist, mask, pb)
+            ctx.save_for_backward(z, z_out, hist, mask, pb, packed["chain"], packed["nets"])
         return z_out, tok
 
     @staticmethod
     def backward(ctx, dz_out, dtok):
-        z, z_out, hist, mask, pb = ctx.saved_tensors
+        z, z_out, hist, mask, pb, pc, pn = ctx.saved_tensors
         Bn, S, D, H, K, act, base, mu, std = ctx.meta
         h, N = D // 2, Bn * S
         dev = z.device
         params = ctx.params
-        pc = nice_big_pack(params, K, h, H, "chain")
-        pn = nice_big_pack(params, K, h, H, "nets")
         dz_in = torch.empty_like(z)
         dsdt = torch.empty(K, 2, N, h, dtype=z.dtype, device=dev)
         ws = torch.empty(L.query("mivae_nice_big_dw_workspace_floats", N, h, H, K), dtype=torch.float32, device=dev)
