@@ -397,6 +397,16 @@ int mivae_maf_sequential_supported(int64_t D, int64_t Hp);
 int mivae_maf_sequential(const void* z, const float* w1t, const float* b1, const float* w2, const float* b2,
                          const int64_t* mask, void* out, float* tok_ld, int64_t rows, int64_t D, int64_t Hp, int act,
                          int parity, int dtype, void* stream);
+/* Backward of mivae_maf_sequential -- autograd of the loop of MAFlow.backward (maf.py:47-62), which is the TRAINING
+ * direction of IAFlow (iaf.py:21-23): x = that call's `out`; dout (rows, D) / dtok (rows) = cotangents of out / tok_ld
+ * (each may be NULL).  Writes dz (rows, D) and mivae_maf_sequential_bwd_blocks(rows) rows of
+ * [dW1t (D, Hp) | dW2 (2D, Hp) | db1 (Hp) | db2 (2D)] fp32 partials in the packed (masked) layout above; sum the rows
+ * with mivae_colsum (fixed order).  Supported when the gradient image (3 D Hp floats) fits the LDS. */
+int mivae_maf_sequential_bwd_supported(int64_t D, int64_t Hp);
+int64_t mivae_maf_sequential_bwd_blocks(int64_t rows);
+int mivae_maf_sequential_bwd(const void* x, const void* dout, const float* dtok, const float* w1t, const float* b1,
+                             const float* w2, const float* b2, const int64_t* mask, void* dz, float* part, int64_t rows,
+                             int64_t D, int64_t Hp, int act, int parity, int dtype, void* stream);
 
 /* ---- NICE stack, wide latents (96 < D/2 <= 256, bf16): MFMA-bound re-tiling of the same path ------------------
  * Same arithmetic and outputs as mivae_nice_stack_fwd / _bwd + mivae_nice_dw (NICECoupling.forward / .backward,

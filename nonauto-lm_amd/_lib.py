@@ -44,6 +44,9 @@ SIGNATURES = {
     "mivae_reparam_logq_fwd_rng": [P, P, P, P, P, P, P, I64, I64, I64, I64, I32, P],
     "mivae_reparam_logq_bwd_rng": [P, P, P, P, P, P, P, I64, I64, I64, I64, I32, P],
     "mivae_philox_normal": [P, P, I64, P],
+    "mivae_maf_sequential_bwd": [P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I32, I32, I32, P],
+    "mivae_maf_sequential_bwd_supported": [I64, I64],
+    "mivae_maf_sequential_bwd_blocks": [I64],
     "mivae_rowgemm": [P, P, P, I64, I64, I32, P],
     "mivae_rowgemm_wgrad": [P, P, P, I64, I64, I32, P],
     "mivae_rowgemm_wgrad_slabs": [I64, I64],
@@ -106,6 +109,7 @@ _RET = {
     "mivae_colsum_static_max_floats": I64,
     "mivae_nice_pack_bytes": I64,
     "mivae_sumsq_blocks": I64,
+    "mivae_maf_sequential_bwd_blocks": I64,
     "mivae_rowgemm_wgrad_slabs": I64,
     "mivae_lce_workspace_floats": I64,
     "mivae_lce_pack_elems": I64,

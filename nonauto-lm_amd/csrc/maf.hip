@@ -225,6 +225,183 @@ int launch_seq(const SeqArgs& a, int act, size_t lds, unsigned grid, hipStream_t
   return MIVAE_OK;
 }
 
+// ---- backward of the sequential direction (IAFlow's training direction / gradients through MAFlow.backward) ---------
+// Autograd of the recurrence of k_maf_seq for one token, walked in REVERSE without any saved intermediate:
+//   pre_D = b1 + sum_i x_i W1m[:, i]                      (a plain product of the saved outputs x: no sequential chain)
+//   for i = D-1 .. 0:   pre_i = pre_{i+1} - x_i W1m[:, i];  h = act(pre_i);  s_i = b2[i] + h . W2[i]
+//                       dx_i = g_i + A . W1m[:, i]          (A = d loss / d pre_{i+1}: the contributions of all later steps)
+//                       dz'_i = dx_i e^{-s_i};  dt_i = -dz'_i;  ds_i = -dx_i x_i + g_ld
+//                       dW1m[:, i] += x_i A;  dW2[i] += ds_i h;  dW2[D+i] += dt_i h;  db2[i] += ds_i;  db2[D+i] += dt_i
+//                       A += act'(pre_i) (ds_i W2[i] + dt_i W2[D+i])
+//   db1 += A
+// One wave per block walks tokens one at a time: lane l owns hidden units l, l + 64, ... (HQ per lane), so the per-unit
+// state (pre, A) lives in registers, the two dot products per step are wave reductions, and the parameter gradients
+// accumulate in LDS columns that only their own lane touches (no atomics, no conflicts).  Padding tokens are skipped
+// (wave-uniform).  Every block leaves one image [dW1t | dW2 | db1 | db2]; the images are summed in block order by
+// mivae_colsum (fixed order: run-to-run reproducible).  VALU-bound, ~the forward's arithmetic x 3.
+template <int ACT>
+__device__ __forceinline__ void act_fd(float x, float& f, float& d) {
+  if (ACT == 0) { f = x; d = 1.f; }
+  else if (ACT == 1) {
+    const float cdf = 0.5f * (1.0f + erff(x * kInvSqrt2));
+    f = x * cdf; d = cdf + x * 0.3989422804014327f * expf(-0.5f * x * x);
+  } else if (ACT == 2) { const float sg = 1.0f / (1.0f + expf(-x)); f = x * sg; d = sg * (1.0f + x * (1.0f - sg)); }
+  else if (ACT == 3) { f = fmaxf(x, 0.f); d = x > 0.f ? 1.f : 0.f; }
+  else if (ACT == 4) { f = tanhf(x); d = 1.0f - f * f; }
+  else if (ACT == 5) { f = 1.0f / (1.0f + expf(-x)); d = f * (1.0f - f); }
+  else { const float em = expm1f(x); f = x > 0.f ? x : em; d = x > 0.f ? 1.f : em + 1.0f; }
+}
+
+struct SeqBwdArgs {
+  const void* x;        // (rows, D): the forward's output
+  const void* dout;     // (rows, D) or null
+  const float* dtok;    // (rows) or null: cotangent of tok_ld
+  const int64_t* mask;  // (rows) or null
+  const float *w1t, *b1, *w2, *b2;
+  void* dz;             // (rows, D)
+  float* part;          // [gridDim.x][3 D Hp + Hp + 2 D]
+  int64_t rows;
+  int D, Hp, parity;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+template <typename T, int ACT, int HQ>
+__global__ __launch_bounds__(64) void k_maf_seq_bwd(SeqBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int D = a.D, Hp = a.Hp, lane = threadIdx.x;
+  float* gW1 = smem;                  // [D][Hp]
+  float* gW2 = gW1 + D * Hp;          // [2D][Hp]
+  float* gb2 = gW2 + 2 * D * Hp;      // [2D]
+  float* xr = gb2 + 2 * D;            // [D]   x of the current token
+  float* gr = xr + D;                 // [D]   d loss / d out of the current token
+  float* zr = gr + D;                 // [D]   d z of the current token (already in z's feature order)
+  for (int i = lane; i < 3 * D * Hp + 2 * D; i += 64) smem[i] = 0.f;
+  int jq[HQ];
+  bool jon[HQ];
+  float gb1[HQ], b1v[HQ];
+#pragma unroll
+  for (int q = 0; q < HQ; ++q) {
+    jq[q] = q * 64 + lane; jon[q] = jq[q] < Hp;
+    if (!jon[q]) jq[q] = 0;           // idle lanes (Hp < 64) read unit 0 and contribute nothing
+    gb1[q] = 0.f; b1v[q] = a.b1[jq[q]];
+  }
+  const T* X = static_cast<const T*>(a.x);
+  const T* G = static_cast<const T*>(a.dout);
+  T* DZ = static_cast<T*>(a.dz);
+  __syncthreads();
+  for (int64_t r = blockIdx.x; r < a.rows; r += gridDim.x) {
+    const bool live = !a.mask || a.mask[r] != 0;
+    if (!live) {                      // out = x * 0, tok_ld = ld * 0: no gradient reaches this token
+      for (int c = lane; c < D; c += 64) { float o[1] = {0.f}; RowIO<T, 1>::store(DZ + r * D + c, o); }
+      continue;
+    }
+    for (int c = lane; c < D; c += 64) {
+      float t1[1];
+      RowIO<T, 1>::load(X + r * D + c, t1);
+      xr[c] = t1[0];
+      float g1[1] = {0.f};
+      if (G) RowIO<T, 1>::load(G + r * D + c, g1);
+      gr[c] = g1[0];
+    }
+    const float gld = a.dtok ? a.dtok[r] : 0.f;
+    __syncthreads();
+    float pre[HQ], A[HQ];
+#pragma unroll
+    for (int q = 0; q < HQ; ++q) { pre[q] = b1v[q]; A[q] = 0.f; }
+    for (int i = 0; i < D; ++i) {
+      const float xi = xr[i];
+#pragma unroll
+      for (int q = 0; q < HQ; ++q) pre[q] = fmaf(xi, a.w1t[i * Hp + jq[q]], pre[q]);
+    }
+    for (int i = D - 1; i >= 0; --i) {
+      const float xi = xr[i];
+      float w1v[HQ], ws[HQ], wt[HQ], h[HQ], dh[HQ];
+      float sp = 0.f, ad = 0.f;
+#pragma unroll
+      for (int q = 0; q < HQ; ++q) {
+        w1v[q] = a.w1t[i * Hp + jq[q]];
+        ws[q] = a.w2[i * Hp + jq[q]];
+        wt[q] = a.w2[(D + i) * Hp + jq[q]];
+        pre[q] = fmaf(-xi, w1v[q], pre[q]);
+        act_fd<ACT>(pre[q], h[q], dh[q]);
+        if (!jon[q]) { h[q] = 0.f; dh[q] = 0.f; }
+        sp = fmaf(h[q], ws[q], sp);
+        ad = fmaf(A[q], w1v[q], ad);
+      }
+      sp = wave_sum(sp);
+      ad = wave_sum(ad);
+      const float s = sp + a.b2[i];
+      const float dx = gr[i] + ad;
+      const float dzi = dx * expf(-s);
+      const float dt = -dzi, ds = fmaf(-dx, xi, gld);
+#pragma unroll
+      for (int q = 0; q < HQ; ++q) {
+        if (jon[q]) {
+          gW1[i * Hp + jq[q]] += xi * A[q];
+          gW2[i * Hp + jq[q]] += ds * h[q];
+          gW2[(D + i) * Hp + jq[q]] += dt * h[q];
+        }
+        A[q] = fmaf(dh[q], fmaf(ds, ws[q], dt * wt[q]), A[q]);
+      }
+      if (lane == 0) {
+        gb2[i] += ds; gb2[D + i] += dt;
+        zr[a.parity ? D - 1 - i : i] = dzi;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < HQ; ++q) gb1[q] += jon[q] ? A[q] : 0.f;
+    __syncthreads();
+    for (int c = lane; c < D; c += 64) { float o[1] = {zr[c]}; RowIO<T, 1>::store(DZ + r * D + c, o); }
+    __syncthreads();
+  }
+  float* P = a.part + (int64_t)blockIdx.x * (3 * D * Hp + Hp + 2 * D);
+  for (int i = lane; i < 3 * D * Hp; i += 64) P[i] = smem[i];
+#pragma unroll
+  for (int q = 0; q < HQ; ++q)
+    if (jon[q]) P[3 * D * Hp + jq[q]] = gb1[q];
+  for (int i = lane; i < 2 * D; i += 64) P[3 * D * Hp + Hp + i] = gb2[i];
+}
+
+static size_t seq_bwd_lds_bytes(int D, int Hp) { return ((size_t)3 * D * Hp + 5 * D) * sizeof(float); }
+static bool seq_bwd_supported(int64_t D, int64_t Hp) {
+  return seq_supported(D, Hp) && seq_bwd_lds_bytes((int)D, (int)Hp) <= 156 * 1024;
+}
+static int seq_bwd_blocks(int64_t rows) { return (int)(rows < 768 ? (rows < 1 ? 1 : rows) : 768); }
+
+template <typename T, int ACT>
+int launch_seq_bwd_hq(const SeqBwdArgs& a, size_t lds, unsigned grid, hipStream_t st) {
+  const int hq = (a.Hp + 63) / 64;
+#define MAF_BWD_HQ(Q)                                                                                     \
+  {                                                                                                       \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_maf_seq_bwd<T, ACT, Q>),          \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
+    if (e != hipSuccess) { mivae_set_error("maf_sequential_bwd: LDS opt-in failed: %s", hipGetErrorString(e)); \
+                           return MIVAE_ELAUNCH; }                                                        \
+    k_maf_seq_bwd<T, ACT, Q><<<grid, 64, lds, st>>>(a);                                                   \
+  }
+  if (hq <= 1) MAF_BWD_HQ(1) else if (hq == 2) MAF_BWD_HQ(2) else MAF_BWD_HQ(4)
+#undef MAF_BWD_HQ
+  return MIVAE_OK;
+}
+template <typename T>
+int launch_seq_bwd(const SeqBwdArgs& a, int act, size_t lds, unsigned grid, hipStream_t st) {
+  switch (act) {
+    case 0: return launch_seq_bwd_hq<T, 0>(a, lds, grid, st);
+    case 1: return launch_seq_bwd_hq<T, 1>(a, lds, grid, st);
+    case 2: return launch_seq_bwd_hq<T, 2>(a, lds, grid, st);
+    case 3: return launch_seq_bwd_hq<T, 3>(a, lds, grid, st);
+    case 4: return launch_seq_bwd_hq<T, 4>(a, lds, grid, st);
+    case 5: return launch_seq_bwd_hq<T, 5>(a, lds, grid, st);
+    case 6: return launch_seq_bwd_hq<T, 6>(a, lds, grid, st);
+    default: mivae_set_error("maf_sequential_bwd: unknown activation %d", act); return MIVAE_EINVAL;
+  }
+}
+
 struct AffCfg { int vec, L; unsigned grid; };
 static AffCfg aff_cfg(int64_t rows, int64_t D, int dtype, bool aligned) {
   AffCfg c;
@@ -304,5 +481,35 @@ extern "C" int mivae_maf_sequential(const void* z, const float* w1t, const float
                                     : launch_seq<unsigned short>(a, act, lds, grid, S_(stream));
   if (rc != MIVAE_OK) return rc;
   MIVAE_CHECK_LAUNCH("maf_sequential");
+  return MIVAE_OK;
+}
+
+extern "C" int mivae_maf_sequential_bwd_supported(int64_t D, int64_t Hp) { return seq_bwd_supported(D, Hp) ? 1 : 0; }
+// rows of the partial matrix mivae_maf_sequential_bwd writes; each row holds [dW1t (D, Hp) | dW2 (2D, Hp) | db1 (Hp) |
+// db2 (2D)] floats in the packed layout of mivae_maf_sequential
+extern "C" int64_t mivae_maf_sequential_bwd_blocks(int64_t rows) { return seq_bwd_blocks(rows); }
+
+// Backward of mivae_maf_sequential: x = that call's `out` (rows, D), dout (rows, D) or NULL and dtok (rows) or NULL the
+// cotangents of out and tok_ld; writes dz (rows, D) and the per-block parameter-gradient partials (sum the rows of
+// `part` with mivae_colsum).  Autograd of maf.py:47-62 (MAFlow.backward, the training direction of IAFlow, iaf.py:21-23).
+extern "C" int mivae_maf_sequential_bwd(const void* x, const void* dout, const float* dtok, const float* w1t, const float* b1,
+                                        const float* w2, const float* b2, const int64_t* mask, void* dz, float* part,
+                                        int64_t rows, int64_t D, int64_t Hp, int act, int parity, int dtype, void* stream) {
+  MIVAE_REQUIRE(rows >= 0, "maf_sequential_bwd: rows < 0");
+  MIVAE_REQUIRE(dtype == MIVAE_F32 || dtype == MIVAE_BF16, "maf_sequential_bwd: dtype must be f32 or bf16");
+  if (!seq_bwd_supported(D, Hp)) {
+    mivae_set_error("maf_sequential_bwd: unsupported shape D=%lld Hp=%lld (gradient image 3 D Hp floats must fit the LDS)",
+                    (long long)D, (long long)Hp);
+    return MIVAE_EUNSUPPORTED;
+  }
+  if (rows == 0) return MIVAE_OK;
+  MIVAE_REQUIRE(x && w1t && b1 && w2 && b2 && dz && part, "maf_sequential_bwd: null pointer");
+  SeqBwdArgs a = {x, dout, dtok, mask, w1t, b1, w2, b2, dz, part, rows, (int)D, (int)Hp, parity ? 1 : 0};
+  const unsigned grid = (unsigned)seq_bwd_blocks(rows);
+  const size_t lds = seq_bwd_lds_bytes(a.D, a.Hp);
+  const int rc = dtype == MIVAE_F32 ? launch_seq_bwd<float>(a, act, lds, grid, S_(stream))
+                                    : launch_seq_bwd<unsigned short>(a, act, lds, grid, S_(stream));
+  if (rc != MIVAE_OK) return rc;
+  MIVAE_CHECK_LAUNCH("maf_sequential_bwd");
   return MIVAE_OK;
 }

@@ -311,12 +311,19 @@ class MAFlow(Flow):
     def _sequential(self, z, mask=None):
         layers = self._made.masked_layers()
         needs_grad = torch.is_grad_enabled() and (z.requires_grad or any(p.requires_grad for p in self._made.parameters()))
-        if (not needs_grad and len(layers) == 2 and self._made._activation_name in ops.MAF_ACT_IDS
+        if (len(layers) == 2 and self._made._activation_name in ops.MAF_ACT_IDS
                 and z.dtype in (torch.float32, torch.bfloat16)):
             l1, l2 = layers
-            packed = ops.maf_sequential_pack(l1.weight, l1.weight_mask, l1.bias, l2.weight, l2.weight_mask, l2.bias)
-            if packed is not None:
-                return ops.maf_sequential(z, packed, mask, self._made._activation_name, self._parity)
+            if needs_grad:      # training direction of IAF: one-launch forward + reverse-recurrence backward
+                if ops.maf_sequential_grad_supported(l1.weight) and l1.weight.dtype == torch.float32:
+                    return ops.maf_sequential(z, None, mask, self._made._activation_name, self._parity,
+                                              params=(l1.weight, l1.weight_mask, l1.bias, l2.weight, l2.weight_mask,
+                                                      l2.bias))
+            else:
+                packed = ops.maf_sequential_pack(l1.weight, l1.weight_mask, l1.bias, l2.weight, l2.weight_mask,
+                                                 l2.bias)
+                if packed is not None:
+                    return ops.maf_sequential(z, packed, mask, self._made._activation_name, self._parity)
         # composed path (training direction of IAF, deeper MADEs): the reference's loop, maf.py:51-62
         from . import _lib as L
         L.require_gpu(z, mask)

@@ -371,14 +371,73 @@ def maf_sequential_pack(w1, m1, b1, w2, m2, b2):
     return w1t, b1p, w2p, b2.detach().float().contiguous(), Hp
 
 
-def maf_sequential(z, packed, mask, activation: str, parity: bool):
-    """MAFlow.backward / IAFlow.forward (maf.py:47-62) in one launch; no autograd (sampling / inference direction)."""
+class _MafSequential(torch.autograd.Function):
+    """mivae_maf_sequential with autograd: the backward walks the recurrence in reverse (mivae_maf_sequential_bwd) and
+    needs nothing but the forward's output."""
+
+    @staticmethod
+    def forward(ctx, z, mask, act, parity, w1, m1, b1, w2, m2, b2):
+        Bn, S, D = _shape3(z)
+        packed = maf_sequential_pack(w1, m1, b1, w2, m2, b2)
+        w1t, b1p, w2p, b2p, Hp = packed
+        zc = z.contiguous()
+        out = torch.empty_like(zc)
+        tok = torch.empty(Bn * S, dtype=torch.float32, device=z.device)
+        L.call("mivae_maf_sequential", L.ptr(zc), L.ptr(w1t), L.ptr(b1p), L.ptr(w2p), L.ptr(b2p), L.ptr(mask), L.ptr(out),
+               L.ptr(tok), Bn * S, D, Hp, act, int(parity), L.dtype_code(z.dtype), L.stream())
+        ctx.save_for_backward(out, mask, w1t, b1p, w2p, b2p, m1, m2)
+        ctx.meta = (Bn * S, D, Hp, w1.size(0), act, int(parity), [t.dtype for t in (w1, b1, w2, b2)])
+        return out, tok
+
+    @staticmethod
+    def backward(ctx, dout, dtok):
+        out, mask, w1t, b1p, w2p, b2p, m1, m2 = ctx.saved_tensors
+        rows, D, Hp, H, act, parity, dts = ctx.meta
+        dout = None if dout is None else dout.contiguous().to(out.dtype)
+        dtok = None if dtok is None else dtok.contiguous().float()
+        dz = torch.empty_like(out)
+        nb = L.query("mivae_maf_sequential_bwd_blocks", rows)
+        P = 3 * D * Hp + Hp + 2 * D
+        part = torch.empty(nb, P, dtype=torch.float32, device=out.device)
+        L.call("mivae_maf_sequential_bwd", L.ptr(out), L.ptr(dout), L.ptr(dtok), L.ptr(w1t), L.ptr(b1p), L.ptr(w2p),
+               L.ptr(b2p), L.ptr(mask), L.ptr(dz), L.ptr(part), rows, D, Hp, act, parity, L.dtype_code(out.dtype),
+               L.stream())
+        sums = colsum(part)
+        gw1t = sums[:D * Hp].view(D, Hp)
+        gw2 = sums[D * Hp:3 * D * Hp].view(2 * D, Hp)
+        gb1 = sums[3 * D * Hp:3 * D * Hp + Hp]
+        gb2 = sums[3 * D * Hp + Hp:]
+        # the kernel differentiates the MASKED weights (made.py:39-40: weight * weight_mask)
+        dw1 = (gw1t[:, :H].t() * m1).to(dts[0])
+        dw2 = (gw2[:, :H] * m2).to(dts[2])
+        return dz, None, None, None, dw1, None, gb1[:H].to(dts[1]), dw2, None, gb2.to(dts[3])
+
+
+def maf_sequential_grad_supported(w1) -> bool:
+    H, D = w1.shape
+    lanes = 1
+    while lanes * MAF_HIDDEN_PER_LANE < H:
+        lanes *= 2
+    return bool(L.query("mivae_maf_sequential_bwd_supported", D, lanes * MAF_HIDDEN_PER_LANE))
+
+
+def maf_sequential(z, packed, mask, activation: str, parity: bool, params=None):
+    """MAFlow.backward / IAFlow.forward (maf.py:47-62) in one launch.  `packed` (maf_sequential_pack): no autograd
+    (sampling / inference).  `params` = (w1, m1, b1, w2, m2, b2) instead: differentiable w.r.t. z and the MADE
+    parameters (IAF training), backward = one reverse-recurrence launch + a fixed-order fold."""
     L.require_gpu(z, mask)
     mask = _mask_i64(mask)
     Bn, S, D = _shape3(z)
-    w1t, b1, w2, b2, Hp = packed
     if mask is not None and mask.numel() != Bn * S:
         raise ValueError("mask must be (B, S) for a (B, S, D) latent")
+    if params is not None:
+        out, tok = _MafSequential.apply(z, mask, MAF_ACT_IDS[activation], bool(parity), *params)
+        if z.dim() == 2:
+            return out, tok
+        if mask is None:
+            return out, tok.view(Bn, S)
+        return out, _SegmentSum.apply(tok, Bn, S)
+    w1t, b1, w2, b2, Hp = packed
     zc = z.detach().contiguous()
     out = torch.empty_like(zc)
     tok = torch.empty(Bn * S, dtype=torch.float32, device=z.device)

@@ -1434,3 +1434,45 @@ def test_posterior_module_uses_philox_and_is_seed_reproducible(M):
     assert not torch.equal(l1.z, l1b.z)                              # successive draws differ
     eps = (l1.z.view(4, 2, 6, 8) - l1.mu.unsqueeze(1)) / l1.sigma.unsqueeze(1)
     assert abs(float(eps.mean())) < 0.2 and abs(float(eps.std()) - 1) < 0.2
+
+
+@pytest.mark.parametrize("B,S,D,H,act,parity,masked", [
+    (6, 21, 64, 64, "elu", False, True), (4, 9, 32, 40, "tanh", True, True), (3, 5, 64, 128, "gelu", True, True),
+    (5, 1, 16, 16, "relu", False, False), (2, 7, 24, 20, "swish", True, True), (3, 4, 8, 256, "sigmoid", False, True),
+    (2, 3, 12, 24, "linear", True, False)])
+def test_maf_sequential_backward_kernel_vs_oracle(M, B, S, D, H, act, parity, masked):
+    """mivae_maf_sequential_bwd (reverse recurrence) through IAFlow's training direction against autograd
+    of the oracle's D-pass loop (maf.py:47-62, iaf.py:21-23): d z and the gradients of all four MADE tensors, every
+    activation, both parities, padded hidden sizes (1, 2 and 4 units per lane), ragged masks."""
+    gen = torch.Generator().manual_seed(300 + D + H)
+    torch.manual_seed(9)
+    flow = M.IAFlow(M.MADE(D, [H], permute_order=False, activation=act), parity=parity)
+    with torch.no_grad():
+        for p in flow.parameters():
+            p.add_(0.05 * torch.randn(p.shape, generator=gen))
+    l1, l2 = flow._made.masked_layers()
+    ws = [l1.weight.detach().clone().requires_grad_(True), l2.weight.detach().clone().requires_grad_(True)]
+    bs = [l1.bias.detach().clone().requires_grad_(True), l2.bias.detach().clone().requires_grad_(True)]
+    ms = [l1.weight_mask.clone(), l2.weight_mask.clone()]
+    z = torch.randn(B, S, D, generator=gen)
+    mask = None
+    if masked:
+        lens = torch.randint(1, S + 1, (B,), generator=gen)
+        mask = (torch.arange(S)[None, :] < lens[:, None]).to(torch.int64)
+        z = z * mask.unsqueeze(-1)
+    cz, cl = torch.randn(B, S, D, generator=gen), torch.randn(B, generator=gen) if masked else torch.randn(B, S, generator=gen)
+    zr = z.clone().requires_grad_(True)
+    xo, ldo = O.maf_sequential(zr, lambda x: O.made_forward(x, ws, bs, ms, act), parity, mask)
+    ((xo * cz).sum() + (ldo * cl).sum()).backward()
+    flow = flow.to(DEV)
+    assert M.ops.maf_sequential_grad_supported(l1.weight)
+    zg = dev(z).clone().requires_grad_(True)
+    x, ld = flow(zg, dev(mask))                       # IAFlow.forward == the sequential direction, with autograd
+    assert x.grad_fn is not None and "MafSequential" in type(x.grad_fn).__name__
+    assert rel_err(x, xo) < 2e-5 and rel_err(ld, ldo) < 2e-5
+    ((x * dev(cz)).sum() + (ld * dev(cl)).sum()).backward()
+    assert rel_err(zg.grad, zr.grad) < 1e-4, rel_err(zg.grad, zr.grad)
+    for got, ref in ((l1.weight.grad, ws[0].grad), (l1.bias.grad, bs[0].grad), (l2.weight.grad, ws[1].grad),
+                     (l2.bias.grad, bs[1].grad)):
+        assert rel_err(got, ref) < 1e-4, rel_err(got, ref)
+    assert float((l1.weight.grad.cpu() * (1 - ms[0])).abs().max()) == 0.0      # masked connections get no gradient
