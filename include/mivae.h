@@ -210,6 +210,18 @@ int mivae_embedding_bwd(const float* dy, const int64_t* ids, float* dW, int64_t 
  * (trainer.py:284, loss.backward()).  max_D = the largest D in the table. */
 int mivae_colsum_sink_multi(const void* jobs, int64_t njobs, int64_t max_D, void* stream);
 
+/* ---- InfoVAE MMD: pairwise squared distances (a19 / f4) ------------------------------------------------- */
+/* out (B1, B2) fp32, out[i][j] = sum_f (a[i][f] - b[j][f])^2 for a (B1, F), b (B2, F): the pairwise term of
+ * InfoVAEKLLoss._compute_rbf / _compute_inv_mult_quad (nn/kl_loss.py:124-149; the reference builds the (B, B, F)
+ * difference tensor) before the kernel function, in the reference's own arithmetic (differences, not a Gram identity),
+ * tiled through LDS, fixed summation order. */
+int mivae_pair_sqdist(const void* a, const void* b, float* out, int64_t B1, int64_t B2, int64_t F, int dtype,
+                      void* stream);
+/* gradients of sum_ij G[i][j] out[i][j] w.r.t. a and b: da (B1, F), db (B2, F) fp32, each may be NULL; accumulate != 0
+ * adds into them.  Autograd of the expression above. */
+int mivae_pair_sqdist_bwd(const void* a, const void* b, const float* G, float* da, float* db, int64_t B1, int64_t B2,
+                          int64_t F, int dtype, int accumulate, void* stream);
+
 /* ---- invertible linear flows (a14) ------------------------------------------------------------------- */
 /* Y (R, hs) = X (R, hs) M^T on the matrix cores, M (hs, hs) row major in the latent dtype, 1 <= hs <= 512.
  * Replaces F.linear(z, W) of InvertibleLinearFlow.forward / .backward (models/base/flows/invertible_flows.py:29,

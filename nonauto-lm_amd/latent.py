@@ -247,8 +247,8 @@ class InfoVAEKLLoss(KLLoss):
     """InfoVAE objective (nn/kl_loss.py:52-149): (1 - alpha) KL + (alpha + reg - 1) / (B (B-1)) MMD.
 
     The reference materialises the (B, B, S*D) difference tensor (1 GiB at B=256, S=D=64); here the pairwise
-    squared distances come from the Gram identity |x|^2 + |y|^2 - 2 x.y -- one (B, F) x (F, B) library GEMM in
-    fp32 per kernel matrix, no (B, B, F) intermediate.  Reference quirks kept: `z_dim` is D for 2-D latents and
+    squared distances come from the tiled kernels of csrc/pairwise.hip (mivae_pair_sqdist / _bwd: the reference's own
+    difference arithmetic, streamed through LDS, fixed summation order), no (B, B, F) intermediate.  Reference quirks kept: `z_dim` is D for 2-D latents and
     S + D for 3-D latents (kl_loss.py:127,142); the IMQ kernel returns row sums without the diagonal, whose
     `.mean(-1)` is then a scalar (kl_loss.py:106,148).  `prior_z` may be injected (tests); otherwise drawn from the
     prior's base distribution like kl_loss.py:102."""
@@ -281,7 +281,7 @@ class InfoVAEKLLoss(KLLoss):
                 - 2 * self._kernel(a, b, z_dim).mean(-1))
 
     def _kernel(self, x1, x2, z_dim):
-        sq = (x1.pow(2).sum(-1)[:, None] + x2.pow(2).sum(-1)[None, :] - 2.0 * (x1 @ x2.t())).clamp(min=0.0)
+        sq = ops.pair_sqdist(x1, x2)        # tiled HIP kernel: sum_f (x1_i - x2_j)^2, no (B, B, F) intermediate
         scale = 2.0 * z_dim * self._prior.std
         if self._kernel_type == "rbf":
             return torch.exp(-(sq / x1.size(-1)) / scale)           # mean over features, kl_loss.py:130-132

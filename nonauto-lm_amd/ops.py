@@ -868,6 +868,42 @@ def colsum(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+# ----------------------------------------------------------------------------------- pairwise distances (InfoVAE MMD)
+class _PairSqDist(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        B1, F = a.shape
+        B2 = b.size(0)
+        out = torch.empty(B1, B2, dtype=torch.float32, device=a.device)
+        L.call("mivae_pair_sqdist", L.ptr(a), L.ptr(b), L.ptr(out), B1, B2, F, L.dtype_code(a.dtype), L.stream())
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        B1, F = a.shape
+        B2 = b.size(0)
+        g = g.contiguous().float()
+        da = torch.empty(B1, F, dtype=torch.float32, device=a.device) if ctx.needs_input_grad[0] else None
+        db = torch.empty(B2, F, dtype=torch.float32, device=a.device) if ctx.needs_input_grad[1] else None
+        if da is not None or db is not None:
+            L.call("mivae_pair_sqdist_bwd", L.ptr(a), L.ptr(b), L.ptr(g), L.ptr(da), L.ptr(db), B1, B2, F,
+                   L.dtype_code(a.dtype), 0, L.stream())
+        return (None if da is None else da.to(a.dtype)), (None if db is None else db.to(b.dtype))
+
+
+def pair_sqdist(a, b):
+    """(B1, B2) fp32 squared distances between the rows of a (B1, F) and b (B2, F), fp32 or bf16 on the GPU, with
+    gradients: the pairwise term of the InfoVAE MMD (nn/kl_loss.py:124-149) without the (B, B, F) tensor."""
+    L.require_gpu(a, b)
+    if a.dim() != 2 or b.dim() != 2 or a.size(1) != b.size(1) or a.dtype != b.dtype:
+        raise ValueError("pair_sqdist: (B1, F) and (B2, F) matrices of one dtype")
+    if a.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("pair_sqdist: fp32 or bf16")
+    return _PairSqDist.apply(a.contiguous(), b.contiguous())
+
+
 # ----------------------------------------------------------------------------------- invertible linear flows
 class _RowGemm(torch.autograd.Function):
     """Y = X M^T for X (R, hs) and a small square M (hs, hs): mivae_rowgemm forward, the same kernel on M^T for d X,

@@ -1476,3 +1476,32 @@ def test_maf_sequential_backward_kernel_vs_oracle(M, B, S, D, H, act, parity, ma
                      (l2.bias.grad, bs[1].grad)):
         assert rel_err(got, ref) < 1e-4, rel_err(got, ref)
     assert float((l1.weight.grad.cpu() * (1 - ms[0])).abs().max()) == 0.0      # masked connections get no gradient
+
+
+# ------------------------------------------------------------------------------------ pairwise distances (f4)
+@pytest.mark.parametrize("B1,B2,F,dtype", [(7, 7, 33, torch.float32), (40, 17, 200, torch.float32),
+                                           (256, 256, 4096, torch.float32), (33, 50, 130, torch.bfloat16)])
+def test_pair_sqdist_vs_fp64(M, B1, B2, F, dtype):
+    """mivae_pair_sqdist / _bwd against the reference expression (x1.unsqueeze(1) - x2).pow(2).sum(-1)
+    (nn/kl_loss.py:124-149) in fp64, sizes off the 16-row / 64-feature tiles and the C2 MMD shape."""
+    gen = torch.Generator().manual_seed(B1 + F)
+    a, b = torch.randn(B1, F, generator=gen), torch.randn(B2, F, generator=gen) * 0.7 + 0.2
+    g = torch.randn(B1, B2, generator=gen)
+    if dtype == torch.bfloat16:
+        a, b = a.to(dtype).float(), b.to(dtype).float()
+    ar, br = a.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = (ar.unsqueeze(1) - br).pow(2).sum(-1)
+    (ref * g.double()).sum().backward()
+    ag, bg = dev(a).to(dtype).requires_grad_(True), dev(b).to(dtype).requires_grad_(True)
+    out = M.ops.pair_sqdist(ag, bg)
+    (out * dev(g)).sum().backward()
+    tol = 5e-6 if dtype == torch.float32 else 1e-2
+    assert rel_err(out, ref) < tol
+    assert rel_err(ag.grad.float(), ar.grad) < max(tol, 2e-5) and rel_err(bg.grad.float(), br.grad) < max(tol, 2e-5)
+    # both arguments the same tensor (the z-z kernel matrix): autograd adds the two gradients
+    zz = dev(a).clone().requires_grad_(True)
+    (M.ops.pair_sqdist(zz, zz) * dev(g[:, :B1] if B2 >= B1 else torch.randn(B1, B1))).sum().backward() if B2 >= B1 else None
+    if B2 >= B1:
+        zr = a.double().requires_grad_(True)
+        ((zr.unsqueeze(1) - zr).pow(2).sum(-1) * g[:, :B1].double()).sum().backward()
+        assert rel_err(zz.grad, zr.grad) < 2e-5
