@@ -38,6 +38,9 @@ typedef const __attribute__((address_space(1))) void glb_cvoid_t;
 enum Stream { ST_FWD = 0, ST_INV = 1, ST_CHAIN = 2, ST_NETS = 3, ST_BIAS = 4 };
 enum Kind { KIND_W1 = 0, KIND_W2 = 1, KIND_W2T = 2, KIND_W1T = 3, KIND_ZERO = 4 };
 
+#ifndef BIG_DW_NBUF
+#define BIG_DW_NBUF 6   // tile buffers of the weight-gradient kernel at h <= 128 (3 in use + prefetch depth)
+#endif
 constexpr int kBiasBlockFloats = 1024;   // [b1: Hp][b2: hp] zero padded to 4 KiB
 constexpr int kBiasSlots = 4;
 
@@ -1139,7 +1142,7 @@ __global__ void __launch_bounds__(512) k_big_dw(DwBigArgs a) {
   // the slab are fetched from a clamped valid address and their d out chunks overwritten with zeros once the DMA has
   // landed (x0 stays: finite values times d out = 0).  No compiler-visible global load remains in the loop, so the
   // only vmcnt waits are the counted ones below.
-  constexpr int NBUF = HT <= 4 ? 6 : 4;
+  constexpr int NBUF = HT <= 4 ? BIG_DW_NBUF : 4;
   constexpr int PD = NBUF - 3;
   const int64_t tile0 = (int64_t)slab * a.slab_tiles;
   int ntiles = (int)((a.N + 31) / 32 - tile0);
@@ -1657,7 +1660,7 @@ extern "C" int mivae_nice_big_bwd(const void* z_in, const void* z_out, const voi
     const int nw = 8;
     const int64_t ngrp = (int64_t)a.nslab * K * 2, zsib = (a.HW + nw - 1) / nw;
     dim3 dgrid((unsigned)(((ngrp + 7) / 8) * 8 * zsib));   // 1-D: see the block order in k_big_dw
-    const size_t dlds = (size_t)(g.HT <= 4 ? 6 : 4) * 2 * 32 * g.HT * 64;   // NBUF tile buffers x 2 operands
+    const size_t dlds = (size_t)(g.HT <= 4 ? BIG_DW_NBUF : 4) * 2 * 32 * g.HT * 64;   // NBUF tile buffers x 2 operands
 #define CALL(HTc, ACTc) launch_dw<HTc, ACTc>(a, dgrid, dlds, st)
     BIG_DISPATCH(g.HT, act, CALL);
 #undef CALL
