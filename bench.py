@@ -292,7 +292,7 @@ def main():
     if args.torch_adam:
         opt = torch.optim.Adam(model.parameters(), lr=1e-4, foreach=True, capturable=not args.eager)
     else:                                          # clip + Adam + zero_grad fused over the flat buckets (libmivae)
-        opt = dp.FusedAdam(reducer, lr=1e-4, bf16_shadow=amp_dtype == torch.bfloat16)
+        opt = dp.FusedAdam(reducer, lr=1e-4, bf16_shadow=amp_dtype == torch.bfloat16, model=model)
     scalars = dp.PackedScalars(["batch-loss", "batch-kl", "batch-nll", "done"], dev)
     tokens = synthetic_tokens(B, S, ragged, 13 + rank).to(dev)     # per-rank shard of the global batch
 

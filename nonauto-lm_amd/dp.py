@@ -209,7 +209,8 @@ class FusedAdam:
     inside a HIP graph.  Needs GradReducer(..., flatten_params=True) and fp32 parameters."""
 
     def __init__(self, reducer: "GradReducer", lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 0.0, amsgrad: bool = False, bf16_shadow: bool = False):
+                 weight_decay: float = 0.0, amsgrad: bool = False, bf16_shadow: bool = False,
+                 model: Optional[torch.nn.Module] = None):
         from . import _lib as L
         if amsgrad:
             raise NotImplementedError("FusedAdam: amsgrad is not supported")
@@ -230,7 +231,8 @@ class FusedAdam:
         self._partial = torch.zeros(max(sum(self._nblk), 1), dtype=torch.float32, device=dev)
         # bf16_shadow: the update kernel also writes a bf16 copy of every parameter; each parameter gets a
         # `_mivae_lp` view into it, which nn_bracket.Linear uses as its compute copy under bf16 autocast
-        # (no per-layer weight casts).  After loading weights by any other route call refresh_shadow().
+        # (no per-layer weight casts).  Pass `model` to have model.load_state_dict() refresh the shadow by itself; after
+        # writing weights by any other route call refresh_shadow().
         self.shadow = None
         if bf16_shadow:
             self.shadow = [torch.empty(b.numel(), dtype=torch.bfloat16, device=dev) for b in reducer.buckets]
@@ -239,6 +241,8 @@ class FusedAdam:
                 off = (p.data_ptr() - reducer.flat_params[bi].data_ptr()) // 4
                 p._mivae_lp = self.shadow[bi][off:off + p.numel()].view_as(p)
             self.refresh_shadow()
+            if model is not None:        # weights loaded later (checkpoint restore) must reach the shadow too
+                model.register_load_state_dict_post_hook(lambda module, incompatible: self.refresh_shadow())
 
     def refresh_shadow(self) -> None:
         if self.shadow is not None:

@@ -1505,3 +1505,21 @@ def test_pair_sqdist_vs_fp64(M, B1, B2, F, dtype):
         zr = a.double().requires_grad_(True)
         ((zr.unsqueeze(1) - zr).pow(2).sum(-1) * g[:, :B1].double()).sum().backward()
         assert rel_err(zz.grad, zr.grad) < 2e-5
+
+
+def test_fused_adam_shadow_follows_load_state_dict(M):
+    """weights loaded after construction reach the bf16 shadow the bf16 forward reads."""
+    from nonauto_lm_amd import dp
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Linear(16, 16), torch.nn.Linear(16, 8)).to(DEV)
+    reducer = dp.GradReducer(net.parameters(), flatten_params=True)
+    opt = dp.FusedAdam(reducer, lr=1e-3, bf16_shadow=True, model=net)
+    sd = {k: torch.randn_like(v) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    for name, p in net.named_parameters():
+        assert torch.equal(p.detach(), sd[name])                           # in place: still views of the flat buffer
+        assert torch.equal(p._mivae_lp, sd[name].to(torch.bfloat16))
+    st = opt.state_dict()
+    st["exp_avg"][0].add_(1.0)
+    opt.load_state_dict(st)                                                # also refreshes
+    assert all(torch.equal(p._mivae_lp, p.detach().to(torch.bfloat16)) for p in net.parameters())
