@@ -235,6 +235,20 @@ int mivae_rowgemm(const void* x, const void* m, void* y, int64_t R, int64_t hs, 
 int64_t mivae_rowgemm_wgrad_slabs(int64_t R, int64_t hs);
 int mivae_rowgemm_wgrad(const void* x, const void* dy, float* part, int64_t R, int64_t hs, int dtype, void* stream);
 
+/* Mixed flow stack, one launch, no gradients (evaluation / sampling): K steps executed in the order given, each a
+ * NICE feed-forward coupling (couplings.py:141-183 + :50-51), an ActNorm (actnorm.py:30-54) or an invertible linear
+ * map with one matrix per head (invertible_flows.py:26-44, :58-83), the loop of FlowPrior.forward_pass /
+ * backward_pass (flow_prior.py:37-70) for lists that are not coupling-only.  D even, <= 128; coupling hidden <= 128.
+ *   steps: HOST array of 12 int64 per step {kind 0 NICE / 1 ActNorm / 2 linear, H, activation id, head size, 8 device
+ *   pointers to fp32 parameters (NICE: W1s b1s W2s b2s W1t b1t W2t b2t; ActNorm: log_scale bias; linear: M (hs, hs))},
+ *   read during the call.  For the sampling direction pass the list reversed, inverse = 1 and the inverted matrices.
+ *   tok_val (Bn S) fp32 or NULL: masked per-token sum of the coupling log-scales (negated when inverse); the
+ *   parameter-only log-determinants (sum log_scale, slogdet M) x token count are the caller's to add. */
+int mivae_mixed_stack_supported(int64_t D, int64_t Hmax);
+int mivae_mixed_stack(const void* z_in, void* z_out, const int64_t* mask, float* tok_val, const int64_t* steps,
+                      int64_t K, int64_t Bn, int64_t S, int64_t mask_div, int64_t D, int inverse, int dtype,
+                      void* stream);
+
 /* ---- KL / ELBO tail -------------------------------------------------------------------------------- */
 /* kl = clamp(logq - logp, min = free_bits) (clamp only if use_fb).  Replaces DefaultKLLoss.forward
  * nn/kl_loss.py:38-49 and _free_bits_kl :14-21. */

@@ -52,6 +52,8 @@ SIGNATURES = {
     "mivae_rowgemm": [P, P, P, I64, I64, I32, P],
     "mivae_rowgemm_wgrad": [P, P, P, I64, I64, I32, P],
     "mivae_rowgemm_wgrad_slabs": [I64, I64],
+    "mivae_mixed_stack_supported": [I64, I64],
+    "mivae_mixed_stack": [P, P, P, P, P, I64, I64, I64, I64, I64, I32, I32, P],
     "mivae_elbo_fwd": [P, P, P, I64, I64, F32, F32, I32, P, P],
     "mivae_elbo_bwd": [P, P, P, P, P, I64, I64, F32, F32, I32, P, P],
     "mivae_nll_fwd": [P, P, P, P, P, P, P, I64, I64, I64, F32, I32, P],

@@ -268,6 +268,8 @@ class FusedAdam:
                    L.ptr(self.grad_norm) if i == 0 else None, b.numel(), self.lr, self.betas[0], self.betas[1],
                    self.eps, self.weight_decay, float(max_norm or 0.0), float(max_value or 0.0), gscale, st)
         L.call("mivae_scalar_add", L.ptr(self.step_count), 1.0, st)
+        from . import ops
+        ops.params_changed()       # raw-pointer writes: torch's version counters did not move
         return self.grad_norm
 
     def zero_grad(self, set_to_none: bool = False) -> None:

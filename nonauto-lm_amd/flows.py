@@ -448,3 +448,84 @@ def fused_stack_spec(flows, z):
     if not params:
         return None
     return params, H0, act0
+
+
+def _mixed_plan(flows, z, inverse: bool):
+    """(MixedPlan, constant) for the list, cached on the first flow while no parameter changes (storage address,
+    in-place version counter, and ops.PARAM_EPOCH for the raw-pointer writes of FusedAdam / replayed graphs): the matrix inverse and the slogdet of the linear steps are rocSOLVER calls that cost
+    far more than the flow kernel.  `constant` = sum over steps of the parameter-only log-determinant per token
+    (ActNorm: sum log_scale; linear: slogdet x heads), a device scalar, or None when nothing contributes."""
+    D, three = z.size(-1), z.dim() == 3
+    key = (D, three, z.dtype, z.device, ops.PARAM_EPOCH[0],
+           tuple((p.data_ptr(), p._version) for f in flows for p in f.parameters()),
+           tuple(getattr(f, "_is_initted", True) for f in flows), tuple(f.training for f in flows))
+    cache = flows[0].__dict__.setdefault("_mixed_plan_cache", {})
+    hit = cache.get(inverse)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    plan = None
+    steps, const, hmax, ok = [], None, 0, D % 2 == 0
+    for flow in (flows[::-1] if inverse else flows):
+        if not ok:
+            break
+        if isinstance(flow, NICECoupling):
+            spec = flow.fused_spec(z)
+            if spec is None:
+                ok = False
+                break
+            params, H, act = spec
+            hmax = max(hmax, H)
+            steps.append((ops.MIXED_NICE, H, act, params))
+            continue
+        if isinstance(flow, ActNorm):
+            if not flow._is_initted or flow._log_scale.dtype != torch.float32 or flow._input_size != D:
+                ok = False
+                break
+            steps.append((ops.MIXED_ACTNORM, flow._log_scale, flow._bias))
+            c = flow._log_scale.detach().sum()
+            c = -c if inverse else c
+        elif isinstance(flow, _InvLinearBase):
+            heads = getattr(flow, "_num_heads", 1)
+            w = flow._weight.detach()
+            if w.dtype != torch.float32 or w.size(0) * heads != D:
+                ok = False
+                break
+            if inverse:
+                w = torch.inverse(w.double()).float()            # invertible_flows.py:37
+            steps.append((ops.MIXED_LINEAR, w))
+            c = torch.linalg.slogdet(w)[1]
+            if three:                                            # 2-D inputs: no head factor, like the per-flow modules
+                c = c * heads
+        else:
+            ok = False
+            break
+        const = c if const is None else const + c
+    if ok and steps and ops.mixed_stack_supported(D, hmax) and len(steps) <= 24:
+        plan = (ops.MixedPlan(steps), const)
+    cache[inverse] = (key, plan)
+    return plan
+
+
+def mixed_stack_run(flows, z, mask, inverse: bool):
+    """One-launch evaluation of a flow list that mixes NICE-FF, ActNorm and invertible-linear steps (flow_prior.py:37-70
+    run through csrc/mixed_stack.hip).  Returns (z', log_det) like the per-flow loop, or None when the list does not
+    qualify: a gradient is needed, an unsupported flow / width, an ActNorm that still has to see its first batch, or a
+    coupling-only list (which has its own fused kernels)."""
+    flows = list(flows)
+    if not flows or z.dtype not in (torch.float32, torch.bfloat16) or z.dim() not in (2, 3):
+        return None
+    if z.dim() == 3 and mask is None:
+        return None
+    if torch.is_grad_enabled() and (z.requires_grad or any(p.requires_grad for f in flows for p in f.parameters())):
+        return None
+    if all(isinstance(f, NICECoupling) for f in flows):
+        return None
+    planned = _mixed_plan(flows, z, bool(inverse))
+    if planned is None:
+        return None
+    plan, const = planned
+    out, val = ops.mixed_stack(z, mask, plan, inverse=inverse)
+    if const is not None:
+        # (sum log_scale) x tokens, slogdet x tokens x heads; a 2-D input counts once
+        val = val + (const * ops.mask_count(mask, z.size(0)) if z.dim() == 3 else const)
+    return out, val

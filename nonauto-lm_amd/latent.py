@@ -11,7 +11,7 @@ import torch
 import torch.distributions as D
 
 from . import ops
-from .flows import Flow, fused_stack_spec
+from .flows import Flow, fused_stack_spec, mixed_stack_run
 from .nn_bracket import Linear, linear_group
 from .registrable import Registrable
 
@@ -122,6 +122,10 @@ class FlowPrior(DefaultPrior):
             params, H, act = spec
             return ops.nice_stack(z0, mask, params, H, act, inverse=False, base=True,
                                   mu=float(self.mu), std=float(self.std))
+        mixed = mixed_stack_run(self._flows, z0, mask, False) if self.allow_fused else None
+        if mixed is not None:       # no-grad evaluation of a mixed list: one launch
+            z, total = mixed
+            return z, self.masked_log_prob(z, mask, size_average=True) + total
         z = z0
         total = None
         for flow in self._flows:
@@ -138,6 +142,9 @@ class FlowPrior(DefaultPrior):
             params, H, act = spec
             z, total = ops.nice_stack(z0, mask, params, H, act, inverse=True, base=False)
             return z, log_prob + total
+        mixed = mixed_stack_run(self._flows, z0, mask, True) if self.allow_fused else None
+        if mixed is not None:
+            return mixed[0], log_prob + mixed[1]
         z = z0
         total = None
         for flow in list(self._flows)[::-1]:

@@ -653,6 +653,15 @@ def pinned_tables():
 
 # SINK_NOTIFY(grad_tensor): set by step.TrainStep to dp.GradReducer.notify_sink -- "a contribution to this .grad has been
 # enqueued on the current stream" (sinks bypass autograd's accumulation, so the reducer's grad hooks do not fire for them).
+# Bumped whenever parameters are rewritten through raw pointers (FusedAdam's kernel, graph replays): such writes do
+# not move torch's per-tensor version counters, so caches derived from parameter values key on this as well.
+PARAM_EPOCH = [0]
+
+
+def params_changed() -> None:
+    PARAM_EPOCH[0] += 1
+
+
 SINK_NOTIFY = None
 
 
@@ -1368,3 +1377,69 @@ def nice_stack(z, mask, params: Sequence[torch.Tensor], H: int, activation: str,
     if mask is None and not base:
         return z_out, tok.view(Bn, S)
     return z_out, _SegmentSum.apply(tok, Bn, S)
+
+
+# ----------------------------------------------------------------------------------- mixed flow stack (no grad)
+MIXED_NICE, MIXED_ACTNORM, MIXED_LINEAR = 0, 1, 2
+
+
+def mixed_stack_supported(D: int, Hmax: int) -> bool:
+    return bool(L.query("mivae_mixed_stack_supported", int(D), int(Hmax)))
+
+
+class MixedPlan:
+    """Host step table of mivae_mixed_stack for one flow list (built once, reusable while the parameters' storage is
+    unchanged: the table holds device pointers)."""
+
+    def __init__(self, steps):
+        import ctypes
+        table, self.keep = [], []
+        for st in steps:
+            kind = st[0]
+            if kind == MIXED_NICE:
+                row = [kind, int(st[1]), ACT_IDS[st[2]], 0]
+                ps = list(st[3])
+                assert len(ps) == 8
+            elif kind == MIXED_ACTNORM:
+                row, ps = [kind, 0, 0, 0], [st[1], st[2]]
+            elif kind == MIXED_LINEAR:
+                row, ps = [kind, 0, 0, int(st[1].size(-1))], [st[1]]
+                assert st[1].dim() == 2 and st[1].size(0) == st[1].size(1)
+            else:
+                raise ValueError(f"mixed_stack: unknown step kind {kind}")
+            for p in ps:
+                L.require_gpu(p)
+                if p.dtype != torch.float32:
+                    raise TypeError("mixed_stack: parameters must be fp32")
+            ps = [p.detach().contiguous() for p in ps]
+            self.keep += ps
+            table += row + [p.data_ptr() for p in ps] + [0] * (8 - len(ps))
+        self.K = len(steps)
+        self.host = (ctypes.c_int64 * len(table))(*table)
+        self.addr = ctypes.addressof(self.host)
+
+
+def mixed_stack(z, mask, steps, inverse: bool = False):
+    """Any list of NICE-FF / ActNorm / invertible-linear steps in ONE launch (csrc/mixed_stack.hip), without
+    gradients: the evaluation / sampling form of FlowPrior.forward_pass / backward_pass (flow_prior.py:37-70) for
+    lists that are not coupling-only.  `steps` (or a MixedPlan made from them) in execution order, each one of
+      (MIXED_NICE, H, activation name, [W1s, b1s, W2s, b2s, W1t, b1t, W2t, b2t]),
+      (MIXED_ACTNORM, log_scale, bias),  (MIXED_LINEAR, matrix (hs, hs))      -- fp32 CUDA tensors.
+    Returns (z_out, val): val = the masked sum of the coupling log-scales (negated for `inverse`), reduced like the
+    reference ((B,) for masked 3-D and 2-D inputs, (B, S) for unmasked 3-D inputs).  The parameter-only
+    log-determinants are the caller's to add."""
+    L.require_gpu(z, mask)
+    mask = _mask_i64(mask)
+    Bn, S, D = _shape3(z)
+    plan = steps if isinstance(steps, MixedPlan) else MixedPlan(steps)
+    zc = z.detach().contiguous()
+    z_out = torch.empty_like(zc)
+    tok = torch.empty(Bn * S, dtype=torch.float32, device=z.device)
+    mask_div = 1 if mask is None else Bn // mask.size(0)
+    L.call("mivae_mixed_stack", L.ptr(zc), L.ptr(z_out), L.ptr(mask), L.ptr(tok), plan.addr, plan.K,
+           Bn, S, mask_div, D, int(bool(inverse)), L.dtype_code(z.dtype), L.stream())
+    if z.dim() == 2:
+        return z_out, tok
+    if mask is None:
+        return z_out, tok.view(Bn, S)
+    return z_out, segment_sum(tok, Bn, S)

@@ -251,6 +251,7 @@ class TrainStep:
         if self.world > 1 and not self.comm_in_graph:
             self.reducer.finish()                 # bucket all-reduces, outside the graphs
         self.graph_b.replay()
+        ops.params_changed()                      # the replayed optimizer kernel rewrote the parameters
         if m.training:                            # what VAELmModel.forward does after the loss (model.py:180-184)
             m.kl_scheduler_step()
             m._recon_scheduler.step()
