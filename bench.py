@@ -139,6 +139,7 @@ def flow_kernel_times(model, tokens, dtype, reps=50, graph=True):
         ptab = ops._ptr_table(plist, dev)
         dsdt = e(K, 2, N, h)
         ws = e(L.query("mivae_nice_big_dw_workspace_floats", N, h, H, K), dt=torch.float32)
+        hid = e(L.query("mivae_nice_big_hidden_elems", N, h, H, K)) if ops._nice_big_save_hidden(h) else None
     else:
         npad = L.query("mivae_nice_stack_npad", N)
         packed = ops.nice_pack(plist, K, h, H, dtype)
@@ -189,7 +190,7 @@ def flow_kernel_times(model, tokens, dtype, reps=50, graph=True):
                                              L.stream()),
             "nice_stack_bwd": lambda: L.call("mivae_nice_big_bwd", L.ptr(z), L.ptr(z_out), L.ptr(hist), L.ptr(mask),
                                              L.ptr(ptab), L.ptr(pk_c), L.ptr(pk_n), L.ptr(pk_b), L.ptr(dz_out), L.ptr(dlog),
-                                             L.ptr(dz_in), L.ptr(dsdt), L.ptr(ws), L.ptr(dW1), L.ptr(db1), L.ptr(dW2),
+                                             L.ptr(dz_in), L.ptr(dsdt), L.ptr(hid), L.ptr(ws), L.ptr(dW1), L.ptr(db1), L.ptr(dW2),
                                              L.ptr(db2), None, B, 1, S, D, H, K, actid, 1, 0.0, 1.0, L.stream()),
         })
     else:

@@ -457,11 +457,14 @@ int64_t mivae_nice_big_dw_workspace_floats(int64_t N, int64_t h, int64_t H, int6
  * into the buffers of grad_ptrs (device int64[K][8], mivae_nice_pack's order) when that is given.  dlogp (N) = per-token
  * cotangent of tok_val; ptr_table = the device pointer table given to mivae_nice_big_pack (the weight-gradient kernel reads
  * its stationary operands from the fp32 parameters); dSdT = scratch (K, 2, N, h) in the latent dtype; workspace:
- * mivae_nice_big_dw_workspace_floats. */
+ * mivae_nice_big_dw_workspace_floats.  hidden = scratch of mivae_nice_big_hidden_elems(N, h, H, K) elements of the
+ * latent dtype, or NULL: with it the nets launch saves the hidden activations and d pre and the weight gradients are two
+ * plain contractions over the tokens; without it they are recomputed (no extra memory, ~2x the weight-gradient time). */
+int64_t mivae_nice_big_hidden_elems(int64_t N, int64_t h, int64_t H, int64_t K);
 int mivae_nice_big_bwd(const void* z_in, const void* z_out, const void* x1_hist, const int64_t* mask,
                        const int64_t* ptr_table, const void* packed_chain, const void* packed_nets,
                        const void* packed_bias, const void* dz_out,
-                       const float* dlogp, void* dz_in, void* dSdT, float* workspace, float* dW1, float* db1,
+                       const float* dlogp, void* dz_in, void* dSdT, void* hidden, float* workspace, float* dW1, float* db1,
                        float* dW2, float* db2, const int64_t* grad_ptrs, int64_t Bn, int64_t mask_div, int64_t S,
                        int64_t D, int64_t H, int64_t K, int act, int base, float mu, float std, void* stream);
 

@@ -104,7 +104,8 @@ SIGNATURES = {
     "mivae_nice_big_pack_multi": [P, P, I64, I64, I64, P],
     "mivae_nice_big_fwd": [P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I32, I32, I32, F32, F32, P],
     "mivae_nice_big_dw_workspace_floats": [I64, I64, I64, I64],
-    "mivae_nice_big_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I32, I32, F32,
+    "mivae_nice_big_hidden_elems": [I64, I64, I64, I64],
+    "mivae_nice_big_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I32, I32, F32,
                            F32, P],
 }
 _RET = {
@@ -125,6 +126,7 @@ _RET = {
     "mivae_nice_dw_workspace_floats": I64,
     "mivae_nice_big_pack_bytes": I64,
     "mivae_nice_big_dw_workspace_floats": I64,
+    "mivae_nice_big_hidden_elems": I64,
 }
 
 _lib = None

@@ -474,6 +474,43 @@ __device__ __forceinline__ void act_pair_d(int act, const f32x4& lo, const f32x4
     for (int r = 0; r < 4; ++r) { dlo[r] = d[r]; dhi[r] = d[4 + r]; }
   }
 }
+// value and derivative of the activation on the two token sub-tiles of a (32 tokens x 16 hidden) block
+template <int ACT>
+__device__ __forceinline__ void act_pair_fd(int act, f32x4& lo, f32x4& hi, f32x4& dlo, f32x4& dhi) {
+  if constexpr (ACT == ACT_GELU) {
+    f32x8v x = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}, a, q, e, d;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) a[r] = __builtin_amdgcn_fmed3f(fabsf(x[r]), 0.f, 5.0f);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) q[r] = fmaf(kGq3, a[r], kGq2);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) e[r] = x[r] * x[r];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) q[r] = fmaf(q[r], a[r], kGq1);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) e[r] = __builtin_amdgcn_exp2f(e[r] * -0.72134752044448170f);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) q[r] = fmaf(q[r], a[r], kGq0);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) q[r] = __builtin_amdgcn_exp2f(fmaf(q[r], a[r], -1.0f));   // Phi(-|x|)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) e[r] *= x[r] * kInvSqrt2Pi;                                 // x phi(x)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) d[r] = (x[r] > 0.f ? 1.0f - q[r] : q[r]) + e[r];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) x[r] = fmaf(-fabsf(x[r]), q[r], relu1(x[r]));
+    lo = f32x4{x[0], x[1], x[2], x[3]}; hi = f32x4{x[4], x[5], x[6], x[7]};
+    dlo = f32x4{d[0], d[1], d[2], d[3]}; dhi = f32x4{d[4], d[5], d[6], d[7]};
+  } else {
+    f32x16 t, d;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { t[r] = lo[r]; t[4 + r] = hi[r]; t[8 + r] = 0.f; t[12 + r] = 0.f; }
+    act_tile_fd<-1, true>(act, t, d);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { lo[r] = t[r]; hi[r] = t[4 + r]; dlo[r] = d[r]; dhi[r] = d[4 + r]; }
+  }
+}
+
 // four consecutive floats from LDS (biases of features 16 v + 4 g + {0..3})
 __device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
@@ -798,13 +835,29 @@ struct NetsArgs {
   const float* dlogp;   // (N) or null
   const T* dSdT;        // (K, 2, N, h)
   T* dz_in;             // (N, D): x0 half written here
+  T* hbuf;              // SAVE: (K, 2, N, Hp) hidden activations, token rows of Hp = 32 HC values
+  T* gbuf;              // SAVE: (K, 2, N, Hp) d pre-activation
   int64_t N;
   int S, mask_div, D, K, h, H, HC;
   int act, base;
   float mu, inv2var;
 };
 
-template <int HT, int ACT>
+// hidden rows of a token no wave computes (dead tile): zeros, so that the weight-gradient products stay finite
+__device__ __forceinline__ void zero_hidden_rows(T* hbuf, T* gbuf, int64_t N, int K, int Hp, int64_t tok, int g) {
+  const u16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int kn = 0; kn < 2 * K; ++kn) {
+    const int64_t row = ((int64_t)kn * N + tok) * Hp;
+    for (int f = 8 * g; f < Hp; f += 32) {
+      *reinterpret_cast<u16x8*>(hbuf + row + f) = zero;
+      *reinterpret_cast<u16x8*>(gbuf + row + f) = zero;
+    }
+  }
+}
+
+// SAVE: also write the hidden activations and d pre of every (step, net, token) for k_big_dw2 (the weight-gradient
+// kernel then contracts them directly instead of recomputing both from x0 and d out).
+template <int HT, int ACT, bool SAVE>
 __global__ void __launch_bounds__(512) k_big_nets(NetsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NF = 2 * HT;
@@ -833,8 +886,12 @@ __global__ void __launch_bounds__(512) k_big_nets(NetsArgs a) {
       const u16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
       T* drow = a.dz_in + tok * a.D;
       for (int f = 8 * g; f < h; f += 32) *reinterpret_cast<u16x8*>(drow + f) = zero;
+      if constexpr (SAVE) zero_hidden_rows(a.hbuf, a.gbuf, a.N, a.K, 32 * HC, tok, g);
     }
     return;
+  }
+  if constexpr (SAVE) {
+    if (!live && valid) zero_hidden_rows(a.hbuf, a.gbuf, a.N, a.K, 32 * HC, tok, g);
   }
   const bool on = valid && m != 0.f;
   bf16x8 x0f[HT];
@@ -888,11 +945,28 @@ __global__ void __launch_bounds__(512) k_big_nets(NetsArgs a) {
     }
   };
   // stage B: d pre = dh * act'(pre) -> B fragment
-  auto stage_b = [&](const f32x4 (&pre)[2], const f32x4 (&dh)[2]) -> bf16x8 {
+  //          (SAVE: task (j1, c1)'s hidden activations and d pre go to hbuf / gbuf, 4 hidden units = 8 bytes a store)
+  auto stage_b = [&](const f32x4 (&pre)[2], const f32x4 (&dh)[2], int j1, int c1) -> bf16x8 {
     f32x4 dlo, dhi;
-    act_pair_d<ACT>(a.act, pre[0], pre[1], dlo, dhi);
+    if constexpr (SAVE) {
+      f32x4 hlo = pre[0], hhi = pre[1];
+      act_pair_fd<ACT>(a.act, hlo, hhi, dlo, dhi);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { dlo[r] *= dh[0][r]; dhi[r] *= dh[1][r]; }
+      for (int r = 0; r < 4; ++r) { dlo[r] *= dh[0][r]; dhi[r] *= dh[1][r]; }
+      if (valid && j1 < NJ) {
+        const int64_t row = ((int64_t)kn_of(j1) * a.N + tok) * (32 * HC) + 32 * c1 + 4 * g;
+        const float h0[4] = {hlo[0], hlo[1], hlo[2], hlo[3]}, h1[4] = {hhi[0], hhi[1], hhi[2], hhi[3]};
+        const float g0[4] = {dlo[0], dlo[1], dlo[2], dlo[3]}, g1[4] = {dhi[0], dhi[1], dhi[2], dhi[3]};
+        RowIO<T, 4>::store(a.hbuf + row, h0);
+        RowIO<T, 4>::store(a.hbuf + row + 16, h1);
+        RowIO<T, 4>::store(a.gbuf + row, g0);
+        RowIO<T, 4>::store(a.gbuf + row + 16, g1);
+      }
+    } else {
+      act_pair_d<ACT>(a.act, pre[0], pre[1], dlo, dhi);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { dlo[r] *= dh[0][r]; dhi[r] *= dh[1][r]; }
+    }
     return pair_to_b(dlo, dhi);
   };
   ring.enter_prologue();
@@ -901,7 +975,7 @@ __global__ void __launch_bounds__(512) k_big_nets(NetsArgs a) {
   {
     f32x4 pre0[2], dh0[2];
     stage_a(ring.item(0), ring.item(1), bias_lds, pre0, dh0);
-    gb = stage_b(pre0, dh0);
+    gb = stage_b(pre0, dh0, 0, 0);
     stage_a(ring.item(2), ring.item(3), bias_lds + 32, pre1, dh1);
   }
   if (!live) {
@@ -928,6 +1002,8 @@ __global__ void __launch_bounds__(512) k_big_nets(NetsArgs a) {
         const char* itB = ring.item(6 + 3 * i);
         int c2 = c + 2, j2 = j;
         if (c2 >= HC) { c2 -= HC; ++j2; }
+        int c1 = c + 1, j1 = j;
+        if (c1 >= HC) { c1 -= HC; ++j1; }
         // the first task of the next net enters stage A here: switch the d out fragments
         if (c2 == 0 && j2 < NJ) load_dout(j2);
         // C(i): dx0 += W1T frags . d pre(i);  A(i+2);  B(i+1) -> d pre(i+1)   (tasks past the end: zero padding)
@@ -947,7 +1023,7 @@ __global__ void __launch_bounds__(512) k_big_nets(NetsArgs a) {
           for (int u = 0; u < 2 * HT; ++u) f1[u] = w1[u * 64];
           pre2[0] = lds4(b1c + 4 * g); pre2[1] = lds4(b1c + 16 + 4 * g);
           __builtin_amdgcn_sched_barrier(0);
-          const bf16x8 gbn = stage_b(pre1, dh1);
+          const bf16x8 gbn = stage_b(pre1, dh1, j1, c1);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int v = 0; v < NF; ++v) dx0[v] = mma16(ft[v], gb, dx0[v]);
@@ -968,10 +1044,13 @@ __global__ void __launch_bounds__(512) k_big_nets(NetsArgs a) {
           }
           gb = gbn;
         } else {
+          // B(i+1) first: with SAVE its stores are issued at the start of the body and have the whole task to complete
+          // before the next group boundary waits for every outstanding vector memory operation
+          const bf16x8 gbn = stage_b(pre1, dh1, j1, c1);
 #pragma unroll
           for (int v = 0; v < NF; ++v) dx0[v] = mma16(wt[v * 64], gb, dx0[v]);
           stage_a(itA, itB, bias_lds + (j2 & 3) * kBiasBlockFloats + 32 * c2, pre2, dh2);
-          gb = stage_b(pre1, dh1);
+          gb = gbn;
         }
         pre1[0] = pre2[0]; pre1[1] = pre2[1]; dh1[0] = dh2[0]; dh1[1] = dh2[1];
       }
@@ -1027,43 +1106,6 @@ __device__ __forceinline__ bf16x8 tr_read(const char* tile, int o0, int o1) {
   const auto v = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
   return __builtin_bit_cast(bf16x8, v);
 }
-// value and derivative of the activation on the two token sub-tiles of a (32 tokens x 16 hidden) block
-template <int ACT>
-__device__ __forceinline__ void act_pair_fd(int act, f32x4& lo, f32x4& hi, f32x4& dlo, f32x4& dhi) {
-  if constexpr (ACT == ACT_GELU) {
-    f32x8v x = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}, a, q, e, d;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) a[r] = __builtin_amdgcn_fmed3f(fabsf(x[r]), 0.f, 5.0f);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) q[r] = fmaf(kGq3, a[r], kGq2);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) e[r] = x[r] * x[r];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) q[r] = fmaf(q[r], a[r], kGq1);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) e[r] = __builtin_amdgcn_exp2f(e[r] * -0.72134752044448170f);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) q[r] = fmaf(q[r], a[r], kGq0);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) q[r] = __builtin_amdgcn_exp2f(fmaf(q[r], a[r], -1.0f));   // Phi(-|x|)
-#pragma unroll
-    for (int r = 0; r < 8; ++r) e[r] *= x[r] * kInvSqrt2Pi;                                 // x phi(x)
-#pragma unroll
-    for (int r = 0; r < 8; ++r) d[r] = (x[r] > 0.f ? 1.0f - q[r] : q[r]) + e[r];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) x[r] = fmaf(-fabsf(x[r]), q[r], relu1(x[r]));
-    lo = f32x4{x[0], x[1], x[2], x[3]}; hi = f32x4{x[4], x[5], x[6], x[7]};
-    dlo = f32x4{d[0], d[1], d[2], d[3]}; dhi = f32x4{d[4], d[5], d[6], d[7]};
-  } else {
-    f32x16 t, d;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { t[r] = lo[r]; t[4 + r] = hi[r]; t[8 + r] = 0.f; t[12 + r] = 0.f; }
-    act_tile_fd<-1, true>(act, t, d);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { lo[r] = t[r]; hi[r] = t[4 + r]; dlo[r] = d[r]; dhi[r] = d[4 + r]; }
-  }
-}
-
 // 16 bytes per lane global -> LDS (wave-uniform destination base, lanes land 16 bytes apart), issued behind the
 // compiler's back: after a __builtin_amdgcn_global_load_lds it cannot prove disjoint from a later LDS read, hipcc's
 // wait-count pass puts s_waitcnt vmcnt(0) in front of that read, which would expose the whole global latency in
@@ -1368,6 +1410,201 @@ __global__ void __launch_bounds__(512) k_big_dw(DwBigArgs a) {
   }
 }
 
+// ---- weight gradients from the saved hidden activations -----------------------------------------------------------
+// k_big_nets<SAVE> leaves hid = act(pre) and d pre of every (step, net, token) in HBM; the weight gradients are then two
+// plain contractions over the tokens, dW1^T = x0^T d pre and dW2 = d out^T hid, with no recomputation and no activation
+// arithmetic (the recompute kernel above spends half its MFMAs and all of its VALU time on them).  Same decomposition as
+// k_big_dw: a block = 8 waves x 16 hidden units of one (step, net), walking a slab of 32-token tiles; per tile the x0 and
+// d out tiles ([32][hp]) and the block's 128-unit slices of hid and d pre ([32][128]) are LDS-DMA staged (source-side
+// XOR swizzle) and every fragment is a transposing read: A = x0^T / d out^T feature tiles, B = hid^T / d pre^T of the wave's
+// 16 units.  Accumulators and dump layout are k_big_dw's, so k_big_dw_reduce serves both.
+struct Dw2Args {
+  const T* z_in;        // (N, D)
+  const T* dSdT;        // (K, 2, N, h)
+  const T* hbuf;        // (K, 2, N, Hp)
+  const T* gbuf;        // (K, 2, N, Hp)
+  float* part;
+  float* partb1;
+  float* partb2;
+  int64_t N;
+  int D, K, h, HW, Hp;
+  int nslab, slab_tiles;
+};
+
+template <int HT>
+__global__ void __launch_bounds__(512) k_big_dw2(Dw2Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NF = 2 * HT;
+  constexpr int HPB = HT * 64;
+  constexpr int CPR = HPB / 16;
+  constexpr int TILE = 32 * HPB;
+  constexpr int HTILE = 32 * 256;           // [32 tokens][128 hidden] bf16
+  constexpr int NTH = 512;
+  constexpr int CPT = TILE / 16 / NTH;
+  constexpr int STAGE = 2 * TILE + 2 * HTILE;
+  constexpr int NBUF = HT <= 4 ? 4 : 3;
+  constexpr int PER = 2 * CPT + 2;          // DMAs per thread and tile
+  static_assert(CPT >= 1 && HTILE / 16 == NTH, "tile / block mismatch");
+  const int lane = threadIdx.x & 63;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int Z = (a.HW + 7) / 8;             // same XCD-aware block order as k_big_dw
+  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+  const int zb = jx % Z, grp = (jx / Z) * 8 + xcd;
+  if (grp >= a.nslab * 2 * a.K) return;
+  const int slab = grp % a.nslab, kn = grp / a.nslab, hw = zb * 8 + wave;
+  const int h = a.h;
+  const bool wave_on = hw < a.HW;
+  const bool want_b2 = zb == 0 && wave == 0;
+  f32x4 dW1[NF], dW2[NF];
+  float db1 = 0.f, db2[NF];
+#pragma unroll
+  for (int v = 0; v < NF; ++v) { dW1[v] = f32x4{0.f, 0.f, 0.f, 0.f}; dW2[v] = dW1[v]; db2[v] = 0.f; }
+
+  const int64_t tile0 = (int64_t)slab * a.slab_tiles;
+  int ntiles = (int)((a.N + 31) / 32 - tile0);
+  if (ntiles > a.slab_tiles) ntiles = a.slab_tiles;
+  int srow[CPT], scol[CPT], vox[CPT], vog[CPT];
+#pragma unroll
+  for (int u = 0; u < CPT; ++u) {
+    const int id = threadIdx.x + NTH * u;
+    const int row = id / CPR;
+    int sc = (id % CPR) ^ swz(row);
+    if (sc * 8 >= h) sc = h / 8 - 1;
+    srow[u] = row; scol[u] = sc * 16;
+    vox[u] = row * a.D * 2 + sc * 16;
+    vog[u] = row * h * 2 + sc * 16;
+  }
+  // hidden tiles: one chunk per thread; chunks past Hp (units no wave of this block owns) re-read a valid chunk
+  const int hrow = threadIdx.x >> 4;
+  int hsc = (threadIdx.x & 15) ^ swz(hrow);
+  if (128 * zb + 8 * hsc >= a.Hp) hsc = 0;
+  const int hcol = (128 * zb + 8 * hsc) * 2;
+  const char* gx = reinterpret_cast<const char*>(a.z_in);
+  const char* gg = reinterpret_cast<const char*>(a.dSdT + (int64_t)kn * a.N * h);
+  const char* gh = reinterpret_cast<const char*>(a.hbuf + (int64_t)kn * a.N * a.Hp);
+  const char* gd = reinterpret_cast<const char*>(a.gbuf + (int64_t)kn * a.N * a.Hp);
+  auto issue_tile = [&](int n, int buf) {
+    const int nn = n < ntiles ? n : ntiles - 1;
+    const int64_t t0 = (tile0 + nn) * 32;
+    const int64_t left = a.N - t0;
+    const int lastrow = left < 32 ? (int)left - 1 : 31;
+    char* bx = smem + buf * STAGE + wave * 1024;
+    const char* tx = gx + t0 * a.D * 2;
+    const char* tg = gg + t0 * h * 2;
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) {
+      const bool inrow = srow[u] <= lastrow;
+      const unsigned ox = inrow ? vox[u] : lastrow * a.D * 2 + scol[u];
+      const unsigned og = inrow ? vog[u] : lastrow * h * 2 + scol[u];
+      dma16(tx + ox, bx + u * NTH * 16);
+      dma16(tg + og, bx + TILE + u * NTH * 16);
+    }
+    const unsigned oh = (unsigned)((hrow <= lastrow ? hrow : lastrow) * a.Hp * 2 + hcol);
+    dma16(gh + t0 * a.Hp * 2 + oh, bx + 2 * TILE);
+    dma16(gd + t0 * a.Hp * 2 + oh, bx + 2 * TILE + HTILE);
+  };
+  auto rows_of = [&](int n) -> int {
+    if (n >= ntiles) return 0;
+    const int64_t left = a.N - (tile0 + n) * 32;
+    return left < 32 ? (int)left : 32;
+  };
+  // rows that do not count: zero d out and d pre (x0 and hid stay: finite values times zero)
+  auto fix_tile = [&](int n, int buf) {
+    const int nrows = rows_of(n);
+    if (nrows < 32) {
+      const u16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+      char* bg = smem + buf * STAGE + TILE + threadIdx.x * 16;
+#pragma unroll
+      for (int u = 0; u < CPT; ++u)
+        if (srow[u] >= nrows) *reinterpret_cast<u16x8*>(bg + u * NTH * 16) = zero;
+      if (hrow >= nrows) *reinterpret_cast<u16x8*>(smem + buf * STAGE + 2 * TILE + HTILE + threadIdx.x * 16) = zero;
+    }
+  };
+  int to0[8], to1[8], th0, th1;
+#pragma unroll
+  for (int v = 0; v < 8; ++v) tr_offsets<HPB>(v, lane, to0[v], to1[v]);
+  tr_offsets<256>(wave, lane, th0, th1);
+
+  // tile t lives in stage t % NBUF; NBUF - 1 tiles are issued ahead.  Per tile: wait for its DMAs, one block barrier (the
+  // tile is visible to every wave AND the stage tile n-1 used is free), refill that stage, compute.
+#pragma unroll
+  for (int t = 0; t < NBUF - 1; ++t) issue_tile(t, t);
+  int bc = 0, bi = NBUF - 1;
+#pragma unroll 1
+  for (int n = 0; n < ntiles; ++n) {
+    __builtin_amdgcn_sched_barrier(0);
+    wait_vm<(NBUF - 2) * PER>();
+    fix_tile(n, bc);
+    __syncthreads();
+    issue_tile(n + NBUF - 1, bi);
+    if (wave_on) {
+      const char* bx = smem + bc * STAGE;
+      const char* bg = bx + TILE;
+      const bf16x8 hb = tr_read(bx + 2 * TILE, th0, th1);
+      const bf16x8 gb = tr_read(bx + 2 * TILE + HTILE, th0, th1);
+      {
+        float sm = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) sm += (float)gb[jj];
+        db1 += sm;
+      }
+      // feature tiles in chunks of CV: the reads of chunk c+1 are issued before the MFMAs of chunk c
+      constexpr int CV = 4, NCH = NF / CV;
+      bf16x8 fb[2][2 * CV];
+      auto reads = [&](int c, int sl) {
+#pragma unroll
+        for (int i = 0; i < CV; ++i) {
+          const int v = c * CV + i;
+          fb[sl][i] = tr_read(bx + (v >> 3) * 256, to0[v & 7], to1[v & 7]);
+          fb[sl][CV + i] = tr_read(bg + (v >> 3) * 256, to0[v & 7], to1[v & 7]);
+        }
+      };
+      reads(0, 0);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < NCH) reads(c + 1, (c + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < CV; ++i) {
+          const int v = c * CV + i;
+          dW1[v] = mma16(fb[c & 1][i], gb, dW1[v]);
+          const bf16x8 gf = fb[c & 1][CV + i];
+          dW2[v] = mma16(gf, hb, dW2[v]);
+          if (want_b2) {                       // wave-uniform
+            float sm = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) sm += (float)gf[jj];
+            db2[v] += sm;
+          }
+        }
+      }
+    }
+    bc = bc + 1 == NBUF ? 0 : bc + 1; bi = bi + 1 == NBUF ? 0 : bi + 1;
+  }
+  wait_vm<0>();                                // the refills issued past the slab's end land before the block exits
+  if (!wave_on) return;
+  const int64_t item = ((int64_t)kn * a.HW + hw) * a.nslab + slab;
+  float* out = a.part + item * (2 * NF * 256) + lane * 4;
+#pragma unroll
+  for (int v = 0; v < NF; ++v) {
+    *reinterpret_cast<f32x4*>(out + v * 256) = dW1[v];
+    *reinterpret_cast<f32x4*>(out + (NF + v) * 256) = dW2[v];
+  }
+  db1 += __shfl_xor(db1, 16, 64);
+  db1 += __shfl_xor(db1, 32, 64);
+  if (g == 0) a.partb1[item * 16 + r16] = db1;
+  if (want_b2) {
+#pragma unroll
+    for (int v = 0; v < NF; ++v) {
+      float s2 = db2[v] + __shfl_xor(db2[v], 16, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (g == 0) a.partb2[((int64_t)kn * a.nslab + slab) * (16 * NF) + 16 * v + r16] = s2;
+    }
+  }
+}
+
 struct DwRedArgs {
   const float *part, *partb1, *partb2;
   float *dW1, *db1, *dW2, *db2;   // (K, 2, H, h), (K, 2, H), (K, 2, h, H), (K, 2, h)
@@ -1455,8 +1692,13 @@ static void launch_chain(int mode, const BigArgs& a, unsigned grid, size_t lds, 
 }
 template <int HT, int ACT>
 static void launch_nets(const NetsArgs& a, unsigned grid, size_t lds, hipStream_t st) {
-  (void)hipFuncSetAttribute((const void*)k_big_nets<HT, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  k_big_nets<HT, ACT><<<grid, 512, lds, st>>>(a);
+  if (a.hbuf) {
+    (void)hipFuncSetAttribute((const void*)k_big_nets<HT, ACT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    k_big_nets<HT, ACT, true><<<grid, 512, lds, st>>>(a);
+  } else {
+    (void)hipFuncSetAttribute((const void*)k_big_nets<HT, ACT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    k_big_nets<HT, ACT, false><<<grid, 512, lds, st>>>(a);
+  }
 }
 template <int HT, int ACT>
 static void launch_dw(const DwBigArgs& a, dim3 grid, size_t lds, hipStream_t st) {
@@ -1469,6 +1711,12 @@ static void launch_dw(const DwBigArgs& a, dim3 grid, size_t lds, hipStream_t st)
     k_big_dw<HT, ACT, 1><<<grid, 512, lds, st>>>(a);
     k_big_dw<HT, ACT, 2><<<grid, 512, lds, st>>>(a);
   }
+}
+template <int HT>
+static void launch_dw2(const Dw2Args& a, dim3 grid, hipStream_t st) {
+  const size_t lds = (size_t)(HT <= 4 ? 4 : 3) * (2 * 32 * HT * 64 + 2 * 32 * 256);
+  (void)hipFuncSetAttribute((const void*)k_big_dw2<HT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  k_big_dw2<HT><<<grid, 512, lds, st>>>(a);
 }
 #define BIG_DISPATCH(HTv, actv, CALL)                                           \
   do {                                                                          \
@@ -1595,15 +1843,25 @@ extern "C" int64_t mivae_nice_big_dw_workspace_floats(int64_t N, int64_t h, int6
   return (int64_t)K * 2 * (g.Hp / 16) * nslab * (4 * g.HT * 256 + 16) + (int64_t)K * 2 * nslab * g.hp;
 }
 
+// elements (latent dtype) of the optional hidden-activation scratch of mivae_nice_big_bwd
+extern "C" int64_t mivae_nice_big_hidden_elems(int64_t N, int64_t h, int64_t H, int64_t K) {
+  if (N < 1 || K < 1 || !big_shape_ok(h, H)) return 0;
+  const BigGeom g = big_geom_inst((int)h, (int)H, (int)K);
+  return 2 * K * 2 * N * g.Hp;
+}
+
 // Backward of mivae_nice_big_fwd (forward direction): dz_in (N, D) and the parameter gradients.
 //   packed_chain / packed_nets / packed_bias: ST_CHAIN / ST_NETS / ST_BIAS images of the same weights;
 //   dSdT: scratch (K, 2, N, h) in the latent dtype; workspace: mivae_nice_big_dw_workspace_floats floats;
+//   hidden: scratch of mivae_nice_big_hidden_elems elements (latent dtype, 16-byte aligned) or NULL.  With it the nets
+//   kernel saves the hidden activations and d pre and the weight gradients contract them directly (k_big_dw2); without
+//   it they are recomputed from x0 and d s / d t (k_big_dw: no extra memory, ~2x the weight-gradient time);
 //   gradients go to dW1 (K,2,H,h), db1 (K,2,H), dW2 (K,2,h,H), db2 (K,2,h), or, when grad_ptrs (device int64[K][8] in
 //   mivae_nice_pack's order) is given, are ADDED into those buffers.
 extern "C" int mivae_nice_big_bwd(const void* z_in, const void* z_out, const void* x1_hist, const int64_t* mask,
                                   const int64_t* ptr_table, const void* packed_chain, const void* packed_nets,
                                   const void* packed_bias, const void* dz_out, const float* dlogp, void* dz_in,
-                                  void* dSdT, float* workspace,
+                                  void* dSdT, void* hidden, float* workspace,
                                   float* dW1, float* db1, float* dW2, float* db2, const int64_t* grad_ptrs,
                                   int64_t Bn, int64_t mask_div, int64_t S, int64_t D, int64_t H, int64_t K, int act,
                                   int base, float mu, float std, void* stream) {
@@ -1615,7 +1873,8 @@ extern "C" int mivae_nice_big_bwd(const void* z_in, const void* z_out, const voi
   MIVAE_REQUIRE(grad_ptrs || (dW1 && db1 && dW2 && db2), "nice_big_bwd: no gradient destination");
   MIVAE_REQUIRE(!base || (std > 0.f && z_out), "nice_big_bwd: base log-prob needs z_out and std > 0");
   MIVAE_REQUIRE(aligned16(z_in) && aligned16(x1_hist) && aligned16(dz_in) && aligned16(dSdT) && aligned16(workspace) &&
-                (!z_out || aligned16(z_out)) && (!dz_out || aligned16(dz_out)) && aligned16(packed_chain) &&
+                (!z_out || aligned16(z_out)) && (!dz_out || aligned16(dz_out)) && (!hidden || aligned16(hidden)) &&
+                aligned16(packed_chain) &&
                 aligned16(packed_nets) && aligned16(packed_bias), "nice_big_bwd: operands must be 16-byte aligned");
   const BigGeom g = big_geom_inst((int)(D / 2), (int)H, (int)K);
   hipStream_t st = (hipStream_t)stream;
@@ -1641,6 +1900,7 @@ extern "C" int mivae_nice_big_bwd(const void* z_in, const void* z_out, const voi
     a.dz_in = (T*)dz_in; a.N = N; a.S = (int)S; a.mask_div = (int)mask_div; a.D = (int)D; a.K = (int)K;
     a.h = g.h; a.H = g.H; a.HC = g.HC; a.act = act; a.base = base; a.mu = mu;
     a.inv2var = base ? 1.0f / (2.0f * std * std) : 0.f;
+    if (hidden) { a.hbuf = (T*)hidden; a.gbuf = (T*)hidden + (int64_t)K * 2 * N * g.Hp; }
 #define CALL(HTc, ACTc) launch_nets<HTc, ACTc>(a, grid, lds_nets, st)
     BIG_DISPATCH(g.HT, act, CALL);
 #undef CALL
@@ -1660,10 +1920,18 @@ extern "C" int mivae_nice_big_bwd(const void* z_in, const void* z_out, const voi
     const int nw = 8;
     const int64_t ngrp = (int64_t)a.nslab * K * 2, zsib = (a.HW + nw - 1) / nw;
     dim3 dgrid((unsigned)(((ngrp + 7) / 8) * 8 * zsib));   // 1-D: see the block order in k_big_dw
-    const size_t dlds = (size_t)(g.HT <= 4 ? BIG_DW_NBUF : 4) * 2 * 32 * g.HT * 64;   // NBUF tile buffers x 2 operands
+    if (hidden) {
+      Dw2Args b = {};
+      b.z_in = a.z_in; b.dSdT = a.dSdT; b.hbuf = (const T*)hidden; b.gbuf = (const T*)hidden + (int64_t)K * 2 * N * g.Hp;
+      b.part = a.part; b.partb1 = a.partb1; b.partb2 = a.partb2; b.N = N; b.D = (int)D; b.K = (int)K; b.h = g.h;
+      b.HW = a.HW; b.Hp = g.Hp; b.nslab = a.nslab; b.slab_tiles = a.slab_tiles;
+      if (g.HT == 4) launch_dw2<4>(b, dgrid, st); else launch_dw2<8>(b, dgrid, st);
+    } else {
+      const size_t dlds = (size_t)(g.HT <= 4 ? BIG_DW_NBUF : 4) * 2 * 32 * g.HT * 64;   // NBUF tile buffers x 2 operands
 #define CALL(HTc, ACTc) launch_dw<HTc, ACTc>(a, dgrid, dlds, st)
-    BIG_DISPATCH(g.HT, act, CALL);
+      BIG_DISPATCH(g.HT, act, CALL);
 #undef CALL
+    }
     MIVAE_CHECK_LAUNCH("nice_big_dw");
     DwRedArgs r = {};
     r.part = a.part; r.partb1 = a.partb1; r.partb2 = a.partb2;

@@ -1297,6 +1297,18 @@ def nice_big_pack_multi(params: Sequence[torch.Tensor], K: int, h: int, H: int, 
     return outs
 
 
+# Weight-gradient route of the wide-latent backward.  True: the nets launch keeps the hidden activations / d pre in HBM
+# (2 K 2 N Hp elements) and the weight gradients contract them directly (k_big_dw2); False: they are recomputed from x0
+# and d s / d t (k_big_dw, no extra memory); "auto": save when D/2 > 128 -- there the recompute kernel needs two passes
+# (register budget) and saving wins (C5: nets + dW 4.8 ms vs 6.2 ms), while at D/2 <= 128 the extra 2 x K 2 N Hp HBM
+# round trip costs more than the recompute it removes (C3: 952 us vs 886 us).
+NICE_BIG_SAVE_HIDDEN = "auto"
+
+
+def _nice_big_save_hidden(h: int) -> bool:
+    return h > 128 if NICE_BIG_SAVE_HIDDEN == "auto" else bool(NICE_BIG_SAVE_HIDDEN)
+
+
 class _NiceStackBig(torch.autograd.Function):
     """K fused NICE-FF steps (+ optional base log-prob) on the wide-latent kernels.  params as _NiceStack."""
 
@@ -1334,6 +1346,9 @@ class _NiceStackBig(torch.autograd.Function):
         dz_in = torch.empty_like(z)
         dsdt = torch.empty(K, 2, N, h, dtype=z.dtype, device=dev)
         ws = torch.empty(L.query("mivae_nice_big_dw_workspace_floats", N, h, H, K), dtype=torch.float32, device=dev)
+        # hidden activations + d pre of every (step, net, token), saved by the nets launch for the weight gradients
+        hid = torch.empty(L.query("mivae_nice_big_hidden_elems", N, h, H, K), dtype=z.dtype, device=dev) \
+            if _nice_big_save_hidden(h) else None
         dlog = None if dtok is None else dtok.contiguous().float()
         dzo = None if dz_out is None else dz_out.contiguous()
         sink = grad_sink_ok(*params) and all(ctx.needs_input_grad[8:])
@@ -1349,7 +1364,7 @@ class _NiceStackBig(torch.autograd.Function):
         with _timed("nice_stack_bwd"):
             L.call("mivae_nice_big_bwd", L.ptr(z), L.ptr(z_out), L.ptr(hist), L.ptr(mask), L.ptr(_ptr_table(params, dev)),
                    L.ptr(pc), L.ptr(pn), L.ptr(pb),
-                   L.ptr(dzo), L.ptr(dlog), L.ptr(dz_in), L.ptr(dsdt), L.ptr(ws), L.ptr(dW1), L.ptr(db1), L.ptr(dW2),
+                   L.ptr(dzo), L.ptr(dlog), L.ptr(dz_in), L.ptr(dsdt), L.ptr(hid), L.ptr(ws), L.ptr(dW1), L.ptr(db1), L.ptr(dW2),
                    L.ptr(db2), L.ptr(table), Bn, 1, S, D, H, K, act, base, mu, std, L.stream())
         if sink:
             sink_arrived(*[p.grad for p in params])

@@ -33,7 +33,7 @@ from typing import Dict, Optional
 import torch
 import torch.distributed as dist
 
-from . import dp
+from . import dp, ops
 
 
 class TrainStep:

@@ -147,3 +147,27 @@ def test_nice_wide_fp32_composed_path(M, B, S, D, H, K):
             sd = dict(net._feedforward.named_parameters())
             for i, nm in enumerate(names):
                 assert rel_err(sd[nm].grad, g_r[8 * k + off + i]) < 5e-5, (k, off, nm)
+
+
+@pytest.mark.parametrize("D,H", [(256, 160), (512, 288)])
+def test_nice_big_saved_hidden_matches_recompute(M, D, H):
+    """The two weight-gradient routes of mivae_nice_big_bwd -- hidden activations / d pre saved by the nets launch and
+    contracted directly (k_big_dw2), or recomputed from x0 and d s / d t (k_big_dw) -- agree to bf16 rounding (the saved
+    route sums the bf16-rounded d pre for the bias gradient, the recompute route its fp32 value); dz is the same kernel either
+    way (bit equal).  The default picks by width (saved for D/2 > 128), so the oracle tests above cover the recompute
+    route at D = 256 and the saved route at D = 512; this test runs both routes at both widths."""
+    ps, flat, z0, mask, cz, cl = make_case(3, 70, D, H, 2, "gelu", 11, True, True)
+    outs = []
+    for save in (True, False):
+        gp = [t.to(DEV).clone().requires_grad_(True) for t in flat]
+        zg = z0.to(DEV).bfloat16().requires_grad_(True)
+        M.ops.NICE_BIG_SAVE_HIDDEN = save
+        try:
+            zK, lp = M.ops.nice_stack(zg, mask.to(DEV), gp, H, "gelu", base=True)
+            ((zK.float() * cz.to(DEV)).sum() + (lp * cl.to(DEV)).sum()).backward()
+        finally:
+            M.ops.NICE_BIG_SAVE_HIDDEN = "auto"
+        outs.append(([p.grad.clone() for p in gp], zg.grad.clone()))
+    assert torch.equal(outs[0][1], outs[1][1])
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert rel_err(a, b) < 1e-2, rel_err(a, b)

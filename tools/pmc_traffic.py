@@ -22,7 +22,7 @@ NAMES = {r"k_nll_fwd<": "nll_fwd", r"k_nll_bwd<": "nll_bwd", r"k_stack_fwd<": "n
          r"k_lce_bwd(_s)?<\d+, true>": "lce_bwd_dh", r"k_lce_dh_combine\(": "lce_bwd_dh",
          # wide-latent path (csrc/nice_big.hip): MODE 0 = forward, 2 = backward chain
          r"k_big_chain<\d+, 0, ": "nice_stack_fwd", r"k_big_chain<\d+, 2, ": "nice_stack_bwd",
-         r"k_big_nets<": "nice_stack_bwd", r"k_big_dw<": "nice_stack_bwd", r"k_big_dw_reduce\(": "nice_stack_bwd"}
+         r"k_big_nets<": "nice_stack_bwd", r"k_big_dw<": "nice_stack_bwd", r"k_big_dw2<": "nice_stack_bwd", r"k_big_dw_reduce\(": "nice_stack_bwd"}
 
 
 def collect(directory, counter):
