@@ -46,6 +46,11 @@ const char* mivae_last_error(void);
 /* ---- integer helpers (bit exact) ------------------------------------------------------------ */
 /* mask[i] = tokens[i] != 0.  Replaces get_tokens_mask, nn/utils.py:12-14. */
 int mivae_tokens_mask(const int64_t* tokens, int64_t* mask, int64_t n, void* stream);
+/* Additive attention bias from the token mask, built once per encoder / decoder call instead of per layer: 0 where
+ * the key may be attended, -inf at padded keys (and at k > q when causal).  out (B, 1, 1, S), or (B, 1, S, S) when
+ * causal, f32 or bf16.  Replaces the mask.ne(0) / tril / masked_fill chain of MultiHeadAttention.forward,
+ * vae_lm/nn/transformer.py:75-89 (bracket of the path, row f). */
+int mivae_attn_bias(const int64_t* mask, void* out, int64_t B, int64_t S, int causal, int dtype, void* stream);
 /* last_idx[b] = sum_s mask[b,s] - 1; ctx[b,:] = out[b, last_idx[b], :] (index -1 wraps like torch).
  * Replaces Encoder.forward's gather, models/base/encoders/encoder.py:35-37.  last_idx may be NULL. */
 int mivae_gather_last(const void* out, const int64_t* mask, void* ctx, int64_t* last_idx, int64_t B,

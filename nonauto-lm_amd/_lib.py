@@ -22,6 +22,7 @@ SIGNATURES = {
     "mivae_version": [],
     "mivae_last_error": [],
     "mivae_tokens_mask": [P, P, I64, P],
+    "mivae_attn_bias": [P, P, I64, I64, I32, I32, P],
     "mivae_gather_last": [P, P, P, P, I64, I64, I64, I32, P],
     "mivae_reparam_logq_fwd": [P, P, P, P, P, P, I64, I64, I64, I64, I32, P],
     "mivae_reparam_logq_bwd": [P, P, P, P, P, P, P, I64, I64, I64, I64, I32, P],

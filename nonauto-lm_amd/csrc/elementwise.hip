@@ -808,6 +808,40 @@ extern "C" int mivae_tokens_mask(const int64_t* tokens, int64_t* mask, int64_t n
   return MIVAE_OK;
 }
 
+// Additive attention bias of the transformer bracket from the token mask: 0 where the key may be attended, -inf
+// elsewhere (key padding, and k > q when causal).  out (B, 1, 1, S), or (B, 1, S, S) when causal.  Replaces the
+// mask.ne(0) / tril / & / where chain that MultiHeadAttention.forward (nn/transformer.py:75-89) rebuilds per layer.
+template <typename T>
+__global__ void k_attn_bias(const int64_t* __restrict__ mask, T* __restrict__ out, int64_t total, int S, int causal) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % S);
+    bool keep;
+    if (causal) {
+      const int64_t bq = i / S;
+      const int q = (int)(bq % S);
+      keep = mask[(bq / S) * S + k] != 0 && k <= q;
+    } else {
+      keep = mask[i] != 0;
+    }
+    float v[1] = {keep ? 0.f : -INFINITY};
+    RowIO<T, 1>::store(out + i, v);
+  }
+}
+
+extern "C" int mivae_attn_bias(const int64_t* mask, void* out, int64_t B, int64_t S, int causal, int dtype, void* stream) {
+  MIVAE_REQUIRE(B >= 0 && S >= 1 && S < (1 << 20), "attn_bias: bad shape B=%ld S=%ld", (long)B, (long)S);
+  if (B == 0) return MIVAE_OK;
+  MIVAE_REQUIRE(mask && out, "attn_bias: null pointer");
+  MIVAE_REQUIRE(dtype == MIVAE_F32 || dtype == MIVAE_BF16, "attn_bias: bad dtype %d", dtype);
+  const int64_t total = causal ? B * S * S : B * S;
+  unsigned grid = (unsigned)((total + kBlock - 1) / kBlock);
+  if (grid > 8192) grid = 8192;
+  if (dtype == MIVAE_F32) k_attn_bias<float><<<grid, kBlock, 0, S_(stream)>>>(mask, (float*)out, total, (int)S, causal ? 1 : 0);
+  else k_attn_bias<unsigned short><<<grid, kBlock, 0, S_(stream)>>>(mask, (unsigned short*)out, total, (int)S, causal ? 1 : 0);
+  MIVAE_CHECK_LAUNCH("attn_bias");
+  return MIVAE_OK;
+}
+
 extern "C" int mivae_gather_last(const void* out, const int64_t* mask, void* ctx, int64_t* last_idx,
                                  int64_t B, int64_t S, int64_t E, int dtype, void* stream) {
   MIVAE_REQUIRE(B >= 0 && S > 0 && E > 0, "gather_last: bad shape B=%ld S=%ld E=%ld", (long)B, (long)S, (long)E);

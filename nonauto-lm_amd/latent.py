@@ -196,7 +196,7 @@ class Posterior(torch.nn.Module, Registrable):
         else:                                            # injected eps (parity runs) / random=False
             noise = self._draw(self._mu, random, eps)
             z, log_prob = ops.reparam_logq(self._mu, self._sigma, noise, mask, self.samples)
-        rep_mask = None if mask is None else mask.repeat_interleave(self.samples, dim=0)
+        rep_mask = mask if mask is None or self.samples == 1 else mask.repeat_interleave(self.samples, dim=0)
         return z, rep_mask, log_prob
 
     def calc_mutual_info(self, z, log_prob, mask=None):

@@ -106,8 +106,11 @@ class VAELmModel(torch.nn.Module, Registrable):
         latent, posterior_log_prob = self.sample_from_posterior(encoded, random=random, eps=eps)
         tgt_mask = None
         if tgt_tokens is not None:
-            tgt_mask = ops.tokens_mask(tgt_tokens).repeat_interleave(n, dim=0)
-            tgt_tokens = tgt_tokens.repeat_interleave(n, dim=0)
+            # the usual call reconstructs the source: one mask kernel, and no repeat copies for a single sample
+            tgt_mask = encoded.mask if tgt_tokens is src_tokens else ops.tokens_mask(tgt_tokens)
+            if n != 1:
+                tgt_mask = tgt_mask.repeat_interleave(n, dim=0)
+                tgt_tokens = tgt_tokens.repeat_interleave(n, dim=0)
         decoded = {k: v.view(batch, n, *v.shape[1:])
                    for k, v in self.decode(latent.z, tgt_mask, target=tgt_tokens).items()}
         prior_log_prob = self._get_prior_log_prob(latent, tgt_mask)
@@ -187,6 +190,7 @@ class NonAutoModel(VAELmModel):
         return self._encoder(self._embedder(tokens), ops.tokens_mask(tokens))
 
     def decode(self, z, mask, target=None):
+        """`mask` is the token mask of `target` when a target is given (forward() passes it that way)."""
         decoded = self._decoder(z, mask)
         if (self.training_outputs_only and target is not None and torch.is_autocast_enabled()
                 and torch.get_autocast_dtype("cuda") == torch.bfloat16
@@ -194,7 +198,7 @@ class NonAutoModel(VAELmModel):
             # training step under bf16 autocast: projection + NLL fused, the (N, V) logits are never written
             # (SURVEY 8f-1); `logits` / `probs` / `preds` are not produced in this mode
             proj = self._vocab_projection
-            weights = ops.tokens_mask(target).float()
+            weights = (mask if mask is not None and mask.shape == target.shape else ops.tokens_mask(target)).float()
             smoothing = self._loss._smoothing if (self._loss._smoothing and self.training) else 0.0
             return {"loss": ops.linear_nll(decoded, proj.weight, proj.bias, target, weights, smoothing,
                                            getattr(proj.weight, "_mivae_lp", None))}

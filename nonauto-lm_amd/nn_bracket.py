@@ -333,7 +333,13 @@ class MultiHeadAttention(torch.nn.Module):
         b, s, _ = x.shape
         return x.view(b, s, self._num_heads, self._attn_size).transpose(1, 2)
 
-    def forward(self, query, key, value, mask=None):
+    def fused_ok(self, x) -> bool:
+        """the library's fused attention applies (bf16 autocast bracket on the GPU, inactive attention dropout)"""
+        return bool(USE_FUSED_ATTENTION and x.is_cuda and torch.is_autocast_enabled()
+                    and torch.get_autocast_dtype("cuda") == torch.bfloat16
+                    and not (self.training and isinstance(self._dropout, torch.nn.Dropout) and self._dropout.p > 0))
+
+    def forward(self, query, key, value, mask=None, attn_bias=None):
         if query is key and key is value:        # self-attention: the three projections share their input
             q, k, v = linear_group(query, [self._projections[n] for n in ("query", "key", "value")])
             q, k, v = self._split(q), self._split(k), self._split(v)
@@ -346,11 +352,13 @@ class MultiHeadAttention(torch.nn.Module):
                 and not (self.training and isinstance(self._dropout, torch.nn.Dropout) and self._dropout.p > 0)):
             # bf16 training bracket: the library's fused attention (same key-padding x causal mask, -inf instead of
             # -1e13 fill: identical for every row that has a valid key, i.e. always with prefix masks)
-            keep = None if mask is None else mask.ne(0)[:, None, None, :]
-            if self._mask_tril:
-                tril = torch.ones(S, S, dtype=torch.bool, device=q.device).tril()[None, None]
-                keep = tril if keep is None else keep & tril
-            out = F.scaled_dot_product_attention(q, k, v, attn_mask=keep)
+            if attn_bias is not None and mask is not None:
+                # 0 / -inf bias built once per encoder / decoder call by ops.attention_bias (one launch for all layers)
+                out = F.scaled_dot_product_attention(q, k, v, attn_mask=attn_bias)
+            elif mask is not None:
+                out = F.scaled_dot_product_attention(q, k, v, attn_mask=ops.attention_bias(mask, self._mask_tril, q.dtype))
+            else:
+                out = F.scaled_dot_product_attention(q, k, v, is_causal=self._mask_tril)
             return self._output(out.transpose(1, 2).reshape(q.size(0), S, -1))
         scores = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(self._attn_size)
         if mask is None:
@@ -431,8 +439,14 @@ class _TransformerLayer(torch.nn.Module):
             "attn": SublayerConnection(input_size, dropout=dropout),
             "pos_ffn": SublayerConnection(input_size, dropout=dropout)})
 
-    def forward(self, x, mask):
-        x = self._sublayers["attn"](x, lambda y: self._attn(y, y, y, mask))
+    def attention_bias(self, x, mask):
+        """the layer stack's shared attention bias for (x, mask), or None when the explicit masked-softmax path runs"""
+        if mask is None or not self._attn.fused_ok(x):
+            return None
+        return ops.attention_bias(mask, self._attn._mask_tril, torch.bfloat16)
+
+    def forward(self, x, mask, attn_bias=None):
+        x = self._sublayers["attn"](x, lambda y: self._attn(y, y, y, mask, attn_bias))
         sub = self._sublayers["pos_ffn"]
         if USE_FUSED_FFN and ffn_block_supported(x, sub._norm, self._pos_ffn, sub):
             f = self._pos_ffn
@@ -513,8 +527,9 @@ class TransformerEncoder(Encoder):
     def encoder(self, x, mask):
         m = mask.unsqueeze(-1).to(x.dtype)
         x = self._pos_enc(x) * m
+        bias = self._layers[0].attention_bias(x, mask) if len(self._layers) else None
         for layer in self._layers:
-            x = layer(x, mask)
+            x = layer(x, mask, bias)
         return x * m
 
 
@@ -662,8 +677,9 @@ class TransformerDecoder(Decoder):
 
     def decoder(self, z, mask):
         z = self._pos_enc(self._dropout(z)) * mask.unsqueeze(-1).to(z.dtype)
+        bias = self._layers[0].attention_bias(z, mask) if len(self._layers) else None
         for layer in self._layers:
-            z = layer(z, mask)
+            z = layer(z, mask, bias)
         return z
 
 

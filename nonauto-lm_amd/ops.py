@@ -101,6 +101,17 @@ def gather_last(output: torch.Tensor, mask: torch.Tensor) -> Tuple[torch.Tensor,
     return _GatherLast.apply(output, _mask_i64(mask))
 
 
+def attention_bias(mask: torch.Tensor, causal: bool, dtype: torch.dtype) -> torch.Tensor:
+    """Additive attention bias of a (B, S) token mask: 0 / -inf, (B, 1, 1, S) or (B, 1, S, S) when causal (one launch;
+    the bracket builds it once per encoder / decoder call and hands it to every layer)."""
+    L.require_gpu(mask)
+    mask = _mask_i64(mask)
+    B, S = mask.shape
+    out = torch.empty((B, 1, S, S) if causal else (B, 1, 1, S), dtype=dtype, device=mask.device)
+    L.call("mivae_attn_bias", L.ptr(mask), L.ptr(out), B, S, int(bool(causal)), L.dtype_code(dtype), L.stream())
+    return out
+
+
 def segment_sum(tok: torch.Tensor, nseg: int, S: int, add: Optional[torch.Tensor] = None) -> torch.Tensor:
     out = torch.empty(nseg, dtype=torch.float32, device=tok.device)
     L.call("mivae_segment_sum", L.ptr(tok), L.ptr(add), L.ptr(out), nseg, S, L.stream())
