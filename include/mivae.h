@@ -46,6 +46,12 @@ const char* mivae_last_error(void);
 /* ---- integer helpers (bit exact) ------------------------------------------------------------ */
 /* mask[i] = tokens[i] != 0.  Replaces get_tokens_mask, nn/utils.py:12-14. */
 int mivae_tokens_mask(const int64_t* tokens, int64_t* mask, int64_t n, void* stream);
+/* sigma head of the posterior in one launch: sigma = Hardtanh(Softplus(pre), lo, hi) elementwise over n values of the
+ * latent dtype (models/nonauto_lm/posteriors/posterior.py:23-27, auto posterior.py:23-27: Softplus(beta 1, threshold
+ * 20) + Hardtanh(1e-4, 5)); backward: d pre = d sigma * sigmoid(pre) where lo < softplus(pre) < hi, else 0. */
+int mivae_sigma_head_fwd(const void* pre, void* sigma, int64_t n, float lo, float hi, int dtype, void* stream);
+int mivae_sigma_head_bwd(const void* pre, const void* dsigma, void* dpre, int64_t n, float lo, float hi, int dtype,
+                         void* stream);
 /* Additive attention bias from the token mask, built once per encoder / decoder call instead of per layer: 0 where
  * the key may be attended, -inf at padded keys (and at k > q when causal).  out (B, 1, 1, S), or (B, 1, S, S) when
  * causal, f32 or bf16.  Replaces the mask.ne(0) / tril / masked_fill chain of MultiHeadAttention.forward,

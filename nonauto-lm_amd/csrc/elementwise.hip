@@ -842,6 +842,63 @@ extern "C" int mivae_attn_bias(const int64_t* mask, void* out, int64_t B, int64_
   return MIVAE_OK;
 }
 
+// sigma head of the posterior: sigma = Hardtanh(Softplus(pre), lo, hi) (nonauto posterior.py:23-27: Softplus with
+// beta = 1, threshold = 20, then Hardtanh(1e-4, 5)) and its gradient d pre = d sigma * sigmoid(pre) inside the open
+// interval (lo, hi), 0 elsewhere -- one launch each instead of softplus / hardtanh / dtype-cast kernels.
+__device__ __forceinline__ float softplus20(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+template <typename T>
+__global__ void k_sigma_head_fwd(const T* __restrict__ pre, T* __restrict__ sigma, int64_t n, float lo, float hi) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float v[1];
+    RowIO<T, 1>::load(pre + i, v);
+    v[0] = fminf(fmaxf(softplus20(v[0]), lo), hi);
+    RowIO<T, 1>::store(sigma + i, v);
+  }
+}
+template <typename T>
+__global__ void k_sigma_head_bwd(const T* __restrict__ pre, const T* __restrict__ dsigma, T* __restrict__ dpre, int64_t n,
+                                 float lo, float hi) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float v[1], g[1];
+    RowIO<T, 1>::load(pre + i, v);
+    RowIO<T, 1>::load(dsigma + i, g);
+    const float sp = softplus20(v[0]);
+    const float d = v[0] > 20.f ? 1.f : 1.f / (1.f + expf(-v[0]));
+    g[0] = (sp > lo && sp < hi) ? g[0] * d : 0.f;
+    RowIO<T, 1>::store(dpre + i, g);
+  }
+}
+
+extern "C" int mivae_sigma_head_fwd(const void* pre, void* sigma, int64_t n, float lo, float hi, int dtype, void* stream) {
+  MIVAE_REQUIRE(n >= 0 && lo <= hi, "sigma_head_fwd: bad arguments");
+  if (n == 0) return MIVAE_OK;
+  MIVAE_REQUIRE(pre && sigma, "sigma_head_fwd: null pointer");
+  MIVAE_REQUIRE(dtype == MIVAE_F32 || dtype == MIVAE_BF16, "sigma_head_fwd: bad dtype %d", dtype);
+  unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
+  if (grid > 8192) grid = 8192;
+  if (dtype == MIVAE_F32) k_sigma_head_fwd<float><<<grid, kBlock, 0, S_(stream)>>>((const float*)pre, (float*)sigma, n, lo, hi);
+  else k_sigma_head_fwd<unsigned short><<<grid, kBlock, 0, S_(stream)>>>((const unsigned short*)pre, (unsigned short*)sigma, n, lo, hi);
+  MIVAE_CHECK_LAUNCH("sigma_head_fwd");
+  return MIVAE_OK;
+}
+
+extern "C" int mivae_sigma_head_bwd(const void* pre, const void* dsigma, void* dpre, int64_t n, float lo, float hi,
+                                    int dtype, void* stream) {
+  MIVAE_REQUIRE(n >= 0 && lo <= hi, "sigma_head_bwd: bad arguments");
+  if (n == 0) return MIVAE_OK;
+  MIVAE_REQUIRE(pre && dsigma && dpre, "sigma_head_bwd: null pointer");
+  MIVAE_REQUIRE(dtype == MIVAE_F32 || dtype == MIVAE_BF16, "sigma_head_bwd: bad dtype %d", dtype);
+  unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
+  if (grid > 8192) grid = 8192;
+  if (dtype == MIVAE_F32)
+    k_sigma_head_bwd<float><<<grid, kBlock, 0, S_(stream)>>>((const float*)pre, (const float*)dsigma, (float*)dpre, n, lo, hi);
+  else
+    k_sigma_head_bwd<unsigned short><<<grid, kBlock, 0, S_(stream)>>>((const unsigned short*)pre, (const unsigned short*)dsigma,
+                                                                      (unsigned short*)dpre, n, lo, hi);
+  MIVAE_CHECK_LAUNCH("sigma_head_bwd");
+  return MIVAE_OK;
+}
+
 extern "C" int mivae_gather_last(const void* out, const int64_t* mask, void* ctx, int64_t* last_idx,
                                  int64_t B, int64_t S, int64_t E, int dtype, void* stream) {
   MIVAE_REQUIRE(B >= 0 && S > 0 && E > 0, "gather_last: bad shape B=%ld S=%ld E=%ld", (long)B, (long)S, (long)E);

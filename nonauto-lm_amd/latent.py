@@ -190,7 +190,12 @@ class Posterior(torch.nn.Module, Registrable):
         # a3: the two heads share `encoded` -> one grouped launch forward, one for the input gradient
         mu, pre = linear_group(encoded, [self._mu_net, self._sigma_net[0]])
         self._mu = mu
-        self._sigma = self._sigma_net[2](self._sigma_net[1](pre))
+        sp, ht = self._sigma_net[1], self._sigma_net[2]
+        if (pre.is_cuda and pre.dtype in (torch.float32, torch.bfloat16) and isinstance(sp, torch.nn.Softplus)
+                and sp.beta == 1 and sp.threshold == 20 and isinstance(ht, torch.nn.Hardtanh)):
+            self._sigma = ops.sigma_head(pre, ht.min_val, ht.max_val)      # one launch; sigma in the latent dtype
+        else:
+            self._sigma = ht(sp(pre))
         if random and eps is None and ops.PHILOX:        # eps drawn inside the kernel (Philox): no randn launch
             z, log_prob = ops.reparam_logq_rng(self._mu, self._sigma, mask, self.samples)
         else:                                            # injected eps (parity runs) / random=False

@@ -216,6 +216,34 @@ class _ReparamLogQRng(torch.autograd.Function):
         return dmu, dsg.to(ctx.sigma_dtype), None, None
 
 
+class _SigmaHead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pre, lo, hi):
+        pre = pre.contiguous()
+        sigma = torch.empty_like(pre)
+        L.call("mivae_sigma_head_fwd", L.ptr(pre), L.ptr(sigma), pre.numel(), lo, hi, L.dtype_code(pre.dtype), L.stream())
+        ctx.save_for_backward(pre)
+        ctx.bounds = (lo, hi)
+        return sigma
+
+    @staticmethod
+    def backward(ctx, dsigma):
+        (pre,) = ctx.saved_tensors
+        lo, hi = ctx.bounds
+        dsigma = dsigma.contiguous().to(pre.dtype)
+        dpre = torch.empty_like(pre)
+        L.call("mivae_sigma_head_bwd", L.ptr(pre), L.ptr(dsigma), L.ptr(dpre), pre.numel(), lo, hi,
+               L.dtype_code(pre.dtype), L.stream())
+        return dpre, None, None
+
+
+def sigma_head(pre: torch.Tensor, lo: float = 1e-4, hi: float = 5.0) -> torch.Tensor:
+    """a3: sigma = Hardtanh(Softplus(pre), lo, hi) (posterior.py:23-27) in one launch, in `pre`'s dtype (fp32 / bf16;
+    computed in fp32)."""
+    L.require_gpu(pre)
+    return _SigmaHead.apply(pre, float(lo), float(hi))
+
+
 def reparam_logq_rng(mu, sigma, mask, samples: int):
     """reparam_logq with eps ~ N(0, 1) drawn inside the kernels (no randn launch, no eps tensor)."""
     L.require_gpu(mu, sigma, mask)

@@ -1523,3 +1523,22 @@ def test_fused_adam_shadow_follows_load_state_dict(M):
     st["exp_avg"][0].add_(1.0)
     opt.load_state_dict(st)                                                # also refreshes
     assert all(torch.equal(p._mivae_lp, p.detach().to(torch.bfloat16)) for p in net.parameters())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_sigma_head_vs_oracle(M, dtype):
+    """a3: Hardtanh(Softplus(pre), 1e-4, 5) and its gradient in one launch each, against the oracle (values through the
+    clamp at both ends and past softplus' linear threshold)."""
+    gen = torch.Generator().manual_seed(5)
+    pre = torch.cat([torch.randn(4000, generator=gen) * 3, torch.tensor([-30.0, -12.0, 4.99, 5.0, 5.2, 19.9, 20.1, 35.0])])
+    pre = pre.to(dtype).float()                       # representable inputs for both dtypes
+    cot = torch.randn(pre.numel(), generator=gen).to(dtype).float()
+    pr = pre.clone().requires_grad_(True)
+    ref = O.sigma_head(pr)
+    (ref * cot).sum().backward()
+    pg = pre.to(DEV).to(dtype).requires_grad_(True)
+    got = M.ops.sigma_head(pg)
+    (got.float() * cot.to(DEV)).sum().backward()
+    tol = 1e-6 if dtype == torch.float32 else 4e-3
+    assert got.dtype == dtype
+    assert rel_err(got.float(), ref) < tol and rel_err(pg.grad.float(), pr.grad) < tol
