@@ -52,6 +52,12 @@ int mivae_tokens_mask(const int64_t* tokens, int64_t* mask, int64_t n, void* str
 int mivae_sigma_head_fwd(const void* pre, void* sigma, int64_t n, float lo, float hi, int dtype, void* stream);
 int mivae_sigma_head_bwd(const void* pre, const void* dsigma, void* dpre, int64_t n, float lo, float hi, int dtype,
                          void* stream);
+/* Entry of the transformer encoder / decoder in one launch: y = (x + pe[s]) * mask[b, s] for x (B, S, D) of the latent
+ * dtype, pe the fp32 sinusoid table (>= S rows of D), mask (B, S) int64 -- PositionalEncoding.forward
+ * (vae_lm/nn/transformer.py:199-202) followed by the mask multiply of the encoder / decoder.  backward = 1: y = x * mask
+ * (the input gradient; pe may be NULL). */
+int mivae_posenc_mask(const void* x, const float* pe, const int64_t* mask, void* y, int64_t B, int64_t S, int64_t D,
+                      int backward, int dtype, void* stream);
 /* Additive attention bias from the token mask, built once per encoder / decoder call instead of per layer: 0 where
  * the key may be attended, -inf at padded keys (and at k > q when causal).  out (B, 1, 1, S), or (B, 1, S, S) when
  * causal, f32 or bf16.  Replaces the mask.ne(0) / tril / masked_fill chain of MultiHeadAttention.forward,

@@ -24,6 +24,7 @@ SIGNATURES = {
     "mivae_tokens_mask": [P, P, I64, P],
     "mivae_sigma_head_fwd": [P, P, I64, F32, F32, I32, P],
     "mivae_sigma_head_bwd": [P, P, P, I64, F32, F32, I32, P],
+    "mivae_posenc_mask": [P, P, P, P, I64, I64, I64, I32, I32, P],
     "mivae_attn_bias": [P, P, I64, I64, I32, I32, P],
     "mivae_gather_last": [P, P, P, P, I64, I64, I64, I32, P],
     "mivae_reparam_logq_fwd": [P, P, P, P, P, P, I64, I64, I64, I64, I32, P],

@@ -899,6 +899,54 @@ extern "C" int mivae_sigma_head_bwd(const void* pre, const void* dsigma, void* d
   return MIVAE_OK;
 }
 
+// Entry of the transformer encoder / decoder: y = (x + pe[s]) * mask[b, s] (nn/transformer.py:199-202 then the mask
+// multiply of encoders/transformer.py / decoders), and its input gradient dx = dy * mask.  pe is the fp32 sinusoid
+// table (>= S rows of D); it is rounded to the latent dtype before the add, like `pe.to(x.dtype)` in the reference.
+template <typename T, bool BWD>
+__global__ void k_posenc_mask(const T* __restrict__ x, const float* __restrict__ pe, const int64_t* __restrict__ mask,
+                              T* __restrict__ y, int64_t rows, int S, int D) {
+  const int64_t total = rows * D;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / D;
+    const int d = (int)(i - row * D);
+    const float m = (float)mask[row];
+    float v[1];
+    RowIO<T, 1>::load(x + i, v);
+    if (!BWD) {
+      float p[1] = {pe[(row % S) * D + d]};
+      if (sizeof(T) == 2) p[0] = bf16_to_f32(f32_to_bf16(p[0]));
+      float t[1] = {v[0] + p[0]};
+      if (sizeof(T) == 2) t[0] = bf16_to_f32(f32_to_bf16(t[0]));   // the reference's add rounds before the multiply
+      v[0] = t[0] * m;
+    } else {
+      v[0] = v[0] * m;
+    }
+    RowIO<T, 1>::store(y + i, v);
+  }
+}
+
+// backward = 1: x is dy, y is dx, pe unused
+extern "C" int mivae_posenc_mask(const void* x, const float* pe, const int64_t* mask, void* y, int64_t B, int64_t S,
+                                 int64_t D, int backward, int dtype, void* stream) {
+  MIVAE_REQUIRE(B >= 0 && S >= 1 && D >= 1, "posenc_mask: bad shape");
+  if (B == 0) return MIVAE_OK;
+  MIVAE_REQUIRE(x && mask && y && (backward || pe), "posenc_mask: null pointer");
+  MIVAE_REQUIRE(dtype == MIVAE_F32 || dtype == MIVAE_BF16, "posenc_mask: bad dtype %d", dtype);
+  const int64_t rows = B * S, total = rows * D;
+  unsigned grid = (unsigned)((total + kBlock - 1) / kBlock);
+  if (grid > 16384) grid = 16384;
+  hipStream_t st = S_(stream);
+  if (dtype == MIVAE_F32) {
+    if (backward) k_posenc_mask<float, true><<<grid, kBlock, 0, st>>>((const float*)x, pe, mask, (float*)y, rows, (int)S, (int)D);
+    else k_posenc_mask<float, false><<<grid, kBlock, 0, st>>>((const float*)x, pe, mask, (float*)y, rows, (int)S, (int)D);
+  } else {
+    if (backward) k_posenc_mask<unsigned short, true><<<grid, kBlock, 0, st>>>((const unsigned short*)x, pe, mask, (unsigned short*)y, rows, (int)S, (int)D);
+    else k_posenc_mask<unsigned short, false><<<grid, kBlock, 0, st>>>((const unsigned short*)x, pe, mask, (unsigned short*)y, rows, (int)S, (int)D);
+  }
+  MIVAE_CHECK_LAUNCH("posenc_mask");
+  return MIVAE_OK;
+}
+
 extern "C" int mivae_gather_last(const void* out, const int64_t* mask, void* ctx, int64_t* last_idx,
                                  int64_t B, int64_t S, int64_t E, int dtype, void* stream) {
   MIVAE_REQUIRE(B >= 0 && S > 0 && E > 0, "gather_last: bad shape B=%ld S=%ld E=%ld", (long)B, (long)S, (long)E);

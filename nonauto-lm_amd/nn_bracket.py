@@ -429,6 +429,16 @@ class PositionalEncoding(torch.nn.Module):
     def forward(self, tokens):
         return self._dropout(tokens + self._pos_enc[:, :tokens.size(1)].to(tokens.dtype))
 
+    def add_and_mask(self, tokens, mask):
+        """forward(tokens) * mask[..., None]: one launch when the dropout is inactive and the input is a GPU fp32 / bf16
+        (B, S, D) tensor, else the two stock expressions."""
+        drop = self._dropout
+        if (tokens.is_cuda and tokens.dim() == 3 and tokens.dtype in (torch.float32, torch.bfloat16) and mask is not None
+                and mask.shape == tokens.shape[:2]
+                and (not isinstance(drop, torch.nn.Dropout) or drop.p == 0 or not self.training)):
+            return ops.posenc_mask(tokens, self._pos_enc.detach(), mask)
+        return self.forward(tokens) * mask.unsqueeze(-1).to(tokens.dtype)
+
 
 class _TransformerLayer(torch.nn.Module):
     def __init__(self, input_size, hidden_size, num_heads, dropout=0.0, causal=False):
@@ -525,8 +535,8 @@ class TransformerEncoder(Encoder):
         return self._dropout(x)
 
     def encoder(self, x, mask):
+        x = self._pos_enc.add_and_mask(x, mask)
         m = mask.unsqueeze(-1).to(x.dtype)
-        x = self._pos_enc(x) * m
         bias = self._layers[0].attention_bias(x, mask) if len(self._layers) else None
         for layer in self._layers:
             x = layer(x, mask, bias)
@@ -676,7 +686,7 @@ class TransformerDecoder(Decoder):
         return self._input_size * (2 if self._skip_z else 1)
 
     def decoder(self, z, mask):
-        z = self._pos_enc(self._dropout(z)) * mask.unsqueeze(-1).to(z.dtype)
+        z = self._pos_enc.add_and_mask(self._dropout(z), mask)
         bias = self._layers[0].attention_bias(z, mask) if len(self._layers) else None
         for layer in self._layers:
             z = layer(z, mask, bias)

@@ -101,6 +101,35 @@ def gather_last(output: torch.Tensor, mask: torch.Tensor) -> Tuple[torch.Tensor,
     return _GatherLast.apply(output, _mask_i64(mask))
 
 
+class _PosEncMask(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pe, mask):
+        B, S, D = x.shape
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        L.call("mivae_posenc_mask", L.ptr(x), L.ptr(pe), L.ptr(mask), L.ptr(y), B, S, D, 0, L.dtype_code(x.dtype), L.stream())
+        ctx.save_for_backward(mask)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        B, S, D = dy.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        L.call("mivae_posenc_mask", L.ptr(dy), None, L.ptr(mask), L.ptr(dx), B, S, D, 1, L.dtype_code(dy.dtype), L.stream())
+        return dx, None, None
+
+
+def posenc_mask(x: torch.Tensor, pe: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """(x + pe[:, :S]) * mask[..., None] in one launch (bracket entry of the transformer encoder / decoder); pe is the
+    fp32 (1, max_len, D) sinusoid table."""
+    L.require_gpu(x, pe, mask)
+    if pe.dtype != torch.float32 or not pe.is_contiguous() or pe.size(-1) != x.size(-1) or pe.size(-2) < x.size(1):
+        raise ValueError("posenc_mask: pe must be a contiguous fp32 (1, >= S, D) table")
+    return _PosEncMask.apply(x, pe, _mask_i64(mask))
+
+
 def attention_bias(mask: torch.Tensor, causal: bool, dtype: torch.dtype) -> torch.Tensor:
     """Additive attention bias of a (B, S) token mask: 0 / -inf, (B, 1, 1, S) or (B, 1, S, S) when causal (one launch;
     the bracket builds it once per encoder / decoder call and hands it to every layer)."""

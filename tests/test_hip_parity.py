@@ -1542,3 +1542,50 @@ def test_sigma_head_vs_oracle(M, dtype):
     tol = 1e-6 if dtype == torch.float32 else 4e-3
     assert got.dtype == dtype
     assert rel_err(got.float(), ref) < tol and rel_err(pg.grad.float(), pr.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_posenc_mask_matches_stock_expression(M, dtype):
+    """bracket entry (x + pe) * mask in one launch == the two stock expressions, bit for bit, and so is its gradient."""
+    B, S, D = 5, 37, 48
+    gen = torch.Generator().manual_seed(2)
+    pe = M.nn_bracket.PositionalEncoding(D).to(DEV)
+    x = torch.randn(B, S, D, generator=gen).to(DEV).to(dtype)
+    mask = (torch.arange(S)[None, :] < torch.randint(0, S + 1, (B,), generator=gen)[:, None]).long().to(DEV)
+    cot = torch.randn(B, S, D, generator=gen).to(DEV).to(dtype)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya = pe.add_and_mask(xa, mask)
+    yb = pe(xb) * mask.unsqueeze(-1).to(dtype)
+    assert torch.equal(ya, yb)
+    ya.backward(cot)
+    yb.backward(cot)
+    assert torch.equal(xa.grad, xb.grad)
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_attention_bias_matches_mask_chain(M, causal):
+    B, S = 6, 29
+    gen = torch.Generator().manual_seed(4)
+    mask = (torch.arange(S)[None, :] < torch.randint(1, S + 1, (B,), generator=gen)[:, None]).long().to(DEV)
+    keep = mask.ne(0)[:, None, None, :]
+    if causal:
+        keep = keep & torch.ones(S, S, dtype=torch.bool, device=DEV).tril()[None, None]
+    for dtype in (torch.float32, torch.bfloat16):
+        ref = torch.zeros(keep.shape, dtype=dtype, device=DEV).masked_fill(~keep, float("-inf"))
+        got = M.ops.attention_bias(mask, causal, dtype)
+        assert got.shape == ref.shape and torch.equal(got, ref)
+    # and the attention module gives the same output with the shared bias as with the per-layer mask chain
+    torch.manual_seed(0)
+    attn = M.nn_bracket.MultiHeadAttention(4, 32, dropout=0.0, mask_tril=causal).to(DEV)
+    x = torch.randn(B, S, 32, device=DEV)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        a = attn(x, x, x, mask)
+        b = attn(x, x, x, mask, M.ops.attention_bias(mask, causal, torch.bfloat16))
+        M.nn_bracket.USE_FUSED_ATTENTION = False
+        try:
+            c = attn(x, x, x, mask)
+        finally:
+            M.nn_bracket.USE_FUSED_ATTENTION = True
+    assert torch.equal(a, b)
+    valid = mask.bool()
+    assert rel_err(a.float()[valid], c.float()[valid]) < 2e-2
