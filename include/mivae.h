@@ -397,6 +397,12 @@ int mivae_layernorm_bwd_sink(const void* dy, const void* x, const float* gamma, 
 int64_t mivae_layernorm_bwd_partial(const void* dy, const void* x, const float* gamma, const float* mean,
                                     const float* rstd, void* dx, float* workspace, int64_t rows, int64_t D,
                                     int in_dtype, int out_dtype, void* stream);
+/* mivae_layernorm_bwd_partial with the residual branch of a pre-norm sublayer folded in: dx = add + LN input gradient
+ * (`add` (rows, D) in x's dtype) -- the x-gradient of y = x + f(LayerNorm(x)), SublayerConnection.forward
+ * (vae_lm/nn/transformer.py:160-162), in one store instead of a separate add launch. */
+int64_t mivae_layernorm_bwd_partial_add(const void* dy, const void* x, const float* gamma, const float* mean,
+                                        const float* rstd, const void* add, void* dx, float* workspace, int64_t rows,
+                                        int64_t D, int in_dtype, int out_dtype, void* stream);
 
 /* ---- step-harness tail on flat buffers ---------------------------------------------------------- */
 /* Gradient clipping + Adam + zero_grad of DefaultTrainer._train_batch (training/trainers/trainer.py:286-289

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(kBlock) void k_ln_bwd(const TO* __restrict__ dy, co
                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
                                                     const float* __restrict__ rstd, TI* __restrict__ dx,
                                                     float* __restrict__ partial, int64_t rows, int rows_per_block,
-                                                    int D, int L) {
+                                                    int D, int L, const TI* __restrict__ add) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // [rif][2][L * VEC * kMaxChunks]
   const int rif = kBlock / L;
   const int rg = threadIdx.x / L, lig = threadIdx.x % L;
@@ -120,6 +120,16 @@ __global__ __launch_bounds__(kBlock) void k_ln_bwd(const TO* __restrict__ dy, co
           float o[VEC];
 #pragma unroll
           for (int i = 0; i < VEC; ++i) o[i] = rs * (a[j][i] - c1 - xh[j][i] * c2);
+          if (add) {   // residual branch of a pre-norm sublayer: d x = d(residual) + LN backward, one store
+            float r[VEC];
+            RowIO<TI, VEC>::load(add + row * D + c, r);
+            if (sizeof(TI) == 2) {   // the stock path rounds the LN gradient to bf16 before the add
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) o[i] = bf16_to_f32(f32_to_bf16(o[i]));
+            }
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) o[i] += r[i];
+          }
           RowIO<TI, VEC>::store(dx + row * D + c, o);
         }
       }
@@ -190,14 +200,14 @@ void launch_fwd(int vec, const void* x, const float* g, const float* b, void* y,
 }
 template <typename TI, typename TO>
 void launch_bwd(const LnCfg& c, const void* dy, const void* x, const float* g, const float* mean, const float* rstd,
-                void* dx, float* partial, int64_t rows, int D, hipStream_t st) {
+                void* dx, float* partial, int64_t rows, int D, hipStream_t st, const void* add) {
   const size_t smem = (size_t)(kBlock / c.L) * 2 * c.L * c.vec * kMaxChunks * sizeof(float);
   if (c.vec == 4)
     k_ln_bwd<TI, TO, 4><<<c.nblk, kBlock, smem, st>>>((const TO*)dy, (const TI*)x, g, mean, rstd, (TI*)dx, partial,
-                                                      rows, c.rows_per_block, D, c.L);
+                                                      rows, c.rows_per_block, D, c.L, (const TI*)add);
   else
     k_ln_bwd<TI, TO, 1><<<c.nblk, kBlock, smem, st>>>((const TO*)dy, (const TI*)x, g, mean, rstd, (TI*)dx, partial,
-                                                      rows, c.rows_per_block, D, c.L);
+                                                      rows, c.rows_per_block, D, c.L, (const TI*)add);
 }
 
 }  // namespace
@@ -234,20 +244,20 @@ extern "C" int mivae_layernorm_fwd(const void* x, const float* gamma, const floa
 static int layernorm_bwd_impl(const void* dy, const void* x, const float* gamma, const float* mean,
                               const float* rstd, void* dx, float* dgamma_dbeta, float* dbeta_sink, float* workspace,
                               int64_t rows, int64_t D, int in_dtype, int out_dtype, void* stream,
-                              int* nblk_out = nullptr) {
+                              int* nblk_out = nullptr, const void* add = nullptr) {
   MIVAE_REQUIRE(rows >= 1 && D >= 1, "layernorm_bwd: bad shape");
   MIVAE_REQUIRE((in_dtype == MIVAE_F32 || in_dtype == MIVAE_BF16) && (out_dtype == MIVAE_F32 || out_dtype == MIVAE_BF16),
                 "layernorm_bwd: dtype must be 0 (f32) or 1 (bf16)");
   MIVAE_REQUIRE(dy && x && gamma && mean && rstd && dx && (dgamma_dbeta || nblk_out) && workspace,
                 "layernorm_bwd: null pointer");
   LnCfg c;
-  MIVAE_REQUIRE(ln_cfg(rows, D, D % 4 == 0 && aligned16(x) && aligned16(dy) && aligned16(dx), c),
+  MIVAE_REQUIRE(ln_cfg(rows, D, D % 4 == 0 && aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(add), c),
                 "layernorm_bwd: D = %lld too wide for this kernel", (long long)D);
   hipStream_t st = S_(stream);
-  if (in_dtype == MIVAE_F32 && out_dtype == MIVAE_F32) launch_bwd<float, float>(c, dy, x, gamma, mean, rstd, dx, workspace, rows, (int)D, st);
-  else if (in_dtype == MIVAE_F32) launch_bwd<float, unsigned short>(c, dy, x, gamma, mean, rstd, dx, workspace, rows, (int)D, st);
-  else if (out_dtype == MIVAE_F32) launch_bwd<unsigned short, float>(c, dy, x, gamma, mean, rstd, dx, workspace, rows, (int)D, st);
-  else launch_bwd<unsigned short, unsigned short>(c, dy, x, gamma, mean, rstd, dx, workspace, rows, (int)D, st);
+  if (in_dtype == MIVAE_F32 && out_dtype == MIVAE_F32) launch_bwd<float, float>(c, dy, x, gamma, mean, rstd, dx, workspace, rows, (int)D, st, add);
+  else if (in_dtype == MIVAE_F32) launch_bwd<float, unsigned short>(c, dy, x, gamma, mean, rstd, dx, workspace, rows, (int)D, st, add);
+  else if (out_dtype == MIVAE_F32) launch_bwd<unsigned short, float>(c, dy, x, gamma, mean, rstd, dx, workspace, rows, (int)D, st, add);
+  else launch_bwd<unsigned short, unsigned short>(c, dy, x, gamma, mean, rstd, dx, workspace, rows, (int)D, st, add);
   MIVAE_CHECK_LAUNCH("layernorm_bwd");
   if (nblk_out) { *nblk_out = c.nblk; return MIVAE_OK; }    // partials only: the caller folds them
   const int total = 2 * (int)D;
@@ -281,5 +291,17 @@ extern "C" int64_t mivae_layernorm_bwd_partial(const void* dy, const void* x, co
   int nblk = 0;
   const int rc = layernorm_bwd_impl(dy, x, gamma, mean, rstd, dx, nullptr, nullptr, workspace, rows, D, in_dtype,
                                     out_dtype, stream, &nblk);
+  return rc == MIVAE_OK ? (int64_t)nblk : (int64_t)rc;
+}
+
+// mivae_layernorm_bwd_partial with the residual branch folded in: dx = add + (LayerNorm input gradient), `add` (rows, D)
+// in x's dtype -- the gradient of y = x + f(LN(x)) with respect to x in one store (pre-norm sublayers).
+extern "C" int64_t mivae_layernorm_bwd_partial_add(const void* dy, const void* x, const float* gamma, const float* mean,
+                                                   const float* rstd, const void* add, void* dx, float* workspace,
+                                                   int64_t rows, int64_t D, int in_dtype, int out_dtype, void* stream) {
+  if (!add) { mivae_set_error("layernorm_bwd_partial_add: null residual gradient"); return MIVAE_EINVAL; }
+  int nblk = 0;
+  const int rc = layernorm_bwd_impl(dy, x, gamma, mean, rstd, dx, nullptr, nullptr, workspace, rows, D, in_dtype,
+                                    out_dtype, stream, &nblk, add);
   return rc == MIVAE_OK ? (int64_t)nblk : (int64_t)rc;
 }

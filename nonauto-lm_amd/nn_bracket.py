@@ -211,8 +211,8 @@ class _FfnBlockFn(torch.autograd.Function):
             else:                                                          # wide layer: library products
                 grads[name] = (gout.t().matmul(xin).to(w.dtype), ops.colsum(gout).to(b.dtype))
         dxn = ops.linear_dgrad(dh, w1l)
-        dx, gg, gb_ = ops.layer_norm_bwd(dxn, x2, gamma, stats, (g, be))
-        dx = (dx + dy2.to(dx.dtype)).view(ctx.xshape)
+        dx, gg, gb_ = ops.layer_norm_bwd(dxn, x2, gamma, stats, (g, be), add=dy2)    # + the residual branch, same store
+        dx = dx.view(ctx.xshape)
         return dx, gg, gb_, grads["1"][0], grads["1"][1], grads["2"][0], grads["2"][1], None
 
 
@@ -389,14 +389,20 @@ class LayerNorm(torch.nn.LayerNorm):
     GPU fp32/bf16 tensor; under bf16 autocast the output is written as bf16 directly (the next op is always a
     projection), otherwise in the input's dtype.  Anything else falls through to the stock op."""
 
-    def forward(self, x):
+    def kernel_dtype(self, x):
+        """output dtype of the libmivae route for `x`, or None when the stock op has to run"""
         D = x.size(-1)
         if (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and self.elementwise_affine
                 and self.bias is not None and len(self.normalized_shape) == 1 and D % 4 == 0
                 and D <= ops.LAYERNORM_MAX_D and self.weight.dtype == torch.float32 and x.numel() > 0):
-            out_dtype = x.dtype
             if torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
-                out_dtype = torch.bfloat16
+                return torch.bfloat16
+            return x.dtype
+        return None
+
+    def forward(self, x):
+        out_dtype = self.kernel_dtype(x)
+        if out_dtype is not None:
             return ops.layer_norm(x, self.weight, self.bias, self.eps, out_dtype)
         return super().forward(x)
 
@@ -410,7 +416,14 @@ class SublayerConnection(torch.nn.Module):
         self._dropout = _maybe_dropout(dropout)
 
     def forward(self, x, sublayer):
-        return x + self._dropout(sublayer(self._norm(x)))
+        norm = self._norm
+        if isinstance(norm, LayerNorm) and torch.is_grad_enabled() and x.requires_grad:
+            out_dtype = norm.kernel_dtype(x)
+            if out_dtype is not None:
+                # training: the residual branch's gradient is folded into the LayerNorm backward kernel (no add launch)
+                res, xn = ops.layer_norm_residual(x, norm.weight, norm.bias, norm.eps, out_dtype)
+                return res + self._dropout(sublayer(xn))
+        return x + self._dropout(sublayer(norm(x)))
 
 
 class PositionalEncoding(torch.nn.Module):

@@ -618,9 +618,54 @@ class _LayerNorm(torch.autograd.Function):
         return dx.view(ctx.shape), gw, gb, None, None
 
 
-def layer_norm_bwd(dy2, x2, weight, stats, params):
+class _LayerNormResidual(torch.autograd.Function):
+    """(x, LayerNorm(x)) for a pre-norm residual sublayer y = x + f(LN(x)): the backward receives the residual branch's
+    gradient together with the norm's and writes their sum in the LayerNorm backward kernel's one store."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_dtype):
+        D = x.size(-1)
+        x2 = x.contiguous().view(-1, D)
+        rows = x2.size(0)
+        y = torch.empty(rows, D, dtype=out_dtype, device=x.device)
+        stats = torch.empty(2, rows, dtype=torch.float32, device=x.device)
+        L.call("mivae_layernorm_fwd", L.ptr(x2), L.ptr(weight), L.ptr(bias), L.ptr(y), L.ptr(stats[0]), L.ptr(stats[1]),
+               rows, D, float(eps), L.dtype_code(x2.dtype), L.dtype_code(out_dtype), L.stream())
+        ctx.save_for_backward(x2, weight, stats)
+        ctx.shape = x.shape
+        ctx.params = (weight, bias)
+        return x, y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dres, dy):
+        x2, weight, stats = ctx.saved_tensors
+        rows, D = x2.shape
+        if dy is None:
+            return dres, None, None, None, None
+        add = None if dres is None else dres.contiguous().view(rows, D)
+        dx, gw, gb = layer_norm_bwd(dy.contiguous().view(rows, D), x2, weight, stats, ctx.params, add=add)
+        return dx.view(ctx.shape), gw, gb, None, None
+
+
+def layer_norm_residual(x, weight, bias, eps: float, out_dtype):
+    L.require_gpu(x, weight, bias)
+    return _LayerNormResidual.apply(x, weight, bias, float(eps), out_dtype)
+
+
+def layer_norm_bwd(dy2, x2, weight, stats, params, add=None):
     """(dx, d gamma, d beta) of layer_norm for dy2, x2 (rows, D); with gradient sinks active the parameter gradients
-    go straight into params' .grad (deferred: folded by flush_grad_sinks) and None is returned for them."""
+    go straight into params' .grad (deferred: folded by flush_grad_sinks) and None is returned for them.
+    `add` (rows, D): gradient of a residual branch around the norm, included in dx (inside the kernel's store on the
+    deferred-sink route the training step takes, else by a separate add)."""
+    if add is not None:
+        if add.dtype != x2.dtype or not add.is_contiguous():
+            add = add.to(x2.dtype).contiguous()
+        dx, gw, gb = _layer_norm_bwd(dy2, x2, weight, stats, params, add)
+        return dx, gw, gb
+    return _layer_norm_bwd(dy2, x2, weight, stats, params, None)
+
+
+def _layer_norm_bwd(dy2, x2, weight, stats, params, add):
     rows, D = x2.shape
     dx = torch.empty_like(x2)
     ws = torch.empty(L.query("mivae_layernorm_workspace_floats", rows, D), dtype=torch.float32, device=x2.device)
@@ -631,9 +676,14 @@ def layer_norm_bwd(dy2, x2, weight, stats, params):
             wsp = _PART_BUFS.get(key)
             if wsp is None or wsp.device != x2.device:
                 wsp = _PART_BUFS[key] = torch.empty_like(ws)
-            nblk = L.query("mivae_layernorm_bwd_partial", L.ptr(dy2), L.ptr(x2), L.ptr(weight), L.ptr(stats[0]),
-                           L.ptr(stats[1]), L.ptr(dx), L.ptr(wsp), rows, D, L.dtype_code(x2.dtype),
-                           L.dtype_code(dy2.dtype), L.stream())
+            if add is not None:
+                nblk = L.query("mivae_layernorm_bwd_partial_add", L.ptr(dy2), L.ptr(x2), L.ptr(weight), L.ptr(stats[0]),
+                               L.ptr(stats[1]), L.ptr(add), L.ptr(dx), L.ptr(wsp), rows, D, L.dtype_code(x2.dtype),
+                               L.dtype_code(dy2.dtype), L.stream())
+            else:
+                nblk = L.query("mivae_layernorm_bwd_partial", L.ptr(dy2), L.ptr(x2), L.ptr(weight), L.ptr(stats[0]),
+                               L.ptr(stats[1]), L.ptr(dx), L.ptr(wsp), rows, D, L.dtype_code(x2.dtype),
+                               L.dtype_code(dy2.dtype), L.stream())
             if nblk <= 0:
                 raise RuntimeError(f"mivae_layernorm_bwd_partial failed ({nblk}): {L.lib().mivae_last_error().decode()}")
             _DEFER[key] = (wsp[:nblk * 2 * D].view(nblk, 2 * D), gw, gb, D)
@@ -643,11 +693,11 @@ def layer_norm_bwd(dy2, x2, weight, stats, params):
                L.ptr(dx), L.ptr(gw), L.ptr(gb), L.ptr(ws), rows, D, L.dtype_code(x2.dtype), L.dtype_code(dy2.dtype),
                L.stream())
         sink_arrived(gw, gb)
-        return dx, None, None
+        return (dx if add is None else dx + add), None, None
     dgb = torch.empty(2, D, dtype=torch.float32, device=x2.device)
     L.call("mivae_layernorm_bwd", L.ptr(dy2), L.ptr(x2), L.ptr(weight), L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(dx),
            L.ptr(dgb), L.ptr(ws), rows, D, L.dtype_code(x2.dtype), L.dtype_code(dy2.dtype), L.stream())
-    return dx, dgb[0], dgb[1]
+    return (dx if add is None else dx + add), dgb[0], dgb[1]
 
 
 FFN_DIMS = ((64, 128), (64, 256), (128, 128), (128, 256))
