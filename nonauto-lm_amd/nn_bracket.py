@@ -549,11 +549,12 @@ class TransformerEncoder(Encoder):
 
     def encoder(self, x, mask):
         x = self._pos_enc.add_and_mask(x, mask)
-        m = mask.unsqueeze(-1).to(x.dtype)
         bias = self._layers[0].attention_bias(x, mask) if len(self._layers) else None
         for layer in self._layers:
             x = layer(x, mask, bias)
-        return x * m
+        if x.is_cuda and x.dim() == 3 and x.dtype in (torch.float32, torch.bfloat16) and mask.shape == x.shape[:2]:
+            return ops.mask_mul(x, mask)
+        return x * mask.unsqueeze(-1).to(x.dtype)
 
 
 # ----------------------------------------------------------------------------------- recurrent bracket

@@ -130,6 +130,32 @@ def posenc_mask(x: torch.Tensor, pe: torch.Tensor, mask: torch.Tensor) -> torch.
     return _PosEncMask.apply(x, pe, _mask_i64(mask))
 
 
+class _MaskMul(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mask):
+        B, S, D = x.shape
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        L.call("mivae_posenc_mask", L.ptr(x), None, L.ptr(mask), L.ptr(y), B, S, D, 1, L.dtype_code(x.dtype), L.stream())
+        ctx.save_for_backward(mask)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        B, S, D = dy.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        L.call("mivae_posenc_mask", L.ptr(dy), None, L.ptr(mask), L.ptr(dx), B, S, D, 1, L.dtype_code(dy.dtype), L.stream())
+        return dx, None
+
+
+def mask_mul(x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """x * mask[..., None] for x (B, S, D) fp32 / bf16 and an integer (B, S) mask: one launch, no mask cast."""
+    L.require_gpu(x, mask)
+    return _MaskMul.apply(x, _mask_i64(mask))
+
+
 def attention_bias(mask: torch.Tensor, causal: bool, dtype: torch.dtype) -> torch.Tensor:
     """Additive attention bias of a (B, S) token mask: 0 / -inf, (B, 1, 1, S) or (B, 1, S, S) when causal (one launch;
     the bracket builds it once per encoder / decoder call and hands it to every layer)."""
@@ -1241,7 +1267,7 @@ class _LinearNLL(torch.autograd.Function):
         want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1] and want_db:
             # one dense product for both: d W = dl^T h and d b = dl^T 1 (a ones block appended to h)
-            h_aug = torch.cat([h2, torch.ones(h2.size(0), 8, dtype=h2.dtype, device=h2.device)], dim=1)
+            h_aug = torch.nn.functional.pad(h2, (0, 8), value=1.0)          # one launch (was ones + cat)
             n = h2.size(0)
             G = 8 if (n % 8 == 0 and n // 8 >= 1024) else (4 if (n % 4 == 0 and n // 4 >= 1024) else 1)
             dwa = None
