@@ -629,6 +629,63 @@ __global__ void __launch_bounds__(512) k_big_chain(BigArgs a) {
     hb = pair_to_b(l, hi2);
     l1(ring.item(1), bias_lds + 32, a1l, a1h);   // task 1: chunk 1 of net 0 (HC >= 2)
   }
+  // CHAIN: fold of net j (step k = K-1-j) -- x1 holds d loss / d x1_k; emit d s_k, d t_k and step back.  Tile by tile
+  // (no NF-sized fp32 temporaries: at h = 256 they would not fit next to acc and x1); masked tokens read the history as
+  // zeros (the forward does not write the history of all-padding blocks).  At h <= 128 the history rows were requested a
+  // group earlier (xpre); at h = 256 there is no register room for that and they are loaded here.
+  constexpr bool kPrefetchHist = MODE == M_CHAIN && HT <= 4;
+  u16x4 xpre[kPrefetchHist ? NF : 1];
+  int xpre_net = -1;
+  auto load_xpre = [&](int j) {
+    if constexpr (kPrefetchHist) {
+      const T* xh = a.x1_hist + ((int64_t)(a.K - 1 - j) * a.N + tok) * h;
+#pragma unroll
+      for (int v = 0; v < NF; ++v) {
+        const int ft = 16 * v + 4 * g;
+        const u16x4 z4 = {0, 0, 0, 0};
+        xpre[v] = z4;
+        if (on && ft < h) xpre[v] = *reinterpret_cast<const u16x4*>(xh + ft);
+      }
+    }
+  };
+  auto fold_chain = [&](int j) {
+    if constexpr (MODE == M_CHAIN) {
+      const float* b2 = bias_lds + (j & 3) * kBiasBlockFloats + HC * 32 + 4 * g;
+      const int k = a.K - 1 - j;
+      T* dS = a.dSdT + ((int64_t)(k * 2) * a.N + tok) * h;
+      T* dT = dS + a.N * (int64_t)h;
+      const T* xh = a.x1_hist + ((int64_t)k * a.N + tok) * h;
+      const bool have = kPrefetchHist && xpre_net == j;       // wave-uniform
+#pragma unroll
+      for (int v = 0; v < NF; ++v) {
+        const int ft = 16 * v + 4 * g;
+        float xp[4] = {0.f, 0.f, 0.f, 0.f};
+        if (have) {
+          if constexpr (kPrefetchHist) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xp[r] = bf16_to_f32(xpre[v][r]);
+          }
+        } else if (on && ft < h) {
+          RowIO<T, 4>::load(xh + ft, xp);
+        }
+        const f32x4 bt = lds4(b2 + 16 * v);
+        float ds[4], dt[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float g1 = x1[v][r] * m;
+          const float ge = g1 * fast_exp(acc[v][r] + bt[r]);
+          dt[r] = g1;
+          ds[r] = ge * xp[r] + dl;
+          x1[v][r] = ge;
+          acc[v][r] = 0.f;
+        }
+        if (valid && ft < h) {
+          RowIO<T, 4>::store(dS + ft, ds);
+          RowIO<T, 4>::store(dT + ft, dt);
+        }
+      }
+    }
+  };
   // The loop nest is written twice -- with and without the arithmetic -- so that the live path carries its register
   // tiles through straight-line loops without conditional merges.
   if (!live) {
@@ -638,7 +695,7 @@ __global__ void __launch_bounds__(512) k_big_chain(BigArgs a) {
       for (int c = 0; c < HC; ++c, ++i) {
         if (i % G == 0) {
           ring.enter_group(i / G);
-          while (nbias < j + kBiasSlots && nbias < NJ) issue_bias(nbias++);
+          while (nbias < j + kBiasSlots - (MODE == M_CHAIN ? 1 : 0) && nbias < NJ) issue_bias(nbias++);
         }
       }
   } else {
@@ -649,8 +706,19 @@ __global__ void __launch_bounds__(512) k_big_chain(BigArgs a) {
       for (int c = 0; c < HC; ++c, ++i) {
         if (i % G == 0) {
           ring.enter_group(i / G);
-          // nets below j are folded by every wave: their bias slots are free
-          while (nbias < j + kBiasSlots && nbias < NJ) issue_bias(nbias++);
+          // nets below j are folded by every wave: their bias slots are free (CHAIN folds net j-1 just below)
+          while (nbias < j + kBiasSlots - (MODE == M_CHAIN ? 1 : 0) && nbias < NJ) issue_bias(nbias++);
+          if constexpr (MODE == M_CHAIN && HT <= 4) {
+            // x1 history of this net's step: requested one group ahead of the fold that consumes it
+            if (c > 0 && xpre_net != j) { load_xpre(j); xpre_net = j; }
+          }
+        }
+        // A group boundary waits for every outstanding vector memory operation of the wave (vmcnt(0)), so stores are
+        // issued right AFTER one, not before: CHAIN folds net j-1 (d s / d t stores) here and they have the whole group
+        // to complete.  (The same move for the forward's x1-history store costs registers in the task loop and measured
+        // slower: C3 237 -> 249 us, C5 1.36 -> 1.61 ms; it stays in the fold.)
+        if constexpr (MODE == M_CHAIN) {
+          if (c == 0 && j > 0) fold_chain(j - 1);
         }
         const char* it2 = ring.item(2 + 2 * i);
         const char* it1 = ring.item(3 + 2 * i);
@@ -693,8 +761,8 @@ __global__ void __launch_bounds__(512) k_big_chain(BigArgs a) {
         }
         a1l = a2l; a1h = a2h;
       }
-      // ---- fold the finished net into the chain
-      {
+      // ---- fold the finished net into the chain (CHAIN: deferred to the start of the next net, see above)
+      if constexpr (MODE != M_CHAIN) {
         const float* b2 = bias_lds + (j & 3) * kBiasBlockFloats + HC * 32 + 4 * g;
         const int nn = MODE == M_CHAIN ? 0 : (j & 1);
         const int k = MODE == M_FWD ? (j >> 1) : a.K - 1 - (MODE == M_CHAIN ? j : (j >> 1));
@@ -747,36 +815,10 @@ __global__ void __launch_bounds__(512) k_big_chain(BigArgs a) {
               }
             }
           }
-        } else {           // CHAIN: x1 holds d loss / d x1_k; emit d s_k, d t_k and step back
-          T* dS = a.dSdT + ((int64_t)(k * 2) * a.N + tok) * h;
-          T* dT = dS + a.N * (int64_t)h;
-          // tile by tile (no NF-sized temporaries: at h = 256 they would not fit next to acc and x1);
-          // masked tokens read as zeros (the forward does not write the history of all-padding blocks)
-          const T* xh = a.x1_hist + ((int64_t)k * a.N + tok) * h;
-#pragma unroll
-          for (int v = 0; v < NF; ++v) {
-            const int ft = 16 * v + 4 * g;
-            float xp[4] = {0.f, 0.f, 0.f, 0.f};
-            if (on && ft < h) RowIO<T, 4>::load(xh + ft, xp);
-            const f32x4 bt = lds4(b2 + 16 * v);
-            float ds[4], dt[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float g1 = x1[v][r] * m;
-              const float ge = g1 * fast_exp(acc[v][r] + bt[r]);
-              dt[r] = g1;
-              ds[r] = ge * xp[r] + dl;
-              x1[v][r] = ge;
-              acc[v][r] = 0.f;
-            }
-            if (valid && ft < h) {
-              RowIO<T, 4>::store(dS + ft, ds);
-              RowIO<T, 4>::store(dT + ft, dt);
-            }
-          }
         }
       }
     }
+    if constexpr (MODE == M_CHAIN) fold_chain(NJ - 1);
   }
 
   // ---- outputs ---------------------------------------------------------------------------------------------
