@@ -217,7 +217,7 @@ int mivae_colsum_sink(const void* x, float* out0, float* out1, int64_t split, fl
 /* Weight gradient of torch.nn.Embedding (the Embedder in front of VAELmModel.encode, models/base/model.py:213-222):
  * dW (V, E) fp32 (+)= sum over tokens with ids[t] == v of dy[t] (dy (N, E) fp32, ids (N) int64), rows of padding_idx
  * (< 0: none) skipped.  Deterministic (token order, no atomics, no sort).  accumulate != 0: add into dW (gradient sink),
- * else dW is fully written.  E <= 128, else MIVAE_EUNSUPPORTED (-3). */
+ * else dW is fully written.  E <= 512, else MIVAE_EUNSUPPORTED (-3). */
 int mivae_embedding_bwd(const float* dy, const int64_t* ids, float* dW, int64_t N, int64_t V, int64_t E,
                         int64_t padding_idx, int accumulate, void* stream);
 

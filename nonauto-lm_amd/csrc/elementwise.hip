@@ -614,16 +614,19 @@ __global__ void __launch_bounds__(256) k_colsum_short_multi(const ColJob* __rest
 // the same id array: it stays in L2), keep the matching tokens in a wave-private LDS list IN TOKEN ORDER, and add
 // their dy rows into a wave-private LDS accumulator in that order; the 4 accumulators are combined in wave order.
 // The library path sorts the 16 k ids first (radix sort + merges + segmented sums: ~80 us at the bench shape).
-constexpr int kEmbRows = 32, kEmbCap = 2048;
+constexpr int kEmbCap = 2048;
 struct EmbArgs { const float* dy; const int64_t* ids; float* dW; int64_t N; int V, E, pad, accumulate; };
+// ROWS vocabulary ids per block (32 for E <= 128, 16 for E <= 256, 8 for E <= 512: the accumulators fill the LDS);
+// HC = 64-column chunks per row.
+template <int ROWS, int HC>
 __global__ void __launch_bounds__(256) k_embed_bwd(EmbArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int E = a.E;
-  float* acc = smem + wave * kEmbRows * E;                                       // [kEmbRows][E]
-  int* list = reinterpret_cast<int*>(smem + 4 * kEmbRows * E) + wave * kEmbCap;    // token * 32 + row
-  const int base = blockIdx.x * kEmbRows;
-  for (int i = lane; i < kEmbRows * E; i += 64) acc[i] = 0.f;
+  float* acc = smem + wave * ROWS * E;                                           // [ROWS][E]
+  int* list = reinterpret_cast<int*>(smem + 4 * ROWS * E) + wave * kEmbCap;      // token * ROWS + row
+  const int base = blockIdx.x * ROWS;
+  for (int i = lane; i < ROWS * E; i += 64) acc[i] = 0.f;
   for (int64_t p0 = 0; p0 < a.N; p0 += 4 * kEmbCap) {
     const int64_t lo = p0 + (int64_t)wave * kEmbCap;
     int64_t hi = lo + kEmbCap;
@@ -639,9 +642,9 @@ __global__ void __launch_bounds__(256) k_embed_bwd(EmbArgs a) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int64_t tok = t0 + 64 * u + lane;
-        const bool match = id[u] >= base && id[u] < base + kEmbRows && id[u] != a.pad && id[u] < a.V;
+        const bool match = id[u] >= base && id[u] < base + ROWS && id[u] != a.pad && id[u] < a.V;
         const unsigned long long bal = __ballot(match);
-        if (match) list[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = (int)(tok * kEmbRows + (id[u] - base));
+        if (match) list[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = (int)(tok * ROWS + (id[u] - base));
         cnt += __popcll(bal);
       }
     }
@@ -649,23 +652,23 @@ __global__ void __launch_bounds__(256) k_embed_bwd(EmbArgs a) {
     __builtin_amdgcn_wave_barrier();
     for (int j = 0; j < cnt; j += 4) {                                           // 4 rows in flight, added in order
       int e[4];
-      float v[4][2];
+      float v[4][HC];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         e[u] = j + u < cnt ? list[j + u] : -1;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < HC; ++h) {
           const int c = lane + 64 * h;
-          v[u][h] = (e[u] >= 0 && c < E) ? a.dy[(int64_t)(e[u] / kEmbRows) * E + c] : 0.f;
+          v[u][h] = (e[u] >= 0 && c < E) ? a.dy[(int64_t)(e[u] / ROWS) * E + c] : 0.f;
         }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
         if (e[u] >= 0) {
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
+          for (int h = 0; h < HC; ++h) {
             const int c = lane + 64 * h;
-            if (c < E) acc[(e[u] % kEmbRows) * E + c] += v[u][h];
+            if (c < E) acc[(e[u] % ROWS) * E + c] += v[u][h];
           }
         }
     }
@@ -673,7 +676,7 @@ __global__ void __launch_bounds__(256) k_embed_bwd(EmbArgs a) {
     __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
-  const int RE = kEmbRows * E;
+  const int RE = ROWS * E;
   for (int i = threadIdx.x; i < RE; i += 256) {
     const int v = base + i / E;
     if (v >= a.V) continue;
@@ -1409,20 +1412,29 @@ extern "C" int mivae_colsum_sink_multi(const void* jobs, int64_t njobs, int64_t 
 
 // dW (V, E) fp32 (+)= scatter-add of dy (N, E) fp32 rows by ids (N) int64, rows of `padding_idx` (< 0: none) skipped:
 // the weight gradient of torch.nn.Embedding (Embedder of VAELmModel.encode, models/base/model.py:213-222), run-to-run
-// deterministic.  accumulate != 0 adds into dW (a gradient sink), else every row of dW is written.  E <= 128.
+// deterministic.  accumulate != 0 adds into dW (a gradient sink), else every row of dW is written.  E <= 512.
 extern "C" int mivae_embedding_bwd(const float* dy, const int64_t* ids, float* dW, int64_t N, int64_t V, int64_t E,
                                    int64_t padding_idx, int accumulate, void* stream) {
   MIVAE_REQUIRE(N >= 0 && N < (1ll << 26) && V >= 1 && V < (1ll << 31), "embedding_bwd: bad sizes");
-  if (E < 1 || E > 128) {
-    mivae_set_error("embedding_bwd: unsupported width E=%lld (1..128)", (long long)E);
+  if (E < 1 || E > 512) {
+    mivae_set_error("embedding_bwd: unsupported width E=%lld (1..512)", (long long)E);
     return MIVAE_EUNSUPPORTED;
   }
   MIVAE_REQUIRE(dW && (N == 0 || (dy && ids)), "embedding_bwd: null pointer");
   EmbArgs a = {dy, ids, dW, N, (int)V, (int)E, (int)padding_idx, accumulate};
-  const size_t lds = (size_t)4 * kEmbRows * E * sizeof(float) + (size_t)4 * kEmbCap * sizeof(int);
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)k_embed_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  k_embed_bwd<<<(unsigned)((V + kEmbRows - 1) / kEmbRows), kBlock, lds, S_(stream)>>>(a);
+  const int rows = E <= 128 ? 32 : (E <= 256 ? 16 : 8);
+  const size_t lds = (size_t)4 * rows * E * sizeof(float) + (size_t)4 * kEmbCap * sizeof(int);
+  const unsigned grid = (unsigned)((V + rows - 1) / rows);
+#define EMB_LAUNCH(R, H)                                                                                            \
+  do {                                                                                                              \
+    if (lds > 64 * 1024)                                                                                            \
+      (void)hipFuncSetAttribute((const void*)k_embed_bwd<R, H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    k_embed_bwd<R, H><<<grid, kBlock, lds, S_(stream)>>>(a);                                                        \
+  } while (0)
+  if (E <= 128) EMB_LAUNCH(32, 2);
+  else if (E <= 256) EMB_LAUNCH(16, 4);
+  else EMB_LAUNCH(8, 8);
+#undef EMB_LAUNCH
   MIVAE_CHECK_LAUNCH("embedding_bwd");
   return MIVAE_OK;
 }

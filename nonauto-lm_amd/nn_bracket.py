@@ -68,6 +68,10 @@ class _SplitKLinearFn(torch.autograd.Function):
         if g2.dtype != x2.dtype:
             x2 = x2.to(g2.dtype)
         n = x2.size(0)
+        # gradient sinks (training step): fold the partials straight into the parameters' .grad -- no temporaries, no
+        # cast, no accumulate launch per parameter
+        sink = (ctx.has_bias and all(ctx.needs_input_grad[1:3]) and ops.grad_sink_ok(*ctx.params) and g2.is_cuda
+                and g2.dtype in (torch.float32, torch.bfloat16) and n >= 1024 and g2.size(1) <= 1024)
         if ctx.needs_input_grad[1]:
             G = 1                                   # 16 token slabs: flat optimum for 128..1024-wide layers (MI355X)
             while G < 16 and n % (2 * G) == 0 and n // (2 * G) >= 128:
@@ -78,6 +82,12 @@ class _SplitKLinearFn(torch.autograd.Function):
                     part = torch.bmm(ga, xa, out_dtype=torch.float32)
                 except (TypeError, RuntimeError):
                     part = torch.bmm(ga, xa)
+                if sink and part.dtype == torch.float32:
+                    w, b = ctx.params
+                    ops.colsum_into(part.view(G, -1), w.grad.view(-1))
+                    ops.colsum_into(g2, b.grad)
+                    ops.sink_arrived(w.grad, b.grad)
+                    return gx, None, None, None, None
                 if part.is_cuda and part.dtype in (torch.float32, torch.bfloat16):
                     gw = ops.colsum(part.view(G, -1)).view(part.shape[1:])      # fp32 G-way sum, fixed order
                 else:

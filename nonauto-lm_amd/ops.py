@@ -879,8 +879,8 @@ class _Embedding(torch.autograd.Function):
 
 def embedding(ids, weight, padding_idx=None):
     """torch.nn.functional.embedding whose weight gradient is the deterministic sort-free libmivae scatter-add
-    (fp32 weights of width <= 128 on the GPU); anything else goes to the stock op."""
-    if (weight.is_cuda and weight.dtype == torch.float32 and weight.size(1) <= 128 and ids.dtype == torch.int64
+    (fp32 weights of width <= 512 on the GPU); anything else goes to the stock op."""
+    if (weight.is_cuda and weight.dtype == torch.float32 and weight.size(1) <= 512 and ids.dtype == torch.int64
             and torch.is_grad_enabled() and weight.requires_grad and weight.is_contiguous()):
         return _Embedding.apply(ids, weight, padding_idx)
     return torch.nn.functional.embedding(ids, weight, padding_idx)
@@ -1019,6 +1019,19 @@ def colsum(x: torch.Tensor) -> torch.Tensor:
     ws = torch.empty(L.query("mivae_col_workspace_floats", rows, D, code), dtype=torch.float32, device=x.device)
     L.call("mivae_colsum", L.ptr(x), L.ptr(out), L.ptr(ws), rows, D, code, L.stream())
     return out
+
+
+def colsum_into(x: torch.Tensor, dst: torch.Tensor) -> None:
+    """dst (D,) fp32 += column sums of x (rows, D) fp32/bf16, fixed order: a gradient written straight into its
+    parameter's .grad (no temporary, no accumulate launch)."""
+    L.require_gpu(x, dst)
+    x = x.contiguous()
+    rows, D = x.shape
+    if dst.dtype != torch.float32 or not dst.is_contiguous() or dst.numel() != D:
+        raise ValueError("colsum_into: destination must be a contiguous fp32 tensor of D elements")
+    code = L.dtype_code(x.dtype)
+    ws = torch.empty(L.query("mivae_col_workspace_floats", rows, D, code), dtype=torch.float32, device=x.device)
+    L.call("mivae_colsum_sink", L.ptr(x), L.ptr(dst), L.ptr(dst), D, L.ptr(ws), rows, D, code, L.stream())
 
 
 # ----------------------------------------------------------------------------------- pairwise distances (InfoVAE MMD)

@@ -1137,7 +1137,8 @@ def test_ffn_block_fused_forward_vs_fp64_and_layerwise(M, D, H, xdt):
 
 
 @pytest.mark.parametrize("N,V,E,pad", [(16384, 8192, 64, 0), (20000, 1000, 32, 0), (5000, 77, 128, None),
-                                       (64, 40, 64, 3), (9000, 33, 64, 0)])
+                                       (64, 40, 64, 3), (9000, 33, 64, 0), (12000, 1000, 256, 0), (7000, 301, 512, 0),
+                                       (3000, 50, 192, None)])
 def test_embedding_weight_gradient_vs_fp64(M, N, V, E, pad):
     """mivae_embedding_bwd (sort-free deterministic scatter-add) vs an fp64 index_add: heavy id collisions, several
     8192-token passes, ragged vocabulary slab, padding row; and run-to-run bit reproducibility."""
@@ -1617,3 +1618,27 @@ def test_sublayer_connection_folded_residual_gradient(M, dtype):
     assert rel_err(xa.grad.float(), xb.grad.float()) < tol
     for a, b in zip(ga, gb):
         assert rel_err(a, b) < max(tol, 5e-5)
+
+
+def test_wide_linear_gradient_sinks_match_returned_gradients(M):
+    """Linear wider than the MFMA small-Linear kernels (features 256 / 512, many tokens): with gradient sinks the token-slab
+    partials are folded straight into .grad; same numbers as the returned-gradient route."""
+    torch.manual_seed(3)
+    lin = M.nn_bracket.Linear(256, 512).to(DEV)
+    x = torch.randn(8192, 256, device=DEV)
+    cot = torch.randn(8192, 512, device=DEV).bfloat16()
+    outs = []
+    for sink in (False, True):
+        for p in lin.parameters():
+            p.grad = torch.zeros_like(p) if sink else None
+        xg = x.clone().requires_grad_(True)
+        M.ops.GRAD_SINK = sink
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = lin(xg)
+            y.backward(cot)
+        finally:
+            M.ops.GRAD_SINK = False
+        outs.append([lin.weight.grad.clone(), lin.bias.grad.clone(), xg.grad.clone()])
+    for a, b in zip(*outs):
+        assert rel_err(a, b) < 1e-6
