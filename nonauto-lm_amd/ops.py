@@ -843,7 +843,9 @@ def flush_grad_sinks(lo: Optional[int] = None, hi: Optional[int] = None):
         dev = next(iter(jobs.values()))[0].device
         if torch.cuda.is_current_stream_capturing():      # no host-to-device copy inside a capture: fold one by one
             for part, g0, g1, split in jobs.values():
-                L.call("mivae_colsum_sink", L.ptr(part), L.ptr(g0), L.ptr(g1), split, None, part.size(0), part.size(1), 0,
+                ws = torch.empty(max(1, L.query("mivae_col_workspace_floats", part.size(0), part.size(1), 0)),
+                                 dtype=torch.float32, device=dev)
+                L.call("mivae_colsum_sink", L.ptr(part), L.ptr(g0), L.ptr(g1), split, L.ptr(ws), part.size(0), part.size(1), 0,
                        L.stream())
             return
         if len(_JOB_TABLES) > 16 and _PIN == 0:
