@@ -228,6 +228,12 @@ int mivae_embedding_bwd(const float* dy, const int64_t* ids, float* dW, int64_t 
 int mivae_colsum_sink_multi(const void* jobs, int64_t njobs, int64_t max_D, void* stream);
 
 /* ---- InfoVAE MMD: pairwise squared distances (a19 / f4) ------------------------------------------------- */
+/* dens (Bn, Bn) fp32: dens[i][j] = sum_{s,d} mask[i][s] * Normal(mu[j / n], sigma[j / n]).log_prob(z[i]) -- every latent
+ * code against every sentence's posterior, the pairwise term of Posterior.calc_mutual_info (nonauto posterior.py:174-222,
+ * auto posterior.py:158-200 with S = 1, mask NULL) without its (Bn, Bn, S, D) intermediate.  z (Bn, S, D), mu / sigma
+ * (Bn / n, S, D) in `dtype`; mask (Bn, S) int64 or NULL.  The caller takes logsumexp over j. */
+int mivae_pair_gauss_logdens(const void* z, const void* mu, const void* sigma, const int64_t* mask, float* out, int64_t Bn,
+                             int64_t n, int64_t S, int64_t D, int dtype, void* stream);
 /* out (B1, B2) fp32, out[i][j] = sum_f (a[i][f] - b[j][f])^2 for a (B1, F), b (B2, F): the pairwise term of
  * InfoVAEKLLoss._compute_rbf / _compute_inv_mult_quad (nn/kl_loss.py:124-149; the reference builds the (B, B, F)
  * difference tensor) before the kernel function, in the reference's own arithmetic (differences, not a Gram identity),

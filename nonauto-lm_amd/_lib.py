@@ -51,6 +51,7 @@ SIGNATURES = {
     "mivae_maf_sequential_bwd": [P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I32, I32, I32, P],
     "mivae_maf_sequential_bwd_supported": [I64, I64],
     "mivae_maf_sequential_bwd_blocks": [I64],
+    "mivae_pair_gauss_logdens": [P, P, P, P, P, I64, I64, I64, I64, I32, P],
     "mivae_pair_sqdist": [P, P, P, I64, I64, I64, I32, P],
     "mivae_pair_sqdist_bwd": [P, P, P, P, P, I64, I64, I64, I32, I32, P],
     "mivae_rowgemm": [P, P, P, I64, I64, I32, P],

@@ -65,7 +65,75 @@ __global__ __launch_bounds__(256) void k_pair_sqdist_bwd(const T* __restrict__ a
   *dst = accumulate ? *dst + scale * acc : scale * acc;
 }
 
+// dens[i][j] = sum over (s, d) of mask[i][s] * -0.5 * ((z[i] - mu[j / n])^2 / sigma[j / n]^2 + 2 log sigma[j / n] + log 2 pi):
+// the log-density of latent code i under the posterior of sentence j / n, every code against every sentence -- the
+// (B n, B n, S, D) tensor of Posterior.calc_mutual_info (posterior.py:174-222) reduced on the fly.  Same tiling as
+// k_pair_sqdist; 1 / sigma^2 and the per-feature constant are formed once per staged element.
+template <typename T>
+__global__ __launch_bounds__(256) void k_pair_gauss_logdens(const T* __restrict__ z, const T* __restrict__ mu,
+                                                            const T* __restrict__ sigma, const int64_t* __restrict__ mask,
+                                                            float* __restrict__ out, int Bn, int n, int S, int D) {
+  __shared__ float sz[kTile][kChunk + 1], sm[kTile][kChunk + 1], su[kTile][kChunk + 1], sw[kTile][kChunk + 1],
+      sc[kTile][kChunk + 1];
+  const int ti = threadIdx.x / kTile, tj = threadIdx.x % kTile;
+  const int i0 = blockIdx.y * kTile, j0 = blockIdx.x * kTile;
+  const int64_t F = (int64_t)S * D;
+  float acc = 0.f;
+  for (int64_t f0 = 0; f0 < F; f0 += kChunk) {
+    for (int e = threadIdx.x; e < kTile * kChunk; e += 256) {
+      const int r = e / kChunk, c = e % kChunk;
+      const int64_t f = f0 + c;
+      const bool fin = f < F;
+      const bool iok = fin && i0 + r < Bn, jok = fin && j0 + r < Bn;
+      sz[r][c] = iok ? ld1(z + (int64_t)(i0 + r) * F + f) : 0.f;
+      sm[r][c] = iok ? (mask ? (float)mask[(int64_t)(i0 + r) * S + f / D] : 1.f) : 0.f;
+      float u = 0.f, w = 0.f, k = 0.f;
+      if (jok) {
+        const int64_t row = (int64_t)((j0 + r) / n) * F + f;
+        const float sg = ld1(sigma + row);
+        u = ld1(mu + row);
+        w = 1.0f / (sg * sg);
+        k = 2.0f * logf(sg) + kLog2Pi;
+      }
+      su[r][c] = u; sw[r][c] = w; sc[r][c] = k;
+    }
+    __syncthreads();
+    float part = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < kChunk; ++c) {
+      const float d = sz[ti][c] - su[tj][c];
+      part += sm[ti][c] * (-0.5f * (d * d * sw[tj][c] + sc[tj][c]));
+    }
+    acc += part;
+    __syncthreads();
+  }
+  if (i0 + ti < Bn && j0 + tj < Bn) out[(int64_t)(i0 + ti) * Bn + j0 + tj] = acc;
+}
+
 }  // namespace
+
+// dens (Bn, Bn) fp32 for z (Bn, S, D), mu / sigma (Bn / n, S, D) in `dtype`, mask (Bn, S) int64 or NULL: the pairwise
+// Gaussian log-densities of Posterior.calc_mutual_info (nonauto posterior.py:174-222, auto posterior.py:158-200 with
+// S = 1 and no mask) without the (Bn, Bn, S, D) intermediate; the caller takes logsumexp over j.
+extern "C" int mivae_pair_gauss_logdens(const void* z, const void* mu, const void* sigma, const int64_t* mask, float* out,
+                                        int64_t Bn, int64_t n, int64_t S, int64_t D, int dtype, void* stream) {
+  MIVAE_REQUIRE(Bn >= 0 && Bn < (1 << 20) && n >= 1 && S >= 1 && D >= 1 && S * D < (1ll << 31) && Bn % n == 0,
+                "pair_gauss_logdens: bad sizes");
+  MIVAE_REQUIRE(dtype == MIVAE_F32 || dtype == MIVAE_BF16, "pair_gauss_logdens: dtype must be f32 or bf16");
+  if (Bn == 0) return MIVAE_OK;
+  MIVAE_REQUIRE(z && mu && sigma && out, "pair_gauss_logdens: null pointer");
+  dim3 grid((unsigned)((Bn + kTile - 1) / kTile), (unsigned)((Bn + kTile - 1) / kTile));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MIVAE_F32)
+    k_pair_gauss_logdens<float><<<grid, 256, 0, st>>>((const float*)z, (const float*)mu, (const float*)sigma, mask, out,
+                                                      (int)Bn, (int)n, (int)S, (int)D);
+  else
+    k_pair_gauss_logdens<unsigned short><<<grid, 256, 0, st>>>((const unsigned short*)z, (const unsigned short*)mu,
+                                                               (const unsigned short*)sigma, mask, out, (int)Bn, (int)n,
+                                                               (int)S, (int)D);
+  MIVAE_CHECK_LAUNCH("pair_gauss_logdens");
+  return MIVAE_OK;
+}
 
 // out (B1, B2) fp32, out[i][j] = sum_f (a[i][f] - b[j][f])^2 for a (B1, F), b (B2, F) in `dtype`: the pairwise term of
 // InfoVAEKLLoss._compute_rbf / _compute_inv_mult_quad (nn/kl_loss.py:124-149) before the kernel function.

@@ -205,8 +205,13 @@ class Posterior(torch.nn.Module, Registrable):
         return z, rep_mask, log_prob
 
     def calc_mutual_info(self, z, log_prob, mask=None):
-        """I(x, z) estimator (posterior.py:174-222); O(B^2) library ops, not on the training path."""
+        """I(x, z) estimator (posterior.py:174-222).  On the GPU the (B n)^2 pairwise log-densities come from one tiled
+        kernel (ops.pair_gauss_logdens: no (B n, B n, S, D) intermediate, 1 GiB at C2); evaluation metric, no gradients."""
         n = self.samples
+        if z.is_cuda and not (torch.is_grad_enabled() and (z.requires_grad or self._mu.requires_grad)):
+            dens = ops.pair_gauss_logdens(z, self._mu, self._sigma, mask, n)
+            log_qz = torch.logsumexp(dens, dim=-1) - math.log(dens.size(1))
+            return (log_prob - log_qz).mean()
         mu = self._mu.repeat_interleave(n, 0).float()
         sigma = self._sigma.repeat_interleave(n, 0).float()
         dens = -0.5 * ((z.float().unsqueeze(1) - mu).pow(2) * sigma.pow(2).reciprocal()

@@ -1061,6 +1061,22 @@ class _PairSqDist(torch.autograd.Function):
         return (None if da is None else da.to(a.dtype)), (None if db is None else db.to(b.dtype))
 
 
+def pair_gauss_logdens(z, mu, sigma, mask, samples: int) -> torch.Tensor:
+    """(Bn, Bn) fp32 log-densities of every latent code z[i] under every sentence's posterior N(mu[j / n], sigma[j / n]),
+    masked by z[i]'s tokens: the pairwise term of calc_mutual_info (posterior.py:174-222) in one launch, no gradients."""
+    L.require_gpu(z, mu, sigma, mask)
+    Bn, S, D = _shape3(z)
+    dt = z.dtype if z.dtype in (torch.float32, torch.bfloat16) else torch.float32
+    zc, mc, sc = (t.detach().to(dt).contiguous() for t in (z, mu, sigma))
+    if mc.shape[0] * samples != Bn or mc.shape[1:] != zc.shape[1:] or sc.shape != mc.shape:
+        raise ValueError("pair_gauss_logdens: mu / sigma must be (Bn / samples, ...) like z")
+    mask = _mask_i64(mask)
+    out = torch.empty(Bn, Bn, dtype=torch.float32, device=z.device)
+    L.call("mivae_pair_gauss_logdens", L.ptr(zc), L.ptr(mc), L.ptr(sc), L.ptr(mask), L.ptr(out), Bn, int(samples), S, D,
+           L.dtype_code(dt), L.stream())
+    return out
+
+
 def pair_sqdist(a, b):
     """(B1, B2) fp32 squared distances between the rows of a (B1, F) and b (B2, F), fp32 or bf16 on the GPU, with
     gradients: the pairwise term of the InfoVAE MMD (nn/kl_loss.py:124-149) without the (B, B, F) tensor."""

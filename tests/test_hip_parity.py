@@ -1275,6 +1275,36 @@ def test_calc_mutual_info_golden(M, name):
     assert rel_err(latent.z, g["z"]) < TOL and rel_err(logq, g["logq"]) < TOL
     mi = post.calc_mutual_info(latent.z, logq, dev(g["mask"]).repeat_interleave(n, 0))
     assert rel_err(mi, g["mi"]) < 1e-5
+    calls = []
+    real = M.ops.pair_gauss_logdens
+    M.ops.pair_gauss_logdens = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        with torch.no_grad():               # the evaluation route: tiled pairwise kernel, no (Bn, Bn, S, D) tensor
+            mi_k = post.calc_mutual_info(latent.z.detach(), logq.detach(), dev(g["mask"]).repeat_interleave(n, 0))
+    finally:
+        M.ops.pair_gauss_logdens = real
+    assert calls and rel_err(mi_k, g["mi"]) < 1e-5
+
+
+@pytest.mark.parametrize("B,n,S,D,dtype,masked", [(37, 2, 19, 24, torch.float32, True), (64, 1, 64, 64, torch.float32, True),
+                                                  (50, 3, 1, 40, torch.float32, False), (33, 2, 21, 16, torch.bfloat16, True)])
+def test_pair_gauss_logdens_vs_oracle(M, B, n, S, D, dtype, masked):
+    """the pairwise log-density matrix of calc_mutual_info against the oracle's broadcast expression (fp64)."""
+    gen = torch.Generator().manual_seed(B + S)
+    mu = torch.randn(B, S, D, generator=gen).to(dtype)
+    sigma = (torch.rand(B, S, D, generator=gen) * 2 + 0.05).to(dtype)
+    z = torch.randn(B * n, S, D, generator=gen).to(dtype)
+    mask = (torch.arange(S)[None, :] < torch.randint(1, S + 1, (B * n,), generator=gen)[:, None]).long() if masked else None
+    mu_r, sg_r = mu.double().repeat_interleave(n, 0), sigma.double().repeat_interleave(n, 0)
+    dens = -0.5 * ((z.double().unsqueeze(1) - mu_r).pow(2) / sg_r.pow(2) + 2 * sg_r.log() + O.LOG_2PI)
+    if masked:
+        dens = dens * mask.double()[:, None, :, None]
+    ref = dens.reshape(B * n, B * n, -1).sum(-1)
+    zz, mm, ss = (t.to(DEV) for t in (z, mu, sigma))
+    if S == 1:                       # the auto model's 2-D latents
+        zz, mm, ss = zz[:, 0], mm[:, 0], ss[:, 0]
+    got = M.ops.pair_gauss_logdens(zz, mm, ss, None if mask is None else mask.to(DEV), n)
+    assert rel_err(got, ref) < 2e-6
 
 
 # ------------------------------------------------------------------------------------ whole model, bf16, C2 shape
