@@ -1459,7 +1459,7 @@ __global__ void __launch_bounds__(512) k_big_dw(DwBigArgs a) {
 // k_big_dw: a block = 8 waves x 16 hidden units of one (step, net), walking a slab of 32-token tiles; per tile the x0 and
 // d out tiles ([32][hp]) and the block's 128-unit slices of hid and d pre ([32][128]) are LDS-DMA staged (source-side
 // XOR swizzle) and every fragment is a transposing read: A = x0^T / d out^T feature tiles, B = hid^T / d pre^T of the wave's
-// 16 units.  Accumulators and dump layout are k_big_dw's, so k_big_dw_reduce serves both.
+// 2 x 16 units (a wave owns two unit groups and half of the feature tiles: every A fragment feeds two MFMAs).  Accumulators and dump layout are k_big_dw's, so k_big_dw_reduce serves both.
 struct Dw2Args {
   const T* z_in;        // (N, D)
   const T* dSdT;        // (K, 2, N, h)
@@ -1494,14 +1494,22 @@ __global__ void __launch_bounds__(512) k_big_dw2(Dw2Args a) {
   const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
   const int zb = jx % Z, grp = (jx / Z) * 8 + xcd;
   if (grp >= a.nslab * 2 * a.K) return;
-  const int slab = grp % a.nslab, kn = grp / a.nslab, hw = zb * 8 + wave;
+  // a wave owns TWO 16-unit groups (2 hp, 2 hp + 1 of the block's eight) and HALF of the feature tiles (fh): every
+  // A fragment it reads feeds two MFMAs, so the block reads each x0 / d out tile four times instead of eight
+  const int hp = wave & 3, fh = wave >> 2;
+  const int slab = grp % a.nslab, kn = grp / a.nslab, hw0 = zb * 8 + 2 * hp;
   const int h = a.h;
-  const bool wave_on = hw < a.HW;
-  const bool want_b2 = zb == 0 && wave == 0;
-  f32x4 dW1[NF], dW2[NF];
-  float db1 = 0.f, db2[NF];
+  const bool wave_on = hw0 < a.HW;                  // HW is even (Hp is a multiple of 32): the pair is on or off
+  const bool want_b1 = fh == 0;
+  const bool want_b2 = zb == 0 && hp == 0;
+  constexpr int NV = NF / 2;                        // feature tiles of this wave: v = fh NV + i
+  f32x4 dW1[NV][2], dW2[NV][2];
+  float db1[2] = {0.f, 0.f}, db2[NV];
 #pragma unroll
-  for (int v = 0; v < NF; ++v) { dW1[v] = f32x4{0.f, 0.f, 0.f, 0.f}; dW2[v] = dW1[v]; db2[v] = 0.f; }
+  for (int i = 0; i < NV; ++i) {
+    dW1[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; dW1[i][1] = dW1[i][0]; dW2[i][0] = dW1[i][0]; dW2[i][1] = dW1[i][0];
+    db2[i] = 0.f;
+  }
 
   const int64_t tile0 = (int64_t)slab * a.slab_tiles;
   int ntiles = (int)((a.N + 31) / 32 - tile0);
@@ -1563,10 +1571,11 @@ __global__ void __launch_bounds__(512) k_big_dw2(Dw2Args a) {
       if (hrow >= nrows) *reinterpret_cast<u16x8*>(smem + buf * STAGE + 2 * TILE + HTILE + threadIdx.x * 16) = zero;
     }
   };
-  int to0[8], to1[8], th0, th1;
+  int to0[8], to1[8], th0[2], th1[2];
 #pragma unroll
   for (int v = 0; v < 8; ++v) tr_offsets<HPB>(v, lane, to0[v], to1[v]);
-  tr_offsets<256>(wave, lane, th0, th1);
+  tr_offsets<256>(2 * hp, lane, th0[0], th1[0]);
+  tr_offsets<256>(2 * hp + 1, lane, th0[1], th1[1]);
 
   // tile t lives in stage t % NBUF; NBUF - 1 tiles are issued ahead.  Per tile: wait for its DMAs, one block barrier (the
   // tile is visible to every wave AND the stage tile n-1 used is free), refill that stage, compute.
@@ -1583,21 +1592,29 @@ __global__ void __launch_bounds__(512) k_big_dw2(Dw2Args a) {
     if (wave_on) {
       const char* bx = smem + bc * STAGE;
       const char* bg = bx + TILE;
-      const bf16x8 hb = tr_read(bx + 2 * TILE, th0, th1);
-      const bf16x8 gb = tr_read(bx + 2 * TILE + HTILE, th0, th1);
-      {
-        float sm = 0.f;
+      bf16x8 hb[2], gb[2];
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) sm += (float)gb[jj];
-        db1 += sm;
+      for (int u = 0; u < 2; ++u) {
+        hb[u] = tr_read(bx + 2 * TILE, th0[u], th1[u]);
+        gb[u] = tr_read(bx + 2 * TILE + HTILE, th0[u], th1[u]);
+      }
+      if (want_b1) {                             // wave-uniform
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          float sm = 0.f;
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) sm += (float)gb[u][jj];
+          db1[u] += sm;
+        }
       }
       // feature tiles in chunks of CV: the reads of chunk c+1 are issued before the MFMAs of chunk c
-      constexpr int CV = 4, NCH = NF / CV;
+      constexpr int CV = 4, NCH = NV / CV;
+      static_assert(NV % CV == 0, "feature tiles per wave must be a multiple of the chunk");
       bf16x8 fb[2][2 * CV];
       auto reads = [&](int c, int sl) {
 #pragma unroll
         for (int i = 0; i < CV; ++i) {
-          const int v = c * CV + i;
+          const int v = fh * NV + c * CV + i;
           fb[sl][i] = tr_read(bx + (v >> 3) * 256, to0[v & 7], to1[v & 7]);
           fb[sl][CV + i] = tr_read(bg + (v >> 3) * 256, to0[v & 7], to1[v & 7]);
         }
@@ -1610,15 +1627,18 @@ __global__ void __launch_bounds__(512) k_big_dw2(Dw2Args a) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < CV; ++i) {
-          const int v = c * CV + i;
-          dW1[v] = mma16(fb[c & 1][i], gb, dW1[v]);
-          const bf16x8 gf = fb[c & 1][CV + i];
-          dW2[v] = mma16(gf, hb, dW2[v]);
+          const int q = c * CV + i;
+          const bf16x8 xf = fb[c & 1][i], gf = fb[c & 1][CV + i];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            dW1[q][u] = mma16(xf, gb[u], dW1[q][u]);
+            dW2[q][u] = mma16(gf, hb[u], dW2[q][u]);
+          }
           if (want_b2) {                       // wave-uniform
             float sm = 0.f;
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) sm += (float)gf[jj];
-            db2[v] += sm;
+            db2[q] += sm;
           }
         }
       }
@@ -1627,20 +1647,27 @@ __global__ void __launch_bounds__(512) k_big_dw2(Dw2Args a) {
   }
   wait_vm<0>();                                // the refills issued past the slab's end land before the block exits
   if (!wave_on) return;
-  const int64_t item = ((int64_t)kn * a.HW + hw) * a.nslab + slab;
-  float* out = a.part + item * (2 * NF * 256) + lane * 4;
 #pragma unroll
-  for (int v = 0; v < NF; ++v) {
-    *reinterpret_cast<f32x4*>(out + v * 256) = dW1[v];
-    *reinterpret_cast<f32x4*>(out + (NF + v) * 256) = dW2[v];
+  for (int u = 0; u < 2; ++u) {
+    const int64_t item = ((int64_t)kn * a.HW + hw0 + u) * a.nslab + slab;
+    float* out = a.part + item * (2 * NF * 256) + lane * 4;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = fh * NV + i;
+      *reinterpret_cast<f32x4*>(out + v * 256) = dW1[i][u];
+      *reinterpret_cast<f32x4*>(out + (NF + v) * 256) = dW2[i][u];
+    }
+    if (want_b1) {
+      float s1 = db1[u] + __shfl_xor(db1[u], 16, 64);
+      s1 += __shfl_xor(s1, 32, 64);
+      if (g == 0) a.partb1[item * 16 + r16] = s1;
+    }
   }
-  db1 += __shfl_xor(db1, 16, 64);
-  db1 += __shfl_xor(db1, 32, 64);
-  if (g == 0) a.partb1[item * 16 + r16] = db1;
   if (want_b2) {
 #pragma unroll
-    for (int v = 0; v < NF; ++v) {
-      float s2 = db2[v] + __shfl_xor(db2[v], 16, 64);
+    for (int i = 0; i < NV; ++i) {
+      const int v = fh * NV + i;
+      float s2 = db2[i] + __shfl_xor(db2[i], 16, 64);
       s2 += __shfl_xor(s2, 32, 64);
       if (g == 0) a.partb2[((int64_t)kn * a.nslab + slab) * (16 * NF) + 16 * v + r16] = s2;
     }
