@@ -650,11 +650,12 @@ __global__ void __launch_bounds__(256) k_embed_bwd(EmbArgs a) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    for (int j = 0; j < cnt; j += 4) {                                           // 4 rows in flight, added in order
-      int e[4];
-      float v[4][HC];
+    constexpr int RIF = HC <= 2 ? 8 : 4;                                         // dy rows in flight, added in order
+    for (int j = 0; j < cnt; j += RIF) {
+      int e[RIF];
+      float v[RIF][HC];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < RIF; ++u) {
         e[u] = j + u < cnt ? list[j + u] : -1;
 #pragma unroll
         for (int h = 0; h < HC; ++h) {
@@ -663,7 +664,7 @@ __global__ void __launch_bounds__(256) k_embed_bwd(EmbArgs a) {
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < RIF; ++u)
         if (e[u] >= 0) {
 #pragma unroll
           for (int h = 0; h < HC; ++h) {
