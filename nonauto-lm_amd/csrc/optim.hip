@@ -71,10 +71,18 @@ __global__ __launch_bounds__(kBlock) void k_adam_clip(AdamArgs a) {
   float coef = 1.0f;
   if (a.max_norm > 0.f) coef = fminf(a.max_norm / (norm + 1e-6f), 1.0f);   // clip_grad_norm_
   if (a.gscale != 1.0f) coef *= a.gscale;
-  // bias corrections in double like the host arithmetic of torch.optim.Adam (1 - beta ** step)
-  const double t = (double)*a.step + 1.0;
-  const double bc1 = 1.0 - pow(a.b1, t), bc2 = 1.0 - pow(a.b2, t);
-  const float step_size = (float)(a.lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+  // bias corrections in double like the host arithmetic of torch.optim.Adam (1 - beta ** step): two double pow() and a
+  // double sqrt, computed by ONE thread per block and handed round through LDS (every thread used to run them, which
+  // cost more than the thread's share of the update)
+  __shared__ float bcs[2];
+  if (threadIdx.x == 0) {
+    const double t = (double)*a.step + 1.0;
+    const double bc1 = 1.0 - pow(a.b1, t), bc2 = 1.0 - pow(a.b2, t);
+    bcs[0] = (float)(a.lr / bc1);
+    bcs[1] = (float)sqrt(bc2);
+  }
+  __syncthreads();
+  const float step_size = bcs[0], bc2_sqrt = bcs[1];
   const float omb1 = (float)(1.0 - a.b1), b2f = (float)a.b2, omb2 = (float)(1.0 - a.b2);
   const bool vclip = a.max_value > 0.f;
   const int64_t stride = (int64_t)gridDim.x * kBlock * 4;
@@ -114,8 +122,8 @@ __global__ void k_scalar_add(float* x, float d) {
 
 extern "C" int64_t mivae_sumsq_blocks(int64_t n) {
   if (n <= 0) return 0;
-  int64_t b = (n + 16383) / 16384;        // >= 16k floats per block
-  return b > 256 ? 256 : b;
+  int64_t b = (n + 4095) / 4096;          // >= 4k floats per block: a 5 MB gradient already fills the chip
+  return b > 1024 ? 1024 : b;
 }
 
 extern "C" int mivae_sumsq_partial(const float* g, float* partial, int64_t n, void* stream) {
