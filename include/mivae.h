@@ -209,6 +209,10 @@ int mivae_colsum(const void* x, float* out, float* workspace, int64_t rows, int6
 int64_t mivae_colsum_static_max_floats(void);
 int mivae_colsum_static(const void* x, float* out, int64_t rows, int64_t D, int dtype, void* stream);
 
+/* First stage of mivae_colsum only: per-block partial column sums of x (rows, D) into workspace (count, D) fp32, count
+ * returned (> 0; negative = error).  Fold them with mivae_colsum_sink_multi, e.g. once per gradient bucket for all bias
+ * gradients of a step (the wide Linear layers of the bracket, nn/transformer.py:41-48, 129-130). */
+int64_t mivae_colsum_partial(const void* x, float* workspace, int64_t rows, int64_t D, int dtype, void* stream);
 /* As mivae_colsum, but ADDS columns [0, split) into out0 and [split, D) into out1: a finished [dW | db] row goes
  * straight into the parameters' gradient buffers (the accumulation autograd's AccumulateGrad would do with one
  * extra kernel per parameter). */

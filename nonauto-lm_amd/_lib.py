@@ -40,6 +40,7 @@ SIGNATURES = {
     "mivae_actnorm_bwd": [P, P, P, P, P, P, P, I64, I64, I64, I64, I32, P],
     "mivae_actnorm_stats": [P, P, P, P, I64, I64, I32, P],
     "mivae_colsum": [P, P, P, I64, I64, I32, P],
+    "mivae_colsum_partial": [P, P, I64, I64, I32, P],
     "mivae_colsum_sink": [P, P, P, I64, P, I64, I64, I32, P],
     "mivae_colsum_static_max_floats": [],
     "mivae_colsum_static": [P, P, I64, I64, I32, P],
@@ -117,6 +118,7 @@ SIGNATURES = {
 _RET = {
     "mivae_last_error": ctypes.c_char_p,
     "mivae_col_workspace_floats": I64,
+    "mivae_colsum_partial": I64,
     "mivae_colsum_static_max_floats": I64,
     "mivae_nice_pack_bytes": I64,
     "mivae_sumsq_blocks": I64,

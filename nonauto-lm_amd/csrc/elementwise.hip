@@ -1346,6 +1346,25 @@ extern "C" int mivae_colsum(const void* x, float* out, float* workspace, int64_t
   return colsum_impl(x, out, nullptr, 0, 0, workspace, rows, D, dtype, stream);
 }
 
+// First stage only: per-block partial sums of the columns of x (rows, D) into workspace (count, D) fp32, count
+// RETURNED (> 0; negative = error status); the caller folds them later (mivae_colsum_sink_multi, e.g. once per gradient
+// bucket for every bias gradient of a training step).  workspace: mivae_col_workspace_floats.
+extern "C" int64_t mivae_colsum_partial(const void* x, float* workspace, int64_t rows, int64_t D, int dtype, void* stream) {
+  if (!(rows >= 1 && D > 0 && D < (1ll << 31)) || !(dtype == MIVAE_F32 || dtype == MIVAE_BF16) || !x || !workspace) {
+    mivae_set_error("colsum_partial: bad arguments");
+    return MIVAE_EINVAL;
+  }
+  ColCfg c = col_cfg(rows, D, dtype, aligned16(x));
+  DISPATCH_COL(dtype, c.vec, 0, x, nullptr, nullptr, nullptr, nullptr, workspace, rows, c.rows_per_block,
+               c.nblk, 1, 1, (int)D, c.L, S_(stream));
+  hipError_t e_ = hipGetLastError();
+  if (e_ != hipSuccess) {
+    mivae_set_error("colsum_partial: launch failed: %s", hipGetErrorString(e_));
+    return MIVAE_ELAUNCH;
+  }
+  return c.nblk;
+}
+
 // ---- allocation-free variant of mivae_colsum ---------------------------------------------------------------------
 // For callers that cannot allocate (HIP-graph capture, serving loops): the split-row partial sums go to a file-scope
 // device array instead of a caller-supplied workspace.  Every GPU the library runs on holds its own copy of the array

@@ -76,6 +76,9 @@ class _SplitKLinearFn(torch.autograd.Function):
             G = 1                                   # 16 token slabs: flat optimum for 128..1024-wide layers (MI355X)
             while G < 16 and n % (2 * G) == 0 and n // (2 * G) >= 128:
                 G *= 2
+            if G > 1 and sink and g2.is_contiguous() and x2.is_contiguous() and \
+                    ops.wide_linear_wgrad_deferred(g2, x2, ctx.params[0].grad, ctx.params[1].grad, G):
+                return gx, None, None, None, None   # partials queued: folded with the bucket's other partials
             if G > 1:
                 ga, xa = g2.view(G, n // G, -1).transpose(1, 2), x2.view(G, n // G, -1)
                 try:                                # fp32 partials: the fold below is then exact fp32 accumulation

@@ -974,6 +974,45 @@ def linear_wgrad_group_deferred(x2, gs, sinks) -> bool:
     return True
 
 
+def wide_linear_wgrad_deferred(g2, x2, w_grad, b_grad, G: int) -> bool:
+    """Weight / bias gradient of a Linear too wide for the MFMA small-Linear kernels, in deferred-sink mode: the token-slab
+    partials of d W (one batched library GEMM into a persistent buffer) and the per-block partial column sums of d y are
+    queued, and flush_grad_sinks() folds them -- with every other queued partial of the bucket -- in one launch.
+    Returns False when the caller has to fold by itself (no deferred mode, layer used twice in the step, odd shapes)."""
+    n, Fo = g2.shape
+    Fi = x2.size(1)
+    if _DEFER is None or n % G or G > 512:
+        return False
+    code = L.dtype_code(g2.dtype)
+    kw, kb = (w_grad.data_ptr(), G, Fo * Fi), (b_grad.data_ptr(), n, -Fo)
+    if kw in _DEFER or kb in _DEFER:
+        return False
+    nws = L.query("mivae_col_workspace_floats", n, Fo, code)
+    if nws <= 0 or nws // Fo > 2 * 512:            # more row blocks than the fold kernel takes per job
+        return False
+    part = _PART_BUFS.get(kw)
+    if part is None or part.device != g2.device:
+        part = _PART_BUFS[kw] = torch.empty(G, Fo, Fi, dtype=torch.float32, device=g2.device)
+    wsb = _PART_BUFS.get(kb)
+    if wsb is None or wsb.device != g2.device:
+        wsb = _PART_BUFS[kb] = torch.empty(nws, dtype=torch.float32, device=g2.device)
+    ga, xa = g2.view(G, n // G, Fo).transpose(1, 2), x2.view(G, n // G, Fi)
+    try:
+        torch.bmm(ga, xa, out_dtype=torch.float32, out=part)
+    except (TypeError, RuntimeError):
+        part.copy_(torch.bmm(ga, xa, out_dtype=torch.float32))
+    nblk = L.query("mivae_colsum_partial", L.ptr(g2), L.ptr(wsb), n, Fo, code, L.stream())
+    if nblk <= 0:
+        raise RuntimeError(f"mivae_colsum_partial failed ({nblk}): {L.lib().mivae_last_error().decode()}")
+    if nblk > 512:
+        raise RuntimeError("wide_linear_wgrad_deferred: partial count exceeds the fold kernel's limit")
+    wflat = w_grad.view(-1)
+    _DEFER[kw] = (part.view(G, Fo * Fi), wflat, wflat, Fo * Fi)
+    _DEFER[kb] = (wsb[:nblk * Fo].view(nblk, Fo), b_grad, b_grad, Fo)
+    sink_arrived(w_grad, b_grad)
+    return True
+
+
 def linear_dgrad_relu(g2, w16, relu_out):
     """(g2 @ w16) * (relu_out > 0): input gradient of a Linear whose input was a relu output, one launch."""
     N, Fo = g2.shape

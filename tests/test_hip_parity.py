@@ -1658,17 +1658,24 @@ def test_wide_linear_gradient_sinks_match_returned_gradients(M):
     x = torch.randn(8192, 256, device=DEV)
     cot = torch.randn(8192, 512, device=DEV).bfloat16()
     outs = []
-    for sink in (False, True):
+    for sink, deferred in ((False, False), (True, False), (True, True)):
         for p in lin.parameters():
             p.grad = torch.zeros_like(p) if sink else None
         xg = x.clone().requires_grad_(True)
         M.ops.GRAD_SINK = sink
+        if deferred:                      # what TrainStep does: partials queued, one fold at the end of backward
+            M.ops.begin_deferred_sinks()
         try:
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 y = lin(xg)
             y.backward(cot)
+            if deferred:
+                assert float(lin.weight.grad.abs().max()) == 0.0      # nothing folded yet
+                M.ops.flush_grad_sinks()
         finally:
             M.ops.GRAD_SINK = False
+            M.ops._DEFER = None
         outs.append([lin.weight.grad.clone(), lin.bias.grad.clone(), xg.grad.clone()])
-    for a, b in zip(*outs):
-        assert rel_err(a, b) < 1e-6
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert rel_err(a, b) < 1e-6
