@@ -1679,3 +1679,23 @@ def test_wide_linear_gradient_sinks_match_returned_gradients(M):
     for other in outs[1:]:
         for a, b in zip(outs[0], other):
             assert rel_err(a, b) < 1e-6
+
+
+def test_wide_relu_linear_epilogue_matches_separate_ops(M):
+    """FFN first layer at widths above the MFMA small-Linear kernels: bias + ReLU in the library GEMM's epilogue ==
+    relu(linear(x)) bit for bit, gradients included (with and without the gradient sinks)."""
+    torch.manual_seed(9)
+    lin = M.nn_bracket.Linear(256, 512).to(DEV)
+    x = torch.randn(64, 128, 256, device=DEV)
+    cot = torch.randn(64, 128, 512, device=DEV).bfloat16()
+    res = []
+    for fused in (True, False):
+        for p in lin.parameters():
+            p.grad = None
+        xg = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = lin.forward_relu(xg) if fused else torch.relu(lin(xg))
+        y.backward(cot)
+        res.append((y, xg.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
