@@ -215,6 +215,9 @@ def linear_group(x, layers):
         if ops.linear_group_supported(x16, wl):
             return list(_GroupLinearFn.apply(x16, len(layers), *[l.weight for l in layers], *[l.bias for l in layers],
                                              *wl, *bl))
+    if (x.is_cuda and x.dtype == torch.float32 and torch.is_autocast_enabled()
+            and torch.get_autocast_dtype("cuda") == torch.bfloat16 and len(layers) >= 2):
+        x = x.to(torch.bfloat16)        # one cast for the group instead of one per layer
     return [l(x) for l in layers]
 
 
