@@ -63,6 +63,25 @@ int mivae_posenc_mask(const void* x, const float* pe, const int64_t* mask, void*
  * causal, f32 or bf16.  Replaces the mask.ne(0) / tril / masked_fill chain of MultiHeadAttention.forward,
  * vae_lm/nn/transformer.py:75-89 (bracket of the path, row f). */
 int mivae_attn_bias(const int64_t* mask, void* out, int64_t B, int64_t S, int causal, int dtype, void* stream);
+/* Masked multi-head self-attention, forward and backward, on bf16 operands with fp32 softmax: replaces
+ * MultiHeadAttention.forward's score / masked_fill / softmax / matmul chain, nn/transformer.py:62-117 (scores =
+ * q k^T / sqrt(d), masked_fill(-1e13) where mask == 0 or, with causal != 0, key > query, softmax over keys, probs v).
+ * q, k, v: element (b, s, head, d) at base + b * batch_stride + s * row_stride + head * head_size + d (bf16; the
+ * (B, S, heads * head_size) outputs of the projections, no head transposes); strides in elements, multiples of 8.
+ * mask (B, S) int64 or NULL; out / dout / dq / dk / dv (B, S, heads * head_size) bf16 contiguous; lse and delta
+ * (B, heads, S) fp32 (lse may be NULL in forward-only use; it holds log2-domain log-sum-exp, +inf for a query
+ * without any valid key, which attends uniformly to all S keys like the reference's finite fill).
+ * head_size in {16, 32, 64, 128}, 1 <= S <= 2048 (mivae_attention_supported). */
+int mivae_attention_supported(int64_t head_size, int64_t S);
+int mivae_attention_fwd(const void* q, const void* k, const void* v, const int64_t* mask, void* out, float* lse,
+                        int64_t B, int64_t S, int64_t heads, int64_t head_size, int64_t q_batch_stride,
+                        int64_t q_row_stride, int64_t k_batch_stride, int64_t k_row_stride, int64_t v_batch_stride,
+                        int64_t v_row_stride, int causal, float scale, void* stream);
+int mivae_attention_bwd(const void* q, const void* k, const void* v, const int64_t* mask, const void* out,
+                        const void* dout, const float* lse, float* delta, void* dq, void* dk, void* dv, int64_t B,
+                        int64_t S, int64_t heads, int64_t head_size, int64_t q_batch_stride, int64_t q_row_stride,
+                        int64_t k_batch_stride, int64_t k_row_stride, int64_t v_batch_stride, int64_t v_row_stride,
+                        int causal, float scale, void* stream);
 /* last_idx[b] = sum_s mask[b,s] - 1; ctx[b,:] = out[b, last_idx[b], :] (index -1 wraps like torch).
  * Replaces Encoder.forward's gather, models/base/encoders/encoder.py:35-37.  last_idx may be NULL. */
 int mivae_gather_last(const void* out, const int64_t* mask, void* ctx, int64_t* last_idx, int64_t B,

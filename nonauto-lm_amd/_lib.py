@@ -26,6 +26,9 @@ SIGNATURES = {
     "mivae_sigma_head_bwd": [P, P, P, I64, F32, F32, I32, P],
     "mivae_posenc_mask": [P, P, P, P, I64, I64, I64, I32, I32, P],
     "mivae_attn_bias": [P, P, I64, I64, I32, I32, P],
+    "mivae_attention_supported": [I64, I64],
+    "mivae_attention_fwd": [P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I32, F32, P],
+    "mivae_attention_bwd": [P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I32, F32, P],
     "mivae_gather_last": [P, P, P, P, I64, I64, I64, I32, P],
     "mivae_reparam_logq_fwd": [P, P, P, P, P, P, I64, I64, I64, I64, I32, P],
     "mivae_reparam_logq_bwd": [P, P, P, P, P, P, P, I64, I64, I64, I64, I32, P],

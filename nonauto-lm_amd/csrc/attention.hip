@@ -1,0 +1,496 @@
+// Masked multi-head self-attention of the transformer bracket (nn/transformer.py:7-117: scores = q k^T / sqrt(d),
+// masked_fill(-1e13) on padded keys and, for the autoregressive family, on keys after the query, softmax, probs v)
+// for the short sequences this model family trains on (S <= 2048, head sizes 16 / 32 / 64 / 128), forward and
+// backward, bf16 operands, fp32 softmax.  The library attention the bracket used before spends 58 / 161 us
+// (forward / backward) on the 67 / 134 MB of a BASELINE config-3 layer; these kernels read q, k, v in the
+// (B, S, heads * d) layout the projections write (no head transposes) and never materialise the scores.
+//
+// All three kernels work on 32 x 32 score tiles with v_mfma_f32_32x32x16_bf16 and pick, per product, the operand
+// order whose accumulator layout is directly the next product's B operand, so no score tile ever goes through LDS:
+//   forward / dQ:  a wave owns 32 QUERIES.  S^T = K Q^T puts the query on the lane and the keys in the lane's
+//                  registers: the softmax statistics are per lane, and P^T (dS^T) is the B operand of
+//                  O^T = V^T P^T (dQ^T = K^T dS^T), whose A operand comes out of the transposing LDS read.
+//   dK / dV:       a wave owns 32 KEYS.  S = Q K^T puts the key on the lane and the queries in registers: P (dS) is the
+//                  B operand of dV^T = dO^T P (dK^T = Q^T dS).
+// The staged 64-row operand tiles are read both row-wise (16-byte fragments) and through ds_read_b64_tr_b16; the row
+// pitch (4 or 12 mod 16 granules) plus an XOR of the 16-byte granule index with bits 2-3 of the row makes both
+// patterns bank-conflict free.  The backward recomputes the score tile in both kernels (7 products instead of 5)
+// instead of accumulating dQ with atomics: every output is written once, in bf16, in fixed order.
+//
+// Mask semantics are the reference's: a masked score is -1e13 (not -inf), so a query row without any valid key
+// attends uniformly to all S keys (forward), passes that uniform weight to dV and nothing to dQ / dK (backward,
+// masked_fill's gradient).  Such rows are flagged by lse = +inf.
+#include "common.hpp"
+
+using namespace mivae;
+
+namespace {
+
+#define ATT_LDS __attribute__((address_space(3)))
+typedef __bf16 att_bf16x4 __attribute__((__vector_size__(4 * sizeof(__bf16))));
+
+static inline hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
+__device__ __forceinline__ int acc_row(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
+
+constexpr int kChunk = 64;        // rows of the streamed operands staged per pass
+constexpr int kMaxTiles = 64;     // S <= 32 * kMaxTiles
+constexpr float kFill2 = -1.4426950408889634e13f;   // the reference's -1e13 fill in base-2 exponent units
+constexpr float kLog2e = 1.4426950408889634f;
+
+struct AttArgs {
+  const unsigned short *q, *k, *v;    // element (b, s, head, d) at base + b * sb + s * sr + head * HD + d
+  int64_t q_sb, k_sb, v_sb;
+  int q_sr, k_sr, v_sr;
+  const int64_t* mask;                // (B, S), != 0 keeps the key; may be null
+  unsigned short* out;                // (B, S, heads * HD) contiguous
+  float* lse;                         // (B, heads, S): log2-domain log-sum-exp of the scaled scores, +inf = no valid key
+  const unsigned short* dout;         // (B, S, heads * HD) contiguous
+  float* delta;                       // (B, heads, S): sum_d dout * out
+  unsigned short *dq, *dk, *dv;       // (B, S, heads * HD) contiguous
+  int S, heads, causal;
+  float scale;
+};
+
+template <int HD>
+struct Geo {
+  static constexpr int HDP = HD < 32 ? 32 : HD;              // staged columns
+  static constexpr int PITCH = HDP == 32 ? 32 : HDP + 32;    // elements: 4 / 12 / 20 granules = 4 or 12 (mod 16)
+  static constexpr int NS = HD / 16;                         // 16-wide contraction slices over d
+  static constexpr int NDB = HDP / 32;                       // 32-wide blocks of d
+};
+
+__device__ __forceinline__ int swz(int r, int c) { return (c ^ ((r >> 2) & 3)) << 3; }
+
+// rows row0 .. row0 + 63 of one head (zero beyond S and beyond HD) -> swizzled tile
+template <int HD>
+__device__ __forceinline__ void stage_tile(unsigned short* tile, const unsigned short* src, int sr, int row0, int S) {
+  constexpr int G = Geo<HD>::HDP / 8;
+  for (int idx = threadIdx.x; idx < kChunk * G; idx += blockDim.x) {
+    const int r = idx / G, c = idx - r * G;
+    u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (row0 + r < S && c < HD / 8) v = *reinterpret_cast<const u16x8*>(src + (int64_t)(row0 + r) * sr + 8 * c);
+    *reinterpret_cast<u16x8*>(tile + r * Geo<HD>::PITCH + swz(r, c)) = v;
+  }
+}
+
+// A operand, rows of the tile: f[j] = tile[r][8 c + j]
+template <int HD>
+__device__ __forceinline__ bf16x8 row_frag(const unsigned short* tile, int r, int c) {
+  return *reinterpret_cast<const bf16x8*>(tile + r * Geo<HD>::PITCH + swz(r, c));
+}
+
+// A operand, columns of the tile (k = rows): f[j] = tile[row0 + 4 hh + (j & 3) + 8 (j >> 2)][32 db + r32], the row
+// order in which a 32x32 accumulator's registers 8 s .. 8 s + 7 (row0 = 16 s) hold their rows
+template <int HD>
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned short* tile, int row0, int db, int lane) {
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+  const int r0 = row0 + 4 * (g >> 1) + q, r1 = r0 + 8;
+  const int c = 4 * db + 2 * (g & 1) + (p >> 1), e = 4 * (p & 1);
+  const unsigned short* a0 = tile + r0 * Geo<HD>::PITCH + swz(r0, c) + e;
+  const unsigned short* a1 = tile + r1 * Geo<HD>::PITCH + swz(r1, c) + e;
+  const att_bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((ATT_LDS att_bf16x4*)(a0));
+  const att_bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((ATT_LDS att_bf16x4*)(a1));
+  return __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// B operand from global memory: row `row` of one head, f[j] = x[row][16 s + 8 hh + j] (zero for rows >= S)
+template <int HD>
+__device__ __forceinline__ void load_rows(bf16x8 (&f)[Geo<HD>::NS], const unsigned short* base, int sr, int row, int S,
+                                          int hh) {
+  const u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int s = 0; s < Geo<HD>::NS; ++s) {
+    u16x8 v = z;
+    if (row < S) v = *reinterpret_cast<const u16x8*>(base + (int64_t)row * sr + 16 * s + 8 * hh);
+    f[s] = __builtin_bit_cast(bf16x8, v);
+  }
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x16& x, int s) {
+  bf16x8 f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = (bf16_t)x[8 * s + j];
+  return f;
+}
+
+// keep bits of the keys, 32 per word (0 for keys >= S)
+__device__ __forceinline__ void stage_keybits(unsigned* kbits, const int64_t* mask, int64_t b, int S) {
+  const int lane = threadIdx.x & 63;
+  const int ntile = (S + 31) >> 5;
+  for (int base = (threadIdx.x >> 6) * 64; base < ntile * 32; base += blockDim.x) {
+    const int key = base + lane;
+    const bool keep = key < S && (mask == nullptr || mask[b * S + key] != 0);
+    const unsigned long long bal = __ballot(keep);
+    if (lane == 0) {
+      kbits[base >> 5] = (unsigned)bal;
+      kbits[(base >> 5) + 1] = (unsigned)(bal >> 32);
+    }
+  }
+}
+
+// rows 4 a .. 4 a + 3 of accumulator block `x` (d = 32 db + 8 a + 4 hh ..) of the wave's row `row` -> bf16 (B, S, heads * HD)
+template <int HD>
+__device__ __forceinline__ void store_rows(unsigned short* dst, const f32x16 (&x)[Geo<HD>::NDB], float mul, int hh) {
+#pragma unroll
+  for (int db = 0; db < Geo<HD>::NDB; ++db)
+#pragma unroll
+    for (int a4 = 0; a4 < 4; ++a4) {
+      const int d = 32 * db + 8 * a4 + 4 * hh;
+      if (d < HD) {
+        const u16x4 o = {f32_to_bf16(x[db][4 * a4] * mul), f32_to_bf16(x[db][4 * a4 + 1] * mul),
+                         f32_to_bf16(x[db][4 * a4 + 2] * mul), f32_to_bf16(x[db][4 * a4 + 3] * mul)};
+        *reinterpret_cast<u16x4*>(dst + d) = o;
+      }
+    }
+}
+
+#define ATT_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, c_, 0, 0, 0)
+
+// ---- forward: a wave owns 32 queries and walks the keys ---------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256, 2) void k_att_fwd(AttArgs a) {
+  using G = Geo<HD>;
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  unsigned short* kt = lds;
+  unsigned short* vt = lds + kChunk * G::PITCH;
+  unsigned* kbits = reinterpret_cast<unsigned*>(lds + 2 * kChunk * G::PITCH);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r32 = lane & 31, hh = lane >> 5;
+  const int64_t b = blockIdx.z;
+  const int head = blockIdx.y, S = a.S, W = a.heads * HD;
+  const int qrow = (blockIdx.x * (blockDim.x >> 6) + wave) * 32 + r32;
+  const int qlast = a.causal ? qrow : 0x40000000;     // last key the query may attend to
+  stage_keybits(kbits, a.mask, b, S);
+  bf16x8 qf[G::NS];
+  load_rows<HD>(qf, a.q + b * a.q_sb + head * HD, a.q_sr, qrow, S, hh);
+  const unsigned short* kbase = a.k + b * a.k_sb + head * HD;
+  const unsigned short* vbase = a.v + b * a.v_sb + head * HD;
+  f32x16 o[G::NDB];
+#pragma unroll
+  for (int db = 0; db < G::NDB; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  bool anykeep = false;
+  const float c2 = a.scale * kLog2e;
+  for (int kc = 0; kc < S; kc += kChunk) {
+    __syncthreads();                    // the previous chunk has been consumed (first pass: kbits are written)
+    stage_tile<HD>(kt, kbase, a.k_sr, kc, S);
+    stage_tile<HD>(vt, vbase, a.v_sr, kc, S);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < kChunk / 32; ++t) {
+      const int key0 = kc + 32 * t;
+      if (key0 >= S) break;             // block-uniform
+      f32x16 sc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < G::NS; ++s) sc = ATT_MFMA(row_frag<HD>(kt, 32 * t + r32, 2 * s + hh), qf[s], sc);
+      const unsigned bits = kbits[key0 >> 5];
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kl = acc_row(r, hh), key = key0 + kl;
+        const bool keep = ((bits >> kl) & 1u) & (unsigned)(key <= qlast);    // bitwise: no control flow per element
+        anykeep |= keep;
+        const float sv = keep ? sc[r] * c2 : (key < S ? kFill2 : -INFINITY);
+        sc[r] = sv;
+        tmax = fmaxf(tmax, sv);
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float mn = fmaxf(m, tmax);
+      const float alpha = __builtin_amdgcn_exp2f(m - mn);
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(sc[r] - mn);
+        sc[r] = p;
+        ps += p;
+      }
+      l = l * alpha + ps;
+      m = mn;
+#pragma unroll
+      for (int db = 0; db < G::NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+      const bf16x8 p0 = pack8(sc, 0), p1 = pack8(sc, 1);
+#pragma unroll
+      for (int db = 0; db < G::NDB; ++db) {
+        o[db] = ATT_MFMA(tr_frag<HD>(vt, 32 * t, db, lane), p0, o[db]);
+        o[db] = ATT_MFMA(tr_frag<HD>(vt, 32 * t + 16, db, lane), p1, o[db]);
+      }
+    }
+  }
+  l += __shfl_xor(l, 32, 64);           // the two half-waves hold disjoint keys of the same query
+  anykeep = __shfl_xor((int)anykeep, 32, 64) || anykeep;
+  if (qrow < S) {
+    store_rows<HD>(a.out + (b * S + qrow) * W + head * HD, o, 1.f / l, hh);
+    if (a.lse && hh == 0) a.lse[(b * a.heads + head) * S + qrow] = anykeep ? m + __builtin_amdgcn_logf(l) : INFINITY;
+  }
+}
+
+// ---- backward, dQ (and delta = rowsum(dO * O) for the dK / dV kernel): a wave owns 32 queries ----------------------
+template <int HD>
+__global__ __launch_bounds__(256, 2) void k_att_bwd_dq(AttArgs a) {
+  using G = Geo<HD>;
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  unsigned short* kt = lds;
+  unsigned short* vt = lds + kChunk * G::PITCH;
+  unsigned* kbits = reinterpret_cast<unsigned*>(lds + 2 * kChunk * G::PITCH);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r32 = lane & 31, hh = lane >> 5;
+  const int64_t b = blockIdx.z;
+  const int head = blockIdx.y, S = a.S, W = a.heads * HD;
+  const int qrow = (blockIdx.x * (blockDim.x >> 6) + wave) * 32 + r32;
+  const int qlast = a.causal ? qrow : 0x40000000;     // last key the query may attend to
+  stage_keybits(kbits, a.mask, b, S);
+  bf16x8 qf[G::NS], dof[G::NS];
+  load_rows<HD>(qf, a.q + b * a.q_sb + head * HD, a.q_sr, qrow, S, hh);
+  load_rows<HD>(dof, a.dout + b * S * W + head * HD, W, qrow, S, hh);
+  float delta = 0.f;
+  {
+    bf16x8 of[G::NS];
+    load_rows<HD>(of, a.out + b * S * W + head * HD, W, qrow, S, hh);
+#pragma unroll
+    for (int s = 0; s < G::NS; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) delta += (float)dof[s][j] * (float)of[s][j];
+    delta += __shfl_xor(delta, 32, 64);
+  }
+  float lse2 = 0.f;
+  if (qrow < S) {
+    lse2 = a.lse[(b * a.heads + head) * S + qrow];
+    if (hh == 0) a.delta[(b * a.heads + head) * S + qrow] = delta;
+  }
+  const unsigned short* kbase = a.k + b * a.k_sb + head * HD;
+  const unsigned short* vbase = a.v + b * a.v_sb + head * HD;
+  f32x16 dq[G::NDB];
+#pragma unroll
+  for (int db = 0; db < G::NDB; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
+  const float c2 = a.scale * kLog2e;
+  for (int kc = 0; kc < S; kc += kChunk) {
+    __syncthreads();
+    stage_tile<HD>(kt, kbase, a.k_sr, kc, S);
+    stage_tile<HD>(vt, vbase, a.v_sr, kc, S);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < kChunk / 32; ++t) {
+      const int key0 = kc + 32 * t;
+      if (key0 >= S) break;
+      f32x16 sc, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < G::NS; ++s) {
+        sc = ATT_MFMA(row_frag<HD>(kt, 32 * t + r32, 2 * s + hh), qf[s], sc);
+        dp = ATT_MFMA(row_frag<HD>(vt, 32 * t + r32, 2 * s + hh), dof[s], dp);
+      }
+      const unsigned bits = kbits[key0 >> 5];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kl = acc_row(r, hh);
+        const bool keep = ((bits >> kl) & 1u) & (unsigned)(key0 + kl <= qlast);
+        // branch-free: a masked score has exponent -inf.  A query without valid keys has lse2 = +inf: p = 0, and
+        // masked_fill passes no gradient to its scores anyway
+        const float x = keep ? fmaf(sc[r], c2, -lse2) : -INFINITY;
+        sc[r] = __builtin_amdgcn_exp2f(x) * (dp[r] - delta) * a.scale;
+      }
+      const bf16x8 d0 = pack8(sc, 0), d1 = pack8(sc, 1);
+#pragma unroll
+      for (int db = 0; db < G::NDB; ++db) {
+        dq[db] = ATT_MFMA(tr_frag<HD>(kt, 32 * t, db, lane), d0, dq[db]);
+        dq[db] = ATT_MFMA(tr_frag<HD>(kt, 32 * t + 16, db, lane), d1, dq[db]);
+      }
+    }
+  }
+  if (qrow < S) store_rows<HD>(a.dq + (b * S + qrow) * W + head * HD, dq, 1.f, hh);
+}
+
+// ---- backward, dK and dV: a wave owns 32 keys and walks the queries ------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256, HD == 128 ? 1 : 2) void k_att_bwd_dkv(AttArgs a) {
+  using G = Geo<HD>;
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  unsigned short* qt = lds;
+  unsigned short* dt = lds + kChunk * G::PITCH;
+  float* lses = reinterpret_cast<float*>(lds + 2 * kChunk * G::PITCH);   // [kChunk] lse2, [kChunk] delta
+  float* dels = lses + kChunk;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r32 = lane & 31, hh = lane >> 5;
+  const int64_t b = blockIdx.z;
+  const int head = blockIdx.y, S = a.S, W = a.heads * HD;
+  const int key = (blockIdx.x * (blockDim.x >> 6) + wave) * 32 + r32;
+  const bool kok = key < S;
+  const int cbig = a.causal ? 0 : 0x40000000;
+  const bool keepk = kok && (a.mask == nullptr || a.mask[b * S + key] != 0);
+  bf16x8 kf[G::NS], vf[G::NS];
+  load_rows<HD>(kf, a.k + b * a.k_sb + head * HD, a.k_sr, key, S, hh);
+  load_rows<HD>(vf, a.v + b * a.v_sb + head * HD, a.v_sr, key, S, hh);
+  const unsigned short* qbase = a.q + b * a.q_sb + head * HD;
+  const unsigned short* dbase = a.dout + b * S * W + head * HD;
+  const float* lse_g = a.lse + (b * a.heads + head) * S;
+  const float* del_g = a.delta + (b * a.heads + head) * S;
+  f32x16 dk[G::NDB], dv[G::NDB];
+#pragma unroll
+  for (int db = 0; db < G::NDB; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+  const float c2 = a.scale * kLog2e;
+  const float p_full = kok ? 1.f / (float)S : 0.f;
+  for (int qc = 0; qc < S; qc += kChunk) {
+    __syncthreads();
+    stage_tile<HD>(qt, qbase, a.q_sr, qc, S);
+    stage_tile<HD>(dt, dbase, W, qc, S);
+    for (int r = threadIdx.x; r < kChunk; r += blockDim.x) {
+      const bool ok = qc + r < S;       // rows beyond S: q = dO = 0, p stays finite, every product is 0
+      lses[r] = ok ? lse_g[qc + r] : 0.f;
+      dels[r] = ok ? del_g[qc + r] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < kChunk / 32; ++t) {
+      const int q0 = qc + 32 * t;
+      if (q0 >= S) break;
+      f32x16 sc, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < G::NS; ++s) {
+        sc = ATT_MFMA(row_frag<HD>(qt, 32 * t + r32, 2 * s + hh), kf[s], sc);
+        dp = ATT_MFMA(row_frag<HD>(dt, 32 * t + r32, 2 * s + hh), vf[s], dp);
+      }
+#pragma unroll
+      for (int a4 = 0; a4 < 4; ++a4) {
+        const f32x4 L = *reinterpret_cast<const f32x4*>(lses + 32 * t + 8 * a4 + 4 * hh);
+        const f32x4 D = *reinterpret_cast<const f32x4*>(dels + 32 * t + 8 * a4 + 4 * hh);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * a4 + i;
+          const bool keep = keepk & (key <= q0 + 8 * a4 + 4 * hh + i + cbig);
+          const float x = keep ? fmaf(sc[r], c2, -L[i]) : -INFINITY;       // branch-free masking
+          const float p = __builtin_amdgcn_exp2f(x);
+          dp[r] = p * (dp[r] - D[i]) * a.scale;
+          sc[r] = L[i] == INFINITY ? p_full : p;           // query without a valid key: uniform over all S keys
+        }
+      }
+      const bf16x8 p0 = pack8(sc, 0), p1 = pack8(sc, 1), d0 = pack8(dp, 0), d1 = pack8(dp, 1);
+#pragma unroll
+      for (int db = 0; db < G::NDB; ++db) {
+        dv[db] = ATT_MFMA(tr_frag<HD>(dt, 32 * t, db, lane), p0, dv[db]);
+        dv[db] = ATT_MFMA(tr_frag<HD>(dt, 32 * t + 16, db, lane), p1, dv[db]);
+        dk[db] = ATT_MFMA(tr_frag<HD>(qt, 32 * t, db, lane), d0, dk[db]);
+        dk[db] = ATT_MFMA(tr_frag<HD>(qt, 32 * t + 16, db, lane), d1, dk[db]);
+      }
+    }
+  }
+  if (kok) {
+    store_rows<HD>(a.dk + (b * S + key) * W + head * HD, dk, 1.f, hh);
+    store_rows<HD>(a.dv + (b * S + key) * W + head * HD, dv, 1.f, hh);
+  }
+}
+
+template <int HD>
+size_t lds_bytes() {
+  return (size_t)2 * kChunk * Geo<HD>::PITCH * 2 + (kMaxTiles + 2) * 4 + 2 * kChunk * 4;
+}
+
+template <int HD>
+void launch(const AttArgs& a, int64_t B, int which, hipStream_t st) {
+  const int tiles = (a.S + 31) / 32;
+  const int nw = tiles < 4 ? tiles : 4;
+  const dim3 grid((tiles + nw - 1) / nw, a.heads, (unsigned)B), block(64 * nw);
+  const size_t lds = lds_bytes<HD>();
+  if (which == 0) hipLaunchKernelGGL(k_att_fwd<HD>, grid, block, lds, st, a);
+  else if (which == 1) hipLaunchKernelGGL(k_att_bwd_dq<HD>, grid, block, lds, st, a);
+  else hipLaunchKernelGGL(k_att_bwd_dkv<HD>, grid, block, lds, st, a);
+}
+
+int dispatch(const AttArgs& a, int64_t B, int hd, int which, hipStream_t st) {
+  switch (hd) {
+    case 16: launch<16>(a, B, which, st); break;
+    case 32: launch<32>(a, B, which, st); break;
+    case 64: launch<64>(a, B, which, st); break;
+    case 128: launch<128>(a, B, which, st); break;
+    default: return MIVAE_EUNSUPPORTED;
+  }
+  return MIVAE_OK;
+}
+
+int fill_args(AttArgs& a, const char* name, const void* q, const void* k, const void* v, const int64_t* mask, int64_t B,
+              int64_t S, int64_t heads, int64_t hd, const int64_t (&strides)[6], int causal, float scale) {
+  MIVAE_REQUIRE(hd == 16 || hd == 32 || hd == 64 || hd == 128, "%s: head size %lld not in {16, 32, 64, 128}", name,
+                (long long)hd);
+  MIVAE_REQUIRE(S >= 1 && S <= 32 * kMaxTiles, "%s: S = %lld outside 1 .. %d", name, (long long)S, 32 * kMaxTiles);
+  MIVAE_REQUIRE(B >= 1 && B <= 65535 && heads >= 1 && heads <= 65535, "%s: B = %lld / heads = %lld outside 1 .. 65535",
+                name, (long long)B, (long long)heads);
+  MIVAE_REQUIRE(q && k && v, "%s: null operand", name);
+  for (int i = 0; i < 6; ++i)
+    MIVAE_REQUIRE(strides[i] >= 0 && strides[i] % 8 == 0 && strides[i] < (1ll << 40), "%s: stride %d = %lld not a multiple of 8",
+                  name, i, (long long)strides[i]);
+  MIVAE_REQUIRE(strides[1] >= heads * hd && strides[3] >= heads * hd && strides[5] >= heads * hd &&
+                    strides[1] < (1ll << 30) && strides[3] < (1ll << 30) && strides[5] < (1ll << 30),
+                "%s: row stride smaller than heads * head size", name);
+  MIVAE_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v), "%s: q / k / v must be 16-byte aligned", name);
+  a.q = static_cast<const unsigned short*>(q);
+  a.k = static_cast<const unsigned short*>(k);
+  a.v = static_cast<const unsigned short*>(v);
+  a.q_sb = strides[0]; a.q_sr = (int)strides[1];
+  a.k_sb = strides[2]; a.k_sr = (int)strides[3];
+  a.v_sb = strides[4]; a.v_sr = (int)strides[5];
+  a.mask = mask;
+  a.S = (int)S; a.heads = (int)heads; a.causal = causal ? 1 : 0;
+  a.scale = scale;
+  return MIVAE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mivae_attention_supported(int64_t head_size, int64_t S) {
+  return (head_size == 16 || head_size == 32 || head_size == 64 || head_size == 128) && S >= 1 && S <= 32 * kMaxTiles;
+}
+
+int mivae_attention_fwd(const void* q, const void* k, const void* v, const int64_t* mask, void* out, float* lse,
+                        int64_t B, int64_t S, int64_t heads, int64_t head_size, int64_t q_batch_stride,
+                        int64_t q_row_stride, int64_t k_batch_stride, int64_t k_row_stride, int64_t v_batch_stride,
+                        int64_t v_row_stride, int causal, float scale, void* stream) {
+  AttArgs a = {};
+  const int64_t strides[6] = {q_batch_stride, q_row_stride, k_batch_stride, k_row_stride, v_batch_stride, v_row_stride};
+  const int rc = fill_args(a, "mivae_attention_fwd", q, k, v, mask, B, S, heads, head_size, strides, causal, scale);
+  if (rc != MIVAE_OK) return rc;
+  MIVAE_REQUIRE(out && aligned16(out), "mivae_attention_fwd: out must be a 16-byte aligned buffer");
+  a.out = static_cast<unsigned short*>(out);
+  a.lse = lse;
+  dispatch(a, B, (int)head_size, 0, S_(stream));
+  MIVAE_CHECK_LAUNCH("mivae_attention_fwd");
+  return MIVAE_OK;
+}
+
+int mivae_attention_bwd(const void* q, const void* k, const void* v, const int64_t* mask, const void* out,
+                        const void* dout, const float* lse, float* delta, void* dq, void* dk, void* dv, int64_t B,
+                        int64_t S, int64_t heads, int64_t head_size, int64_t q_batch_stride, int64_t q_row_stride,
+                        int64_t k_batch_stride, int64_t k_row_stride, int64_t v_batch_stride, int64_t v_row_stride,
+                        int causal, float scale, void* stream) {
+  AttArgs a = {};
+  const int64_t strides[6] = {q_batch_stride, q_row_stride, k_batch_stride, k_row_stride, v_batch_stride, v_row_stride};
+  const int rc = fill_args(a, "mivae_attention_bwd", q, k, v, mask, B, S, heads, head_size, strides, causal, scale);
+  if (rc != MIVAE_OK) return rc;
+  MIVAE_REQUIRE(out && dout && lse && delta && dq && dk && dv, "mivae_attention_bwd: null operand");
+  MIVAE_REQUIRE(aligned16(out) && aligned16(dout) && aligned16(dq) && aligned16(dk) && aligned16(dv),
+                "mivae_attention_bwd: out / dout / dq / dk / dv must be 16-byte aligned");
+  a.out = static_cast<unsigned short*>(const_cast<void*>(out));
+  a.dout = static_cast<const unsigned short*>(dout);
+  a.lse = const_cast<float*>(lse);
+  a.delta = delta;
+  a.dq = static_cast<unsigned short*>(dq);
+  a.dk = static_cast<unsigned short*>(dk);
+  a.dv = static_cast<unsigned short*>(dv);
+  dispatch(a, B, (int)head_size, 1, S_(stream));
+  MIVAE_CHECK_LAUNCH("mivae_attention_bwd (dq)");
+  dispatch(a, B, (int)head_size, 2, S_(stream));
+  MIVAE_CHECK_LAUNCH("mivae_attention_bwd (dk, dv)");
+  return MIVAE_OK;
+}
+
+}  // extern "C"

@@ -357,6 +357,9 @@ def _maybe_dropout(p):
 # graph-captured library attention kernel on ROCm 7.2)
 USE_FUSED_ATTENTION = os.environ.get("MIVAE_NO_SDPA", "0") != "1"
 USE_FUSED_FFN = True     # pre-norm feed-forward sublayer forward in one libmivae launch (bf16 autocast)
+# libmivae's own attention kernels (csrc/attention.hip: head sizes 16 / 32 / 64 / 128, S <= 2048) instead of the
+# library's; MIVAE_LIB_ATTENTION=1 keeps the library kernel for comparisons
+USE_MIVAE_ATTENTION = os.environ.get("MIVAE_LIB_ATTENTION", "0") != "1"
 
 
 class MultiHeadAttention(torch.nn.Module):
@@ -388,14 +391,25 @@ class MultiHeadAttention(torch.nn.Module):
                     and torch.get_autocast_dtype("cuda") == torch.bfloat16
                     and not (self.training and isinstance(self._dropout, torch.nn.Dropout) and self._dropout.p > 0))
 
+    def kernel_ok(self, x, mask) -> bool:
+        """libmivae's attention kernels apply: fused_ok, a supported head size / length and a (B, S) token mask"""
+        return bool(USE_MIVAE_ATTENTION and self.fused_ok(x) and x.dim() == 3
+                    and (mask is None or mask.shape == x.shape[:2])
+                    and ops.attention_shape_supported(x.size(0), x.size(1), self._num_heads * self._attn_size,
+                                                      self._num_heads))
+
     def forward(self, query, key, value, mask=None, attn_bias=None):
         if query is key and key is value:        # self-attention: the three projections share their input
             q, k, v = linear_group(query, [self._projections[n] for n in ("query", "key", "value")])
-            q, k, v = self._split(q), self._split(k), self._split(v)
         else:
-            q = self._split(self._projections["query"](query))
-            k = self._split(self._projections["key"](key))
-            v = self._split(self._projections["value"](value))
+            q = self._projections["query"](query)
+            k = self._projections["key"](key)
+            v = self._projections["value"](value)
+        if (q.dtype == torch.bfloat16 and q.shape == k.shape and k.shape == v.shape and self.kernel_ok(q, mask)):
+            # scores, reference fill (-1e13), softmax and probs @ v per head in libmivae's kernels, straight on the
+            # (B, S, heads * d) projections (no head transposes, no bias tensor)
+            return self._output(ops.attention(q, k, v, mask, self._num_heads, self._mask_tril))
+        q, k, v = self._split(q), self._split(k), self._split(v)
         S = q.size(2)
         if (USE_FUSED_ATTENTION and q.is_cuda and q.dtype == torch.bfloat16 and torch.is_autocast_enabled()
                 and not (self.training and isinstance(self._dropout, torch.nn.Dropout) and self._dropout.p > 0)):
@@ -513,7 +527,7 @@ class _TransformerLayer(torch.nn.Module):
 
     def attention_bias(self, x, mask):
         """the layer stack's shared attention bias for (x, mask), or None when the explicit masked-softmax path runs"""
-        if mask is None or not self._attn.fused_ok(x):
+        if mask is None or not self._attn.fused_ok(x) or self._attn.kernel_ok(x, mask):
             return None
         return ops.attention_bias(mask, self._attn._mask_tril, torch.bfloat16)
 

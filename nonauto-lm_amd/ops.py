@@ -3,6 +3,7 @@
 PyTorch is plumbing here: it owns device memory, the current HIP stream and autograd bookkeeping.
 Every numeric result on this path comes from a hand-written HIP kernel; inputs must live on the GPU.
 """
+import math
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -165,6 +166,75 @@ def attention_bias(mask: torch.Tensor, causal: bool, dtype: torch.dtype) -> torc
     out = torch.empty((B, 1, S, S) if causal else (B, 1, 1, S), dtype=dtype, device=mask.device)
     L.call("mivae_attn_bias", L.ptr(mask), L.ptr(out), B, S, int(bool(causal)), L.dtype_code(dtype), L.stream())
     return out
+
+
+def attention_shape_supported(B: int, S: int, W: int, heads: int) -> bool:
+    """head size W / heads in {16, 32, 64, 128}, 1 <= S <= 2048, B and heads within the launch grid"""
+    return bool(heads > 0 and W % heads == 0 and 0 < B <= 65535 and heads <= 65535
+                and L.query("mivae_attention_supported", W // heads, S))
+
+
+def attention_supported(x: torch.Tensor, heads: int) -> bool:
+    """libmivae's attention kernels take (B, S, heads * d) bf16 GPU operands of a supported shape"""
+    return bool(x.is_cuda and x.dim() == 3 and x.dtype == torch.bfloat16
+                and attention_shape_supported(x.size(0), x.size(1), x.size(2), heads))
+
+
+def _att_operand(t):
+    """(B, S, W) bf16 view the kernels can address: unit feature stride, 16-byte aligned rows"""
+    if t.stride(2) != 1 or t.stride(1) % 8 or t.stride(0) % 8 or t.data_ptr() % 16 or t.stride(1) < t.size(2):
+        t = t.contiguous()
+    return t
+
+
+class _Attention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, mask, heads, causal):
+        q, k, v = _att_operand(q), _att_operand(k), _att_operand(v)
+        B, S, W = q.shape
+        hd = W // heads
+        scale = 1.0 / math.sqrt(hd)
+        need = any(ctx.needs_input_grad[:3])
+        out = torch.empty(B, S, W, dtype=torch.bfloat16, device=q.device)
+        lse = torch.empty(B, heads, S, dtype=torch.float32, device=q.device) if need else None
+        L.call("mivae_attention_fwd", L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(mask), L.ptr(out), L.ptr(lse), B, S, heads, hd,
+               q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1), int(causal), scale,
+               L.stream())
+        if need:
+            ctx.save_for_backward(q, k, v, mask, out, lse)
+            ctx.geo = (heads, hd, int(causal), scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, mask, out, lse = ctx.saved_tensors
+        heads, hd, causal, scale = ctx.geo
+        B, S, W = q.shape
+        dout = dout.contiguous()
+        if dout.dtype != torch.bfloat16:
+            dout = dout.to(torch.bfloat16)
+        dqkv = torch.empty(3, B, S, W, dtype=torch.bfloat16, device=q.device)
+        delta = torch.empty_like(lse)
+        L.call("mivae_attention_bwd", L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(mask), L.ptr(out), L.ptr(dout), L.ptr(lse),
+               L.ptr(delta), L.ptr(dqkv[0]), L.ptr(dqkv[1]), L.ptr(dqkv[2]), B, S, heads, hd, q.stride(0), q.stride(1),
+               k.stride(0), k.stride(1), v.stride(0), v.stride(1), causal, scale, L.stream())
+        return dqkv[0], dqkv[1], dqkv[2], None, None, None
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask: Optional[torch.Tensor], heads: int,
+              causal: bool = False) -> torch.Tensor:
+    """softmax(masked_fill(q k^T / sqrt(d), mask == 0 [or key > query], -1e13)) v per head for q, k, v (B, S, heads * d)
+    bf16 (the projections' outputs, any row stride) and a (B, S) token mask: MultiHeadAttention.forward's core
+    (nn/transformer.py:62-117) without the score tensor, forward and backward on libmivae's kernels."""
+    L.require_gpu(q, k, v, mask)
+    if not (attention_supported(q, heads) and k.shape == q.shape and v.shape == q.shape
+            and k.dtype == torch.bfloat16 and v.dtype == torch.bfloat16):
+        raise ValueError(f"ops.attention: unsupported operands {tuple(q.shape)} {q.dtype} with {heads} heads")
+    if mask is not None:
+        mask = _mask_i64(mask)
+        if mask.shape != q.shape[:2]:
+            raise ValueError(f"ops.attention: mask {tuple(mask.shape)} does not match (B, S) = {tuple(q.shape[:2])}")
+    return _Attention.apply(q, k, v, mask, int(heads), bool(causal))
 
 
 def segment_sum(tok: torch.Tensor, nseg: int, S: int, add: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -1,0 +1,96 @@
+"""libmivae attention kernels (csrc/attention.hip) against the reference's attention core restated in fp32 torch:
+MultiHeadAttention.forward, nn/transformer.py:62-117 (scores / sqrt(d), masked_fill(-1e13), softmax, probs @ v).
+bf16 operands: outputs within 2e-2 absolute / relative of the fp32 restatement on the same bf16-rounded inputs
+(the probabilities are rounded to bf16 before the second product, like every fused attention)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(q, k, v, mask, heads, causal):
+    B, S, W = q.shape
+    hd = W // heads
+    sp = lambda x: x.view(B, S, heads, hd).transpose(1, 2)
+    qh, kh, vh = sp(q), sp(k), sp(v)
+    scores = torch.matmul(qh, kh.transpose(-1, -2)) / math.sqrt(hd)
+    keep = torch.ones(B, 1, 1, S, dtype=torch.bool, device=q.device) if mask is None else mask.ne(0)[:, None, None, :]
+    if causal:
+        keep = keep & torch.ones(S, S, dtype=torch.bool, device=q.device).tril()[None, None]
+    scores = scores.masked_fill(~keep, -1e13)
+    return torch.matmul(torch.softmax(scores, dim=-1), vh).transpose(1, 2).reshape(B, S, W)
+
+
+def _case(B, S, heads, hd, causal, masked, seed=0, packed=False, empty_row=False):
+    from nonauto_lm_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    W = heads * hd
+    x = torch.randn(B, S, 3 * W, device="cuda", generator=g).to(torch.bfloat16)
+    mask = None
+    if masked:
+        lens = torch.randint(1, S + 1, (B,), device="cuda", generator=g)
+        lens[0] = S
+        mask = (torch.arange(S, device="cuda")[None, :] < lens[:, None]).long()
+        if empty_row:
+            mask[-1] = 0          # a sentence without tokens: the reference attends uniformly (finite fill)
+    dout = torch.randn(B, S, W, device="cuda", generator=g).to(torch.bfloat16)
+    split = lambda t: (t[..., :W], t[..., W:2 * W], t[..., 2 * W:])
+    if packed:        # q, k, v stay column blocks of one (B, S, 3 W) tensor (row stride 3 W)
+        leaves = [x.clone().requires_grad_(True)]
+        out = ops.attention(*split(leaves[0]), mask, heads, causal)
+        refl = [x.float().requires_grad_(True)]
+        ref = _ref(*split(refl[0]), mask, heads, causal)
+    else:
+        leaves = [t.clone().requires_grad_(True) for t in split(x)]
+        out = ops.attention(*leaves, mask, heads, causal)
+        refl = [t.float().clone().requires_grad_(True) for t in split(x)]
+        ref = _ref(*refl, mask, heads, causal)
+    out.backward(dout)
+    ref.backward(dout.float())
+    assert out.dtype == torch.bfloat16 and out.shape == ref.shape
+    torch.testing.assert_close(out.float(), ref, rtol=2e-2, atol=2e-2)
+    for i, (a, b) in enumerate(zip(leaves, refl)):
+        scale = b.grad.abs().max().item()
+        err = (a.grad.float() - b.grad).abs().max().item()
+        assert err <= 2e-2 * max(scale, 1.0), f"grad {i}: max err {err} (scale {scale})"
+
+
+@pytest.mark.parametrize("hd", [16, 32, 64, 128])
+@pytest.mark.parametrize("causal", [False, True])
+def test_attention_matches_reference_core(hd, causal):
+    _case(3, 64, 2, hd, causal, masked=True, seed=hd + causal)
+
+
+@pytest.mark.parametrize("S", [1, 7, 33, 100, 128, 257])
+def test_attention_ragged_lengths(S):
+    _case(2, S, 4, 16, False, masked=True, seed=S)
+    _case(2, S, 2, 64, True, masked=True, seed=S + 1)
+
+
+def test_attention_no_mask_and_packed_rows():
+    _case(2, 96, 4, 32, False, masked=False, seed=5)
+    _case(2, 96, 4, 32, False, masked=True, seed=6, packed=True)
+
+
+def test_attention_row_without_valid_key_is_uniform():
+    """mask == 0 everywhere in a sentence: -1e13 everywhere -> uniform weights over all S keys (forward), that weight
+    into dV and nothing into dQ / dK (masked_fill's gradient), exactly like the reference expression"""
+    _case(3, 40, 2, 16, False, masked=True, seed=9, empty_row=True)
+    _case(3, 70, 2, 64, False, masked=True, seed=10, empty_row=True)
+
+
+def test_attention_config_shapes():
+    _case(4, 64, 4, 16, False, masked=True, seed=11)      # BASELINE config 2
+    _case(4, 128, 4, 64, False, masked=True, seed=12)     # config 3
+    _case(2, 512, 4, 128, False, masked=True, seed=13)    # config 5
+
+
+def test_attention_rejects_unsupported():
+    from nonauto_lm_amd import ops
+    x = torch.zeros(2, 8, 48, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(ValueError):
+        ops.attention(x, x, x, None, 2)                   # head size 24
+    with pytest.raises(ValueError):
+        ops.attention(x.float(), x.float(), x.float(), None, 3)
