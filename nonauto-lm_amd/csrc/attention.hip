@@ -61,15 +61,40 @@ struct Geo {
 
 __device__ __forceinline__ int swz(int r, int c) { return (c ^ ((r >> 2) & 3)) << 3; }
 
-// rows row0 .. row0 + 63 of one head (zero beyond S and beyond HD) -> swizzled tile
-template <int HD>
-__device__ __forceinline__ void stage_tile(unsigned short* tile, const unsigned short* src, int sr, int row0, int S) {
-  constexpr int G = Geo<HD>::HDP / 8;
-  for (int idx = threadIdx.x; idx < kChunk * G; idx += blockDim.x) {
-    const int r = idx / G, c = idx - r * G;
-    u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (row0 + r < S && c < HD / 8) v = *reinterpret_cast<const u16x8*>(src + (int64_t)(row0 + r) * sr + 8 * c);
-    *reinterpret_cast<u16x8*>(tile + r * Geo<HD>::PITCH + swz(r, c)) = v;
+// One operand chunk (kChunk rows of one head) on its way global -> registers -> swizzled LDS tile.  The loads of chunk
+// i + 1 are issued before the products of chunk i and land in the tile after them, so their latency is covered by
+// the products (the block is NW waves; every index below is a compile-time function of the thread id).
+template <int HD, int NW>
+struct Stage {
+  static constexpr int GR = HD / 8;                                   // real 16-byte granules per row
+  static constexpr int N = (kChunk * GR + 64 * NW - 1) / (64 * NW);   // granules per thread
+  u16x8 r[N];
+  __device__ __forceinline__ void load(const unsigned short* src, int sr, int row0, int S) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int idx = threadIdx.x + i * 64 * NW, row = idx / GR, c = idx % GR;
+      const u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      r[i] = z;
+      if (idx < kChunk * GR && row0 + row < S) r[i] = *reinterpret_cast<const u16x8*>(src + (int64_t)(row0 + row) * sr + 8 * c);
+    }
+  }
+  __device__ __forceinline__ void store(unsigned short* tile) const {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int idx = threadIdx.x + i * 64 * NW, row = idx / GR, c = idx % GR;
+      if (idx < kChunk * GR) *reinterpret_cast<u16x8*>(tile + row * Geo<HD>::PITCH + swz(row, c)) = r[i];
+    }
+  }
+};
+
+// head size 16: the staged tiles are 32 columns wide, the upper 16 stay zero (written once, never staged)
+template <int HD, int NW>
+__device__ __forceinline__ void zero_pad_columns(unsigned short* tiles, int ntiles) {
+  if (HD >= 32) return;
+  const u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int idx = threadIdx.x; idx < ntiles * kChunk * 2; idx += 64 * NW) {
+    const int row = idx >> 1, c = 2 + (idx & 1);
+    *reinterpret_cast<u16x8*>(tiles + row * Geo<HD>::PITCH + swz(row & (kChunk - 1), c)) = z;
   }
 }
 
@@ -114,10 +139,11 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& x, int s) {
 }
 
 // keep bits of the keys, 32 per word (0 for keys >= S)
+template <int NW>
 __device__ __forceinline__ void stage_keybits(unsigned* kbits, const int64_t* mask, int64_t b, int S) {
   const int lane = threadIdx.x & 63;
   const int ntile = (S + 31) >> 5;
-  for (int base = (threadIdx.x >> 6) * 64; base < ntile * 32; base += blockDim.x) {
+  for (int base = (threadIdx.x >> 6) * 64; base < ntile * 32; base += 64 * NW) {
     const int key = base + lane;
     const bool keep = key < S && (mask == nullptr || mask[b * S + key] != 0);
     const unsigned long long bal = __ballot(keep);
@@ -147,8 +173,8 @@ __device__ __forceinline__ void store_rows(unsigned short* dst, const f32x16 (&x
 #define ATT_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, c_, 0, 0, 0)
 
 // ---- forward: a wave owns 32 queries and walks the keys ---------------------------------------------------------
-template <int HD>
-__global__ __launch_bounds__(256, 2) void k_att_fwd(AttArgs a) {
+template <int HD, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void k_att_fwd(AttArgs a) {
   using G = Geo<HD>;
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
   unsigned short* kt = lds;
@@ -157,13 +183,17 @@ __global__ __launch_bounds__(256, 2) void k_att_fwd(AttArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r32 = lane & 31, hh = lane >> 5;
   const int64_t b = blockIdx.z;
   const int head = blockIdx.y, S = a.S, W = a.heads * HD;
-  const int qrow = (blockIdx.x * (blockDim.x >> 6) + wave) * 32 + r32;
+  const int qrow = (blockIdx.x * NW + wave) * 32 + r32;
   const int qlast = a.causal ? qrow : 0x40000000;     // last key the query may attend to
-  stage_keybits(kbits, a.mask, b, S);
-  bf16x8 qf[G::NS];
-  load_rows<HD>(qf, a.q + b * a.q_sb + head * HD, a.q_sr, qrow, S, hh);
   const unsigned short* kbase = a.k + b * a.k_sb + head * HD;
   const unsigned short* vbase = a.v + b * a.v_sb + head * HD;
+  Stage<HD, NW> sk, sv;                 // every global load of the prologue is in flight before the first wait
+  sk.load(kbase, a.k_sr, 0, S);
+  sv.load(vbase, a.v_sr, 0, S);
+  bf16x8 qf[G::NS];
+  load_rows<HD>(qf, a.q + b * a.q_sb + head * HD, a.q_sr, qrow, S, hh);
+  stage_keybits<NW>(kbits, a.mask, b, S);
+  zero_pad_columns<HD, NW>(lds, 2);
   f32x16 o[G::NDB];
 #pragma unroll
   for (int db = 0; db < G::NDB; ++db)
@@ -174,9 +204,13 @@ __global__ __launch_bounds__(256, 2) void k_att_fwd(AttArgs a) {
   const float c2 = a.scale * kLog2e;
   for (int kc = 0; kc < S; kc += kChunk) {
     __syncthreads();                    // the previous chunk has been consumed (first pass: kbits are written)
-    stage_tile<HD>(kt, kbase, a.k_sr, kc, S);
-    stage_tile<HD>(vt, vbase, a.v_sr, kc, S);
+    sk.store(kt);
+    sv.store(vt);
     __syncthreads();
+    if (kc + kChunk < S) {              // block-uniform: the next chunk travels while this one is multiplied
+      sk.load(kbase, a.k_sr, kc + kChunk, S);
+      sv.load(vbase, a.v_sr, kc + kChunk, S);
+    }
 #pragma unroll
     for (int t = 0; t < kChunk / 32; ++t) {
       const int key0 = kc + 32 * t;
@@ -230,8 +264,8 @@ __global__ __launch_bounds__(256, 2) void k_att_fwd(AttArgs a) {
 }
 
 // ---- backward, dQ (and delta = rowsum(dO * O) for the dK / dV kernel): a wave owns 32 queries ----------------------
-template <int HD>
-__global__ __launch_bounds__(256, 2) void k_att_bwd_dq(AttArgs a) {
+template <int HD, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void k_att_bwd_dq(AttArgs a) {
   using G = Geo<HD>;
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
   unsigned short* kt = lds;
@@ -240,9 +274,15 @@ __global__ __launch_bounds__(256, 2) void k_att_bwd_dq(AttArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r32 = lane & 31, hh = lane >> 5;
   const int64_t b = blockIdx.z;
   const int head = blockIdx.y, S = a.S, W = a.heads * HD;
-  const int qrow = (blockIdx.x * (blockDim.x >> 6) + wave) * 32 + r32;
+  const int qrow = (blockIdx.x * NW + wave) * 32 + r32;
   const int qlast = a.causal ? qrow : 0x40000000;     // last key the query may attend to
-  stage_keybits(kbits, a.mask, b, S);
+  const unsigned short* kbase = a.k + b * a.k_sb + head * HD;
+  const unsigned short* vbase = a.v + b * a.v_sb + head * HD;
+  Stage<HD, NW> sk, sv;
+  sk.load(kbase, a.k_sr, 0, S);
+  sv.load(vbase, a.v_sr, 0, S);
+  stage_keybits<NW>(kbits, a.mask, b, S);
+  zero_pad_columns<HD, NW>(lds, 2);
   bf16x8 qf[G::NS], dof[G::NS];
   load_rows<HD>(qf, a.q + b * a.q_sb + head * HD, a.q_sr, qrow, S, hh);
   load_rows<HD>(dof, a.dout + b * S * W + head * HD, W, qrow, S, hh);
@@ -261,8 +301,6 @@ __global__ __launch_bounds__(256, 2) void k_att_bwd_dq(AttArgs a) {
     lse2 = a.lse[(b * a.heads + head) * S + qrow];
     if (hh == 0) a.delta[(b * a.heads + head) * S + qrow] = delta;
   }
-  const unsigned short* kbase = a.k + b * a.k_sb + head * HD;
-  const unsigned short* vbase = a.v + b * a.v_sb + head * HD;
   f32x16 dq[G::NDB];
 #pragma unroll
   for (int db = 0; db < G::NDB; ++db)
@@ -271,9 +309,13 @@ __global__ __launch_bounds__(256, 2) void k_att_bwd_dq(AttArgs a) {
   const float c2 = a.scale * kLog2e;
   for (int kc = 0; kc < S; kc += kChunk) {
     __syncthreads();
-    stage_tile<HD>(kt, kbase, a.k_sr, kc, S);
-    stage_tile<HD>(vt, vbase, a.v_sr, kc, S);
+    sk.store(kt);
+    sv.store(vt);
     __syncthreads();
+    if (kc + kChunk < S) {              // block-uniform: the next chunk travels while this one is multiplied
+      sk.load(kbase, a.k_sr, kc + kChunk, S);
+      sv.load(vbase, a.v_sr, kc + kChunk, S);
+    }
 #pragma unroll
     for (int t = 0; t < kChunk / 32; ++t) {
       const int key0 = kc + 32 * t;
@@ -308,8 +350,8 @@ __global__ __launch_bounds__(256, 2) void k_att_bwd_dq(AttArgs a) {
 }
 
 // ---- backward, dK and dV: a wave owns 32 keys and walks the queries ------------------------------------------------
-template <int HD>
-__global__ __launch_bounds__(256, HD == 128 ? 1 : 2) void k_att_bwd_dkv(AttArgs a) {
+template <int HD, int NW>
+__global__ __launch_bounds__(64 * NW, HD == 128 ? 1 : 2) void k_att_bwd_dkv(AttArgs a) {
   using G = Geo<HD>;
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
   unsigned short* qt = lds;
@@ -319,7 +361,7 @@ __global__ __launch_bounds__(256, HD == 128 ? 1 : 2) void k_att_bwd_dkv(AttArgs 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r32 = lane & 31, hh = lane >> 5;
   const int64_t b = blockIdx.z;
   const int head = blockIdx.y, S = a.S, W = a.heads * HD;
-  const int key = (blockIdx.x * (blockDim.x >> 6) + wave) * 32 + r32;
+  const int key = (blockIdx.x * NW + wave) * 32 + r32;
   const bool kok = key < S;
   const int cbig = a.causal ? 0 : 0x40000000;
   const bool keepk = kok && (a.mask == nullptr || a.mask[b * S + key] != 0);
@@ -337,16 +379,24 @@ __global__ __launch_bounds__(256, HD == 128 ? 1 : 2) void k_att_bwd_dkv(AttArgs 
     for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
   const float c2 = a.scale * kLog2e;
   const float p_full = kok ? 1.f / (float)S : 0.f;
+  Stage<HD, NW> sq, sd;
+  float pl = 0.f, pd = 0.f;             // lse2 / delta of chunk row threadIdx.x (the first kChunk threads)
+  auto load_chunk = [&](int qc) {
+    sq.load(qbase, a.q_sr, qc, S);
+    sd.load(dbase, W, qc, S);
+    const bool ok = threadIdx.x < kChunk && qc + (int)threadIdx.x < S;
+    pl = ok ? lse_g[qc + threadIdx.x] : 0.f;     // rows beyond S: q = dO = 0, p stays finite, every product is 0
+    pd = ok ? del_g[qc + threadIdx.x] : 0.f;
+  };
+  load_chunk(0);
+  zero_pad_columns<HD, NW>(lds, 2);
   for (int qc = 0; qc < S; qc += kChunk) {
     __syncthreads();
-    stage_tile<HD>(qt, qbase, a.q_sr, qc, S);
-    stage_tile<HD>(dt, dbase, W, qc, S);
-    for (int r = threadIdx.x; r < kChunk; r += blockDim.x) {
-      const bool ok = qc + r < S;       // rows beyond S: q = dO = 0, p stays finite, every product is 0
-      lses[r] = ok ? lse_g[qc + r] : 0.f;
-      dels[r] = ok ? del_g[qc + r] : 0.f;
-    }
+    sq.store(qt);
+    sd.store(dt);
+    if (threadIdx.x < kChunk) { lses[threadIdx.x] = pl; dels[threadIdx.x] = pd; }
     __syncthreads();
+    if (qc + kChunk < S) load_chunk(qc + kChunk);
 #pragma unroll
     for (int t = 0; t < kChunk / 32; ++t) {
       const int q0 = qc + 32 * t;
@@ -394,15 +444,22 @@ size_t lds_bytes() {
   return (size_t)2 * kChunk * Geo<HD>::PITCH * 2 + (kMaxTiles + 2) * 4 + 2 * kChunk * 4;
 }
 
+template <int HD, int NW>
+void launch_nw(const AttArgs& a, int64_t B, int which, hipStream_t st) {
+  const int tiles = (a.S + 31) / 32;
+  const dim3 grid((tiles + NW - 1) / NW, a.heads, (unsigned)B), block(64 * NW);
+  const size_t lds = lds_bytes<HD>();
+  if (which == 0) hipLaunchKernelGGL((k_att_fwd<HD, NW>), grid, block, lds, st, a);
+  else if (which == 1) hipLaunchKernelGGL((k_att_bwd_dq<HD, NW>), grid, block, lds, st, a);
+  else hipLaunchKernelGGL((k_att_bwd_dkv<HD, NW>), grid, block, lds, st, a);
+}
+
 template <int HD>
 void launch(const AttArgs& a, int64_t B, int which, hipStream_t st) {
-  const int tiles = (a.S + 31) / 32;
-  const int nw = tiles < 4 ? tiles : 4;
-  const dim3 grid((tiles + nw - 1) / nw, a.heads, (unsigned)B), block(64 * nw);
-  const size_t lds = lds_bytes<HD>();
-  if (which == 0) hipLaunchKernelGGL(k_att_fwd<HD>, grid, block, lds, st, a);
-  else if (which == 1) hipLaunchKernelGGL(k_att_bwd_dq<HD>, grid, block, lds, st, a);
-  else hipLaunchKernelGGL(k_att_bwd_dkv<HD>, grid, block, lds, st, a);
+  const int tiles = (a.S + 31) / 32;       // a block is 1, 2 or 4 waves of 32 rows
+  if (tiles == 1) launch_nw<HD, 1>(a, B, which, st);
+  else if (tiles == 2) launch_nw<HD, 2>(a, B, which, st);
+  else launch_nw<HD, 4>(a, B, which, st);
 }
 
 int dispatch(const AttArgs& a, int64_t B, int hd, int which, hipStream_t st) {
