@@ -36,6 +36,7 @@ constexpr int kChunk = 64;        // rows of the streamed operands staged per pa
 constexpr int kMaxTiles = 64;     // S <= 32 * kMaxTiles
 constexpr float kFill2 = -1.4426950408889634e13f;   // the reference's -1e13 fill in base-2 exponent units
 constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kSlack = 8.f;       // forward: exponent slack before the accumulators are rescaled
 
 struct AttArgs {
   const unsigned short *q, *k, *v;    // element (b, s, head, d) at base + b * sb + s * sr + head * HD + d
@@ -138,20 +139,13 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& x, int s) {
   return f;
 }
 
-// keep bits of the keys, 32 per word (0 for keys >= S)
+// additive score bias of the keys in base-2 exponent units: 0 = keep, the reference's fill for a masked key, -inf for
+// the tile padding beyond S (kbias has 32 * ceil(S / 32) entries)
 template <int NW>
-__device__ __forceinline__ void stage_keybits(unsigned* kbits, const int64_t* mask, int64_t b, int S) {
-  const int lane = threadIdx.x & 63;
-  const int ntile = (S + 31) >> 5;
-  for (int base = (threadIdx.x >> 6) * 64; base < ntile * 32; base += 64 * NW) {
-    const int key = base + lane;
-    const bool keep = key < S && (mask == nullptr || mask[b * S + key] != 0);
-    const unsigned long long bal = __ballot(keep);
-    if (lane == 0) {
-      kbits[base >> 5] = (unsigned)bal;
-      kbits[(base >> 5) + 1] = (unsigned)(bal >> 32);
-    }
-  }
+__device__ __forceinline__ void stage_keybias(float* kbias, const int64_t* mask, int64_t b, int S) {
+  const int n = (S + 31) & ~31;
+  for (int key = threadIdx.x; key < n; key += 64 * NW)
+    kbias[key] = key >= S ? -INFINITY : (mask == nullptr || mask[b * S + key] != 0) ? 0.f : kFill2;
 }
 
 // rows 4 a .. 4 a + 3 of accumulator block `x` (d = 32 db + 8 a + 4 hh ..) of the wave's row `row` -> bf16 (B, S, heads * HD)
@@ -179,12 +173,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_att_fwd(AttArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
   unsigned short* kt = lds;
   unsigned short* vt = lds + kChunk * G::PITCH;
-  unsigned* kbits = reinterpret_cast<unsigned*>(lds + 2 * kChunk * G::PITCH);
+  float* kbias = reinterpret_cast<float*>(lds + 2 * kChunk * G::PITCH);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r32 = lane & 31, hh = lane >> 5;
   const int64_t b = blockIdx.z;
   const int head = blockIdx.y, S = a.S, W = a.heads * HD;
   const int qrow = (blockIdx.x * NW + wave) * 32 + r32;
-  const int qlast = a.causal ? qrow : 0x40000000;     // last key the query may attend to
   const unsigned short* kbase = a.k + b * a.k_sb + head * HD;
   const unsigned short* vbase = a.v + b * a.v_sb + head * HD;
   Stage<HD, NW> sk, sv;                 // every global load of the prologue is in flight before the first wait
@@ -192,7 +185,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_att_fwd(AttArgs a) {
   sv.load(vbase, a.v_sr, 0, S);
   bf16x8 qf[G::NS];
   load_rows<HD>(qf, a.q + b * a.q_sb + head * HD, a.q_sr, qrow, S, hh);
-  stage_keybits<NW>(kbits, a.mask, b, S);
+  stage_keybias<NW>(kbias, a.mask, b, S);
   zero_pad_columns<HD, NW>(lds, 2);
   f32x16 o[G::NDB];
 #pragma unroll
@@ -200,10 +193,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_att_fwd(AttArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
   float m = -INFINITY, l = 0.f;
-  bool anykeep = false;
   const float c2 = a.scale * kLog2e;
   for (int kc = 0; kc < S; kc += kChunk) {
-    __syncthreads();                    // the previous chunk has been consumed (first pass: kbits are written)
+    __syncthreads();                    // the previous chunk has been consumed (first pass: the key biases are written)
     sk.store(kt);
     sv.store(vt);
     __syncthreads();
@@ -220,33 +212,39 @@ __global__ __launch_bounds__(64 * NW, 2) void k_att_fwd(AttArgs a) {
       for (int r = 0; r < 16; ++r) sc[r] = 0.f;
 #pragma unroll
       for (int s = 0; s < G::NS; ++s) sc = ATT_MFMA(row_frag<HD>(kt, 32 * t + r32, 2 * s + hh), qf[s], sc);
-      const unsigned bits = kbits[key0 >> 5];
       float tmax = -INFINITY;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kl = acc_row(r, hh), key = key0 + kl;
-        const bool keep = ((bits >> kl) & 1u) & (unsigned)(key <= qlast);    // bitwise: no control flow per element
-        anykeep |= keep;
-        const float sv = keep ? sc[r] * c2 : (key < S ? kFill2 : -INFINITY);
-        sc[r] = sv;
-        tmax = fmaxf(tmax, sv);
+      for (int a4 = 0; a4 < 4; ++a4) {
+        const f32x4 kb = *reinterpret_cast<const f32x4*>(kbias + key0 + 8 * a4 + 4 * hh);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float sv = fmaf(sc[4 * a4 + i], c2, kb[i]);       // fill + score rounds to the fill exactly
+          if (a.causal) sv = key0 + 8 * a4 + 4 * hh + i <= qrow ? sv : fminf(kb[i], kFill2);
+          sc[4 * a4 + i] = sv;
+          tmax = fmaxf(tmax, sv);
+        }
       }
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-      const float mn = fmaxf(m, tmax);
-      const float alpha = __builtin_amdgcn_exp2f(m - mn);
+      // lazy rescaling: the reference exponent m only follows the running maximum when that has grown by more than
+      // 2^kSlack (p stays below 2^kSlack, harmless in fp32 / bf16); most tiles then skip the rescaling of o and l
+      if (__builtin_amdgcn_ballot_w64(tmax > m + kSlack) != 0) {       // wave-uniform
+        const float mn = tmax > m + kSlack ? tmax : m;
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);
+        l *= alpha;
+        m = mn;
+#pragma unroll
+        for (int db = 0; db < G::NDB; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+      }
       float ps = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(sc[r] - mn);
+        const float p = __builtin_amdgcn_exp2f(sc[r] - m);
         sc[r] = p;
         ps += p;
       }
-      l = l * alpha + ps;
-      m = mn;
-#pragma unroll
-      for (int db = 0; db < G::NDB; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+      l += ps;
       const bf16x8 p0 = pack8(sc, 0), p1 = pack8(sc, 1);
 #pragma unroll
       for (int db = 0; db < G::NDB; ++db) {
@@ -256,7 +254,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_att_fwd(AttArgs a) {
     }
   }
   l += __shfl_xor(l, 32, 64);           // the two half-waves hold disjoint keys of the same query
-  anykeep = __shfl_xor((int)anykeep, 32, 64) || anykeep;
+  const bool anykeep = m > 0.5f * kFill2;           // the reference exponent of a query without valid keys is the fill
   if (qrow < S) {
     store_rows<HD>(a.out + (b * S + qrow) * W + head * HD, o, 1.f / l, hh);
     if (a.lse && hh == 0) a.lse[(b * a.heads + head) * S + qrow] = anykeep ? m + __builtin_amdgcn_logf(l) : INFINITY;
@@ -270,18 +268,17 @@ __global__ __launch_bounds__(64 * NW, 2) void k_att_bwd_dq(AttArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
   unsigned short* kt = lds;
   unsigned short* vt = lds + kChunk * G::PITCH;
-  unsigned* kbits = reinterpret_cast<unsigned*>(lds + 2 * kChunk * G::PITCH);
+  float* kbias = reinterpret_cast<float*>(lds + 2 * kChunk * G::PITCH);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r32 = lane & 31, hh = lane >> 5;
   const int64_t b = blockIdx.z;
   const int head = blockIdx.y, S = a.S, W = a.heads * HD;
   const int qrow = (blockIdx.x * NW + wave) * 32 + r32;
-  const int qlast = a.causal ? qrow : 0x40000000;     // last key the query may attend to
   const unsigned short* kbase = a.k + b * a.k_sb + head * HD;
   const unsigned short* vbase = a.v + b * a.v_sb + head * HD;
   Stage<HD, NW> sk, sv;
   sk.load(kbase, a.k_sr, 0, S);
   sv.load(vbase, a.v_sr, 0, S);
-  stage_keybits<NW>(kbits, a.mask, b, S);
+  stage_keybias<NW>(kbias, a.mask, b, S);
   zero_pad_columns<HD, NW>(lds, 2);
   bf16x8 qf[G::NS], dof[G::NS];
   load_rows<HD>(qf, a.q + b * a.q_sb + head * HD, a.q_sr, qrow, S, hh);
@@ -328,15 +325,18 @@ __global__ __launch_bounds__(64 * NW, 2) void k_att_bwd_dq(AttArgs a) {
         sc = ATT_MFMA(row_frag<HD>(kt, 32 * t + r32, 2 * s + hh), qf[s], sc);
         dp = ATT_MFMA(row_frag<HD>(vt, 32 * t + r32, 2 * s + hh), dof[s], dp);
       }
-      const unsigned bits = kbits[key0 >> 5];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kl = acc_row(r, hh);
-        const bool keep = ((bits >> kl) & 1u) & (unsigned)(key0 + kl <= qlast);
-        // branch-free: a masked score has exponent -inf.  A query without valid keys has lse2 = +inf: p = 0, and
-        // masked_fill passes no gradient to its scores anyway
-        const float x = keep ? fmaf(sc[r], c2, -lse2) : -INFINITY;
-        sc[r] = __builtin_amdgcn_exp2f(x) * (dp[r] - delta) * a.scale;
+      for (int a4 = 0; a4 < 4; ++a4) {
+        const f32x4 kb = *reinterpret_cast<const f32x4*>(kbias + key0 + 8 * a4 + 4 * hh);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * a4 + i;
+          // a masked key has exponent fill - lse2 (p = 0).  A query without valid keys has lse2 = +inf: p = 0, and
+          // masked_fill passes no gradient to its scores anyway.  The 1 / sqrt(d) of dS is applied at the store.
+          float x = fmaf(sc[r], c2, kb[i] - lse2);
+          if (a.causal) x = key0 + 8 * a4 + 4 * hh + i <= qrow ? x : -INFINITY;
+          sc[r] = __builtin_amdgcn_exp2f(x) * (dp[r] - delta);
+        }
       }
       const bf16x8 d0 = pack8(sc, 0), d1 = pack8(sc, 1);
 #pragma unroll
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_att_bwd_dq(AttArgs a) {
       }
     }
   }
-  if (qrow < S) store_rows<HD>(a.dq + (b * S + qrow) * W + head * HD, dq, 1.f, hh);
+  if (qrow < S) store_rows<HD>(a.dq + (b * S + qrow) * W + head * HD, dq, a.scale, hh);
 }
 
 // ---- backward, dK and dV: a wave owns 32 keys and walks the queries ------------------------------------------------
@@ -358,13 +358,14 @@ __global__ __launch_bounds__(64 * NW, HD == 128 ? 1 : 2) void k_att_bwd_dkv(AttA
   unsigned short* dt = lds + kChunk * G::PITCH;
   float* lses = reinterpret_cast<float*>(lds + 2 * kChunk * G::PITCH);   // [kChunk] lse2, [kChunk] delta
   float* dels = lses + kChunk;
+  float* fuls = dels + kChunk;                         // 1 / S for a query without valid keys, else 0
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r32 = lane & 31, hh = lane >> 5;
   const int64_t b = blockIdx.z;
   const int head = blockIdx.y, S = a.S, W = a.heads * HD;
   const int key = (blockIdx.x * NW + wave) * 32 + r32;
   const bool kok = key < S;
-  const int cbig = a.causal ? 0 : 0x40000000;
   const bool keepk = kok && (a.mask == nullptr || a.mask[b * S + key] != 0);
+  const float kbias = keepk ? 0.f : (kok ? kFill2 : -INFINITY);       // the lane's key: exponent bias
   bf16x8 kf[G::NS], vf[G::NS];
   load_rows<HD>(kf, a.k + b * a.k_sb + head * HD, a.k_sr, key, S, hh);
   load_rows<HD>(vf, a.v + b * a.v_sb + head * HD, a.v_sr, key, S, hh);
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(64 * NW, HD == 128 ? 1 : 2) void k_att_bwd_dkv(AttA
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
   const float c2 = a.scale * kLog2e;
-  const float p_full = kok ? 1.f / (float)S : 0.f;
+  const float inv_s = 1.f / (float)S;
   Stage<HD, NW> sq, sd;
   float pl = 0.f, pd = 0.f;             // lse2 / delta of chunk row threadIdx.x (the first kChunk threads)
   auto load_chunk = [&](int qc) {
@@ -394,7 +395,11 @@ __global__ __launch_bounds__(64 * NW, HD == 128 ? 1 : 2) void k_att_bwd_dkv(AttA
     __syncthreads();
     sq.store(qt);
     sd.store(dt);
-    if (threadIdx.x < kChunk) { lses[threadIdx.x] = pl; dels[threadIdx.x] = pd; }
+    if (threadIdx.x < kChunk) {
+      lses[threadIdx.x] = pl;
+      dels[threadIdx.x] = pd;
+      fuls[threadIdx.x] = pl == INFINITY ? inv_s : 0.f;
+    }
     __syncthreads();
     if (qc + kChunk < S) load_chunk(qc + kChunk);
 #pragma unroll
@@ -413,14 +418,15 @@ __global__ __launch_bounds__(64 * NW, HD == 128 ? 1 : 2) void k_att_bwd_dkv(AttA
       for (int a4 = 0; a4 < 4; ++a4) {
         const f32x4 L = *reinterpret_cast<const f32x4*>(lses + 32 * t + 8 * a4 + 4 * hh);
         const f32x4 D = *reinterpret_cast<const f32x4*>(dels + 32 * t + 8 * a4 + 4 * hh);
+        const f32x4 F = *reinterpret_cast<const f32x4*>(fuls + 32 * t + 8 * a4 + 4 * hh);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int r = 4 * a4 + i;
-          const bool keep = keepk & (key <= q0 + 8 * a4 + 4 * hh + i + cbig);
-          const float x = keep ? fmaf(sc[r], c2, -L[i]) : -INFINITY;       // branch-free masking
+          float x = fmaf(sc[r], c2, kbias - L[i]);         // masked key: fill - lse2 -> p = 0
+          if (a.causal) x = key <= q0 + 8 * a4 + 4 * hh + i ? x : -INFINITY;
           const float p = __builtin_amdgcn_exp2f(x);
-          dp[r] = p * (dp[r] - D[i]) * a.scale;
-          sc[r] = L[i] == INFINITY ? p_full : p;           // query without a valid key: uniform over all S keys
+          dp[r] = p * (dp[r] - D[i]);                      // dS without its 1 / sqrt(d): applied at the store
+          sc[r] = p + F[i];                                // query without a valid key: p = 0 + uniform 1 / S
         }
       }
       const bf16x8 p0 = pack8(sc, 0), p1 = pack8(sc, 1), d0 = pack8(dp, 0), d1 = pack8(dp, 1);
@@ -434,21 +440,22 @@ __global__ __launch_bounds__(64 * NW, HD == 128 ? 1 : 2) void k_att_bwd_dkv(AttA
     }
   }
   if (kok) {
-    store_rows<HD>(a.dk + (b * S + key) * W + head * HD, dk, 1.f, hh);
+    store_rows<HD>(a.dk + (b * S + key) * W + head * HD, dk, a.scale, hh);
     store_rows<HD>(a.dv + (b * S + key) * W + head * HD, dv, 1.f, hh);
   }
 }
 
 template <int HD>
-size_t lds_bytes() {
-  return (size_t)2 * kChunk * Geo<HD>::PITCH * 2 + (kMaxTiles + 2) * 4 + 2 * kChunk * 4;
+size_t lds_bytes(int S) {     // two operand tiles + the key biases (forward, dQ) or the three per-query rows (dK / dV)
+  const size_t tail = (size_t)((S + 31) & ~31) * 4;
+  return (size_t)2 * kChunk * Geo<HD>::PITCH * 2 + (tail > 3 * kChunk * 4 ? tail : 3 * kChunk * 4);
 }
 
 template <int HD, int NW>
 void launch_nw(const AttArgs& a, int64_t B, int which, hipStream_t st) {
   const int tiles = (a.S + 31) / 32;
   const dim3 grid((tiles + NW - 1) / NW, a.heads, (unsigned)B), block(64 * NW);
-  const size_t lds = lds_bytes<HD>();
+  const size_t lds = lds_bytes<HD>(a.S);
   if (which == 0) hipLaunchKernelGGL((k_att_fwd<HD, NW>), grid, block, lds, st, a);
   else if (which == 1) hipLaunchKernelGGL((k_att_bwd_dq<HD, NW>), grid, block, lds, st, a);
   else hipLaunchKernelGGL((k_att_bwd_dkv<HD, NW>), grid, block, lds, st, a);
