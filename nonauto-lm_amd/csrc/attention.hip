@@ -166,6 +166,22 @@ __device__ __forceinline__ void store_rows(unsigned short* dst, const f32x16 (&x
 
 #define ATT_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, c_, 0, 0, 0)
 
+// Issue order of a run of N products whose A operands each take DS LDS reads: the compiler's own order is
+// read, wait, multiply per product, which exposes the whole LDS latency N times (a wave alone on its SIMD in the
+// hd-128 dK / dV kernel has nothing else to run).  Keep the reads two products ahead of the matrix core instead.
+template <int N, int DS>
+__device__ __forceinline__ void products_pipelined() {
+  if (N > 2) {
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * DS, 0);
+#pragma unroll
+    for (int i = 0; i < N - 2; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, DS, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+  }
+}
+
 // ---- forward: a wave owns 32 queries and walks the keys ---------------------------------------------------------
 template <int HD, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void k_att_fwd(AttArgs a) {
@@ -212,6 +228,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_att_fwd(AttArgs a) {
       for (int r = 0; r < 16; ++r) sc[r] = 0.f;
 #pragma unroll
       for (int s = 0; s < G::NS; ++s) sc = ATT_MFMA(row_frag<HD>(kt, 32 * t + r32, 2 * s + hh), qf[s], sc);
+      products_pipelined<G::NS, 1>();
+      __builtin_amdgcn_sched_barrier(0);
       float tmax = -INFINITY;
 #pragma unroll
       for (int a4 = 0; a4 < 4; ++a4) {
@@ -246,11 +264,14 @@ __global__ __launch_bounds__(64 * NW, 2) void k_att_fwd(AttArgs a) {
       }
       l += ps;
       const bf16x8 p0 = pack8(sc, 0), p1 = pack8(sc, 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int db = 0; db < G::NDB; ++db) {
         o[db] = ATT_MFMA(tr_frag<HD>(vt, 32 * t, db, lane), p0, o[db]);
         o[db] = ATT_MFMA(tr_frag<HD>(vt, 32 * t + 16, db, lane), p1, o[db]);
       }
+      products_pipelined<2 * G::NDB, 2>();
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   l += __shfl_xor(l, 32, 64);           // the two half-waves hold disjoint keys of the same query
@@ -325,6 +346,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_att_bwd_dq(AttArgs a) {
         sc = ATT_MFMA(row_frag<HD>(kt, 32 * t + r32, 2 * s + hh), qf[s], sc);
         dp = ATT_MFMA(row_frag<HD>(vt, 32 * t + r32, 2 * s + hh), dof[s], dp);
       }
+      products_pipelined<2 * G::NS, 1>();
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int a4 = 0; a4 < 4; ++a4) {
         const f32x4 kb = *reinterpret_cast<const f32x4*>(kbias + key0 + 8 * a4 + 4 * hh);
@@ -339,11 +362,14 @@ __global__ __launch_bounds__(64 * NW, 2) void k_att_bwd_dq(AttArgs a) {
         }
       }
       const bf16x8 d0 = pack8(sc, 0), d1 = pack8(sc, 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int db = 0; db < G::NDB; ++db) {
         dq[db] = ATT_MFMA(tr_frag<HD>(kt, 32 * t, db, lane), d0, dq[db]);
         dq[db] = ATT_MFMA(tr_frag<HD>(kt, 32 * t + 16, db, lane), d1, dq[db]);
       }
+      products_pipelined<2 * G::NDB, 2>();
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   if (qrow < S) store_rows<HD>(a.dq + (b * S + qrow) * W + head * HD, dq, a.scale, hh);
@@ -414,6 +440,8 @@ __global__ __launch_bounds__(64 * NW, HD == 128 ? 1 : 2) void k_att_bwd_dkv(AttA
         sc = ATT_MFMA(row_frag<HD>(qt, 32 * t + r32, 2 * s + hh), kf[s], sc);
         dp = ATT_MFMA(row_frag<HD>(dt, 32 * t + r32, 2 * s + hh), vf[s], dp);
       }
+      products_pipelined<2 * G::NS, 1>();
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int a4 = 0; a4 < 4; ++a4) {
         const f32x4 L = *reinterpret_cast<const f32x4*>(lses + 32 * t + 8 * a4 + 4 * hh);
@@ -430,6 +458,7 @@ __global__ __launch_bounds__(64 * NW, HD == 128 ? 1 : 2) void k_att_bwd_dkv(AttA
         }
       }
       const bf16x8 p0 = pack8(sc, 0), p1 = pack8(sc, 1), d0 = pack8(dp, 0), d1 = pack8(dp, 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int db = 0; db < G::NDB; ++db) {
         dv[db] = ATT_MFMA(tr_frag<HD>(dt, 32 * t, db, lane), p0, dv[db]);
@@ -437,6 +466,8 @@ __global__ __launch_bounds__(64 * NW, HD == 128 ? 1 : 2) void k_att_bwd_dkv(AttA
         dk[db] = ATT_MFMA(tr_frag<HD>(qt, 32 * t, db, lane), d0, dk[db]);
         dk[db] = ATT_MFMA(tr_frag<HD>(qt, 32 * t + 16, db, lane), d1, dk[db]);
       }
+      products_pipelined<4 * G::NDB, 2>();
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   if (kok) {
