@@ -476,6 +476,149 @@ __global__ __launch_bounds__(64 * NW, HD == 128 ? 1 : 2) void k_att_bwd_dkv(AttA
   }
 }
 
+// ---- backward for S <= 64 (head sizes up to 64): one launch, one staging --------------------------------------------
+// Q, K, V and dO of a (batch, head) fit one LDS tile each; wave w first plays the dQ kernel's part for queries
+// 32 w .. 32 w + 31, then, after one barrier (delta goes through LDS, not HBM), the dK / dV kernel's part for the same
+// keys.  At BASELINE config 2 (S = 64, d = 16) the two-kernel backward is launch- and latency-bound (8 + 9 us for 2 MB).
+template <int HD, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void k_att_bwd_small(AttArgs a) {
+  using G = Geo<HD>;
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  constexpr int T = kChunk * G::PITCH;
+  unsigned short *qt = lds, *kt = lds + T, *vt = lds + 2 * T, *dt = lds + 3 * T;
+  float* kb = reinterpret_cast<float*>(lds + 4 * T);   // [kChunk] key bias, lse2, delta, uniform weight
+  float* lses = kb + kChunk;
+  float* dels = lses + kChunk;
+  float* fuls = dels + kChunk;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r32 = lane & 31, hh = lane >> 5;
+  const int64_t b = blockIdx.z;
+  const int head = blockIdx.y, S = a.S, W = a.heads * HD;
+  const int row = wave * 32 + r32;      // the lane's query in the first phase, its key in the second
+  Stage<HD, NW> sq, sk, sv, sd;
+  sq.load(a.q + b * a.q_sb + head * HD, a.q_sr, 0, S);
+  sk.load(a.k + b * a.k_sb + head * HD, a.k_sr, 0, S);
+  sv.load(a.v + b * a.v_sb + head * HD, a.v_sr, 0, S);
+  sd.load(a.dout + b * S * W + head * HD, W, 0, S);
+  bf16x8 of[G::NS];
+  load_rows<HD>(of, a.out + b * S * W + head * HD, W, row, S, hh);
+  if (threadIdx.x < kChunk) {           // 64 * NW >= kChunk threads
+    const int r = threadIdx.x;
+    const bool ok = r < S;
+    const float l = ok ? a.lse[(b * a.heads + head) * S + r] : 0.f;
+    lses[r] = l;
+    fuls[r] = l == INFINITY ? 1.f / (float)S : 0.f;
+    kb[r] = !ok ? -INFINITY : (a.mask == nullptr || a.mask[b * S + r] != 0) ? 0.f : kFill2;
+  }
+  zero_pad_columns<HD, NW>(lds, 4);
+  sq.store(qt);
+  sk.store(kt);
+  sv.store(vt);
+  sd.store(dt);
+  __syncthreads();
+  const float c2 = a.scale * kLog2e;
+  {                                     // ---- dQ of queries 32 w .. (k_att_bwd_dq's tile body)
+    bf16x8 qf[G::NS], dof[G::NS];
+    float delta = 0.f;
+#pragma unroll
+    for (int s = 0; s < G::NS; ++s) {
+      qf[s] = row_frag<HD>(qt, row, 2 * s + hh);
+      dof[s] = row_frag<HD>(dt, row, 2 * s + hh);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) delta += (float)dof[s][j] * (float)of[s][j];
+    }
+    delta += __shfl_xor(delta, 32, 64);
+    if (hh == 0) dels[row] = delta;     // rows beyond S: dO = O = 0
+    const float lse2 = lses[row];
+    f32x16 dq[G::NDB];
+#pragma unroll
+    for (int db = 0; db < G::NDB; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NW; ++t) {
+      f32x16 sc, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < G::NS; ++s) {
+        sc = ATT_MFMA(row_frag<HD>(kt, 32 * t + r32, 2 * s + hh), qf[s], sc);
+        dp = ATT_MFMA(row_frag<HD>(vt, 32 * t + r32, 2 * s + hh), dof[s], dp);
+      }
+#pragma unroll
+      for (int a4 = 0; a4 < 4; ++a4) {
+        const f32x4 kbv = *reinterpret_cast<const f32x4*>(kb + 32 * t + 8 * a4 + 4 * hh);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * a4 + i;
+          float x = fmaf(sc[r], c2, kbv[i] - lse2);
+          if (a.causal) x = 32 * t + 8 * a4 + 4 * hh + i <= row ? x : -INFINITY;
+          sc[r] = __builtin_amdgcn_exp2f(x) * (dp[r] - delta);
+        }
+      }
+      const bf16x8 d0 = pack8(sc, 0), d1 = pack8(sc, 1);
+#pragma unroll
+      for (int db = 0; db < G::NDB; ++db) {
+        dq[db] = ATT_MFMA(tr_frag<HD>(kt, 32 * t, db, lane), d0, dq[db]);
+        dq[db] = ATT_MFMA(tr_frag<HD>(kt, 32 * t + 16, db, lane), d1, dq[db]);
+      }
+    }
+    if (row < S) store_rows<HD>(a.dq + (b * S + row) * W + head * HD, dq, a.scale, hh);
+  }
+  __syncthreads();                      // every delta is in LDS
+  {                                     // ---- dK, dV of keys 32 w .. (k_att_bwd_dkv's tile body)
+    bf16x8 kf[G::NS], vf[G::NS];
+#pragma unroll
+    for (int s = 0; s < G::NS; ++s) {
+      kf[s] = row_frag<HD>(kt, row, 2 * s + hh);
+      vf[s] = row_frag<HD>(vt, row, 2 * s + hh);
+    }
+    const float kbias = kb[row];
+    f32x16 dk[G::NDB], dv[G::NDB];
+#pragma unroll
+    for (int db = 0; db < G::NDB; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+#pragma unroll
+    for (int t = 0; t < NW; ++t) {
+      f32x16 sc, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < G::NS; ++s) {
+        sc = ATT_MFMA(row_frag<HD>(qt, 32 * t + r32, 2 * s + hh), kf[s], sc);
+        dp = ATT_MFMA(row_frag<HD>(dt, 32 * t + r32, 2 * s + hh), vf[s], dp);
+      }
+#pragma unroll
+      for (int a4 = 0; a4 < 4; ++a4) {
+        const f32x4 L = *reinterpret_cast<const f32x4*>(lses + 32 * t + 8 * a4 + 4 * hh);
+        const f32x4 D = *reinterpret_cast<const f32x4*>(dels + 32 * t + 8 * a4 + 4 * hh);
+        const f32x4 F = *reinterpret_cast<const f32x4*>(fuls + 32 * t + 8 * a4 + 4 * hh);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * a4 + i;
+          float x = fmaf(sc[r], c2, kbias - L[i]);
+          if (a.causal) x = row <= 32 * t + 8 * a4 + 4 * hh + i ? x : -INFINITY;
+          const float p = __builtin_amdgcn_exp2f(x);
+          dp[r] = p * (dp[r] - D[i]);
+          sc[r] = p + F[i];
+        }
+      }
+      const bf16x8 p0 = pack8(sc, 0), p1 = pack8(sc, 1), d0 = pack8(dp, 0), d1 = pack8(dp, 1);
+#pragma unroll
+      for (int db = 0; db < G::NDB; ++db) {
+        dv[db] = ATT_MFMA(tr_frag<HD>(dt, 32 * t, db, lane), p0, dv[db]);
+        dv[db] = ATT_MFMA(tr_frag<HD>(dt, 32 * t + 16, db, lane), p1, dv[db]);
+        dk[db] = ATT_MFMA(tr_frag<HD>(qt, 32 * t, db, lane), d0, dk[db]);
+        dk[db] = ATT_MFMA(tr_frag<HD>(qt, 32 * t + 16, db, lane), d1, dk[db]);
+      }
+    }
+    if (row < S) {
+      store_rows<HD>(a.dk + (b * S + row) * W + head * HD, dk, a.scale, hh);
+      store_rows<HD>(a.dv + (b * S + row) * W + head * HD, dv, 1.f, hh);
+    }
+  }
+}
+
 template <int HD>
 size_t lds_bytes(int S) {     // two operand tiles + the key biases (forward, dQ) or the three per-query rows (dK / dV)
   const size_t tail = (size_t)((S + 31) & ~31) * 4;
@@ -490,6 +633,25 @@ void launch_nw(const AttArgs& a, int64_t B, int which, hipStream_t st) {
   if (which == 0) hipLaunchKernelGGL((k_att_fwd<HD, NW>), grid, block, lds, st, a);
   else if (which == 1) hipLaunchKernelGGL((k_att_bwd_dq<HD, NW>), grid, block, lds, st, a);
   else hipLaunchKernelGGL((k_att_bwd_dkv<HD, NW>), grid, block, lds, st, a);
+}
+
+template <int HD, int NW>
+void launch_small(const AttArgs& a, int64_t B, hipStream_t st) {
+  const size_t lds = (size_t)4 * kChunk * Geo<HD>::PITCH * 2 + 4 * kChunk * 4;
+  hipLaunchKernelGGL((k_att_bwd_small<HD, NW>), dim3(1, a.heads, (unsigned)B), dim3(64 * NW), lds, st, a);
+}
+
+// S <= 64 and head size <= 64: the one-launch backward
+bool dispatch_small(const AttArgs& a, int64_t B, int hd, hipStream_t st) {
+  if (a.S > kChunk || hd > 64) return false;
+  const bool one = a.S <= 32;
+  switch (hd) {
+    case 16: one ? launch_small<16, 1>(a, B, st) : launch_small<16, 2>(a, B, st); break;
+    case 32: one ? launch_small<32, 1>(a, B, st) : launch_small<32, 2>(a, B, st); break;
+    case 64: one ? launch_small<64, 1>(a, B, st) : launch_small<64, 2>(a, B, st); break;
+    default: return false;
+  }
+  return true;
 }
 
 template <int HD>
@@ -581,6 +743,10 @@ int mivae_attention_bwd(const void* q, const void* k, const void* v, const int64
   a.dq = static_cast<unsigned short*>(dq);
   a.dk = static_cast<unsigned short*>(dk);
   a.dv = static_cast<unsigned short*>(dv);
+  if (dispatch_small(a, B, (int)head_size, S_(stream))) {
+    MIVAE_CHECK_LAUNCH("mivae_attention_bwd (one launch)");
+    return MIVAE_OK;
+  }
   dispatch(a, B, (int)head_size, 1, S_(stream));
   MIVAE_CHECK_LAUNCH("mivae_attention_bwd (dq)");
   dispatch(a, B, (int)head_size, 2, S_(stream));
