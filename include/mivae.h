@@ -368,6 +368,11 @@ int mivae_lce_bwd_dh(const void* h, const void* W, const void* Wtp, const int64_
  * bias (Fo) or NULL, y (N, Fo); Fi, Fo in {32, 64, 128, 256}. */
 int mivae_linear_fwd(const void* x, const void* w, const void* bias, void* y, int64_t N, int64_t Fi, int64_t Fo,
                      void* stream);
+/* out (N, Fo) = res + bf16(x w^T + bias), the sum formed in res's dtype (fp32 or bf16) exactly as torch forms
+ * `res + linear(x)` under bf16 autocast: the output projection of MultiHeadAttention inside SublayerConnection
+ * (nn/transformer.py:116-117 + 160-162) with the residual add as the product's epilogue. */
+int mivae_linear_fwd_residual(const void* x, const void* w, const void* bias, const void* res, void* out, int64_t N,
+                              int64_t Fi, int64_t Fo, int res_dtype, void* stream);
 /* dx (N, Fi) = dy (N, Fo) w  (autograd of the above w.r.t. x). */
 int mivae_linear_dgrad(const void* dy, const void* w, void* dx, int64_t N, int64_t Fi, int64_t Fo, void* stream);
 /* partial (mivae_linear_wgrad_rows(N), Fo*Fi + Fo) fp32: per-wave [dy^T x | colsum dy]; its column sums

@@ -73,6 +73,7 @@ SIGNATURES = {
     "mivae_lce_fwd": [P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P],
     "mivae_lce_bwd": [P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P],
     "mivae_linear_fwd": [P, P, P, P, I64, I64, I64, P],
+    "mivae_linear_fwd_residual": [P, P, P, P, P, I64, I64, I64, I32, P],
     "mivae_linear_dgrad": [P, P, P, I64, I64, I64, P],
     "mivae_linear_wgrad_rows": [I64],
     "mivae_colsum_sink_multi": [P, I64, I64, P],

@@ -31,6 +31,9 @@ struct LinArgs {
   const unsigned short* bias[kMaxGroup];  // (Fo) bf16 or null (fwd only)
   unsigned short* y[kMaxGroup];           // fwd: y_g (N, Fo); dgrad: y[0] = dx (N, Fi)
   const unsigned short* relu_src;         // dgrad only, optional (N, Fi): dx is zeroed where relu_src <= 0 (relu')
+  const void* res;                        // fwd only, optional (N, Fo) residual: out = res + bf16(x W^T + b), in res's dtype
+  void* out;                              //   (N, Fo) fp32 or bf16, written instead of y[0]
+  int res_f32;
   int64_t N;
   int Fo, Fi, G;
 };
@@ -104,6 +107,20 @@ __global__ __launch_bounds__(256) void k_lin(LinArgs a) {
           const u16x4 r = *reinterpret_cast<const u16x4*>(a.relu_src + tok * M + 32 * c + 4 * hh + 8 * q);
 #pragma unroll
           for (int i = 0; i < 4; ++i) o[i] = (r[i] == 0 || (r[i] & 0x8000)) ? (unsigned short)0 : o[i];
+        }
+        if (!TRANS && a.res) {              // residual epilogue: the sum torch forms from the rounded bf16 product
+          const int64_t at = tok * M + 32 * c + 4 * hh + 8 * q;
+          if (a.res_f32) {
+            const f32x4 r = *reinterpret_cast<const f32x4*>(static_cast<const float*>(a.res) + at);
+            const f32x4 v = {r[0] + bf16_to_f32(o[0]), r[1] + bf16_to_f32(o[1]), r[2] + bf16_to_f32(o[2]), r[3] + bf16_to_f32(o[3])};
+            *reinterpret_cast<f32x4*>(static_cast<float*>(a.out) + at) = v;
+          } else {
+            const u16x4 r = *reinterpret_cast<const u16x4*>(static_cast<const unsigned short*>(a.res) + at);
+            const u16x4 v = {f32_to_bf16(bf16_to_f32(r[0]) + bf16_to_f32(o[0])), f32_to_bf16(bf16_to_f32(r[1]) + bf16_to_f32(o[1])),
+                             f32_to_bf16(bf16_to_f32(r[2]) + bf16_to_f32(o[2])), f32_to_bf16(bf16_to_f32(r[3]) + bf16_to_f32(o[3]))};
+            *reinterpret_cast<u16x4*>(static_cast<unsigned short*>(a.out) + at) = v;
+          }
+          continue;
         }
         *reinterpret_cast<u16x4*>(yp + 8 * q) = o;
       }
@@ -465,6 +482,26 @@ extern "C" int mivae_linear_fwd(const void* x, const void* w, const void* bias, 
   a.y[0] = (unsigned short*)y; a.N = N; a.Fo = (int)Fo; a.Fi = (int)Fi; a.G = 1;
   MIVAE_REQUIRE(lin_launch<false>(a, (int)Fi, (int)Fo, S_(stream)) == 0, "linear_fwd: no kernel instance");
   MIVAE_CHECK_LAUNCH("linear_fwd");
+  return MIVAE_OK;
+}
+
+// out (N, Fo) = res + bf16(x W^T + b): the projection that closes a pre-norm residual sublayer, sum in res's dtype.
+extern "C" int mivae_linear_fwd_residual(const void* x, const void* w, const void* bias, const void* res, void* out,
+                                         int64_t N, int64_t Fi, int64_t Fo, int res_dtype, void* stream) {
+  MIVAE_REQUIRE(N >= 0 && N < (1ll << 31), "linear_fwd_residual: bad N");
+  MIVAE_REQUIRE(lin_dim_ok(Fi) && lin_dim_ok(Fo), "linear_fwd_residual: features must be 32, 64, 128 or 256 (Fi=%lld Fo=%lld)",
+                (long long)Fi, (long long)Fo);
+  MIVAE_REQUIRE(res_dtype == MIVAE_F32 || res_dtype == MIVAE_BF16, "linear_fwd_residual: bad residual dtype %d", res_dtype);
+  if (N == 0) return MIVAE_OK;
+  MIVAE_REQUIRE(x && w && res && out, "linear_fwd_residual: null pointer");
+  MIVAE_REQUIRE(aligned16(x) && aligned16(w) && aligned16(res) && aligned16(out),
+                "linear_fwd_residual: operands must be 16-byte aligned");
+  LinArgs a = {};
+  a.x[0] = (const unsigned short*)x; a.w[0] = (const unsigned short*)w; a.bias[0] = (const unsigned short*)bias;
+  a.y[0] = (unsigned short*)out; a.res = res; a.out = out; a.res_f32 = res_dtype == MIVAE_F32;
+  a.N = N; a.Fo = (int)Fo; a.Fi = (int)Fi; a.G = 1;
+  MIVAE_REQUIRE(lin_launch<false>(a, (int)Fi, (int)Fo, S_(stream)) == 0, "linear_fwd_residual: no kernel instance");
+  MIVAE_CHECK_LAUNCH("linear_fwd_residual");
   return MIVAE_OK;
 }
 

@@ -128,6 +128,25 @@ class _ReluLinearFn(torch.autograd.Function):
         return _SplitKLinearFn.backward(ctx, gy)
 
 
+class _LinearResidualFn(torch.autograd.Function):
+    """res + (x W^T + b) for a small bf16 layer: the residual add is the epilogue of the libmivae product (the same sum
+    torch forms from the bf16-rounded product); the backward is `_SplitKLinearFn`'s plus the pass-through to `res`."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, w_lp, b_lp, res):       # argument order of _SplitKLinearFn, the residual last
+        ctx.has_bias, ctx.param_dtype, ctx.params, ctx.small = True, weight.dtype, (weight, bias), True
+        x2 = x.contiguous().view(-1, x.size(-1))
+        ctx.save_for_backward(x2, w_lp)
+        ctx.xshape = x.shape
+        return ops.linear_fwd_residual(x2, w_lp, b_lp, res.contiguous().view(-1, w_lp.size(0))).view(res.shape)
+
+    @staticmethod
+    def backward(ctx, gy):
+        g16 = gy if gy.dtype == torch.bfloat16 else gy.to(torch.bfloat16)    # the cast autograd makes for `res + y`
+        gx, gw, gb, _, _ = _SplitKLinearFn.backward(ctx, g16)
+        return gx, gw, gb, None, None, (gy if ctx.needs_input_grad[5] else None)
+
+
 class Linear(torch.nn.Linear):
     """torch.nn.Linear (same parameters / state-dict keys) whose backward splits the token axis of
     the weight-gradient GEMM when there are many tokens and few features."""
@@ -147,6 +166,18 @@ class Linear(torch.nn.Linear):
                 return _SplitKLinearFn.apply(x.to(dt), self.weight, self.bias, w_lp, b_lp)
             return _SplitKLinearFn.apply(x, self.weight, self.bias, None, None)
         return super().forward(x)
+
+    def forward_residual(self, x, res):
+        """res + self(x); for a small layer on the bf16-autocast training route the add is the product's epilogue."""
+        if (x.is_cuda and torch.is_grad_enabled() and x.dtype == torch.bfloat16 and self.bias is not None
+                and x.numel() // x.size(-1) >= 4096 and torch.is_autocast_enabled()
+                and torch.get_autocast_dtype("cuda") == torch.bfloat16
+                and res.dtype in (torch.float32, torch.bfloat16) and res.is_cuda
+                and res.shape == (*x.shape[:-1], self.out_features)):
+            w_lp, b_lp = _lp(self.weight), _lp(self.bias)
+            if ops.linear_small_supported(x, w_lp):
+                return _LinearResidualFn.apply(x, self.weight, self.bias, w_lp, b_lp, res)
+        return res + self(x)
 
     def forward_relu(self, x):
         """relu(self(x)); on the wide bf16-autocast training route bias + ReLU are the GEMM's epilogue."""
@@ -398,7 +429,11 @@ class MultiHeadAttention(torch.nn.Module):
                     and ops.attention_shape_supported(x.size(0), x.size(1), self._num_heads * self._attn_size,
                                                       self._num_heads))
 
-    def forward(self, query, key, value, mask=None, attn_bias=None):
+    def _project_out(self, t, residual):
+        return self._output(t) if residual is None else self._output.forward_residual(t, residual)
+
+    def forward(self, query, key, value, mask=None, attn_bias=None, residual=None):
+        """`residual` (optional): returns residual + attention(...), the add folded into the output projection"""
         if query is key and key is value:        # self-attention: the three projections share their input
             q, k, v = linear_group(query, [self._projections[n] for n in ("query", "key", "value")])
         else:
@@ -408,7 +443,7 @@ class MultiHeadAttention(torch.nn.Module):
         if (q.dtype == torch.bfloat16 and q.shape == k.shape and k.shape == v.shape and self.kernel_ok(q, mask)):
             # scores, reference fill (-1e13), softmax and probs @ v per head in libmivae's kernels, straight on the
             # (B, S, heads * d) projections (no head transposes, no bias tensor)
-            return self._output(ops.attention(q, k, v, mask, self._num_heads, self._mask_tril))
+            return self._project_out(ops.attention(q, k, v, mask, self._num_heads, self._mask_tril), residual)
         q, k, v = self._split(q), self._split(k), self._split(v)
         S = q.size(2)
         if (USE_FUSED_ATTENTION and q.is_cuda and q.dtype == torch.bfloat16 and torch.is_autocast_enabled()
@@ -422,7 +457,7 @@ class MultiHeadAttention(torch.nn.Module):
                 out = F.scaled_dot_product_attention(q, k, v, attn_mask=ops.attention_bias(mask, self._mask_tril, q.dtype))
             else:
                 out = F.scaled_dot_product_attention(q, k, v, is_causal=self._mask_tril)
-            return self._output(out.transpose(1, 2).reshape(q.size(0), S, -1))
+            return self._project_out(out.transpose(1, 2).reshape(q.size(0), S, -1), residual)
         scores = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(self._attn_size)
         if mask is None:
             keep = torch.ones(q.size(0), 1, 1, S, dtype=torch.bool, device=q.device)
@@ -433,7 +468,7 @@ class MultiHeadAttention(torch.nn.Module):
         scores = scores.masked_fill(~keep, self._fill)
         probs = self._dropout(torch.softmax(scores, dim=-1))
         out = torch.matmul(probs, v).transpose(1, 2).reshape(q.size(0), S, -1)
-        return self._output(out)
+        return self._project_out(out, residual)
 
 
 class PositionwiseFeedForward(torch.nn.Module):
@@ -478,14 +513,21 @@ class SublayerConnection(torch.nn.Module):
         self._norm = LayerNorm(input_size)
         self._dropout = _maybe_dropout(dropout)
 
-    def forward(self, x, sublayer):
+    def forward(self, x, sublayer, residual_aware=False):
+        """`residual_aware`: `sublayer(xn, residual)` returns residual + f(xn) itself (used when the dropout is inactive,
+        so that the add can ride on the sublayer's last product)"""
         norm = self._norm
+        fold = residual_aware and not (self.training and isinstance(self._dropout, torch.nn.Dropout) and self._dropout.p > 0)
         if isinstance(norm, LayerNorm) and torch.is_grad_enabled() and x.requires_grad:
             out_dtype = norm.kernel_dtype(x)
             if out_dtype is not None:
                 # training: the residual branch's gradient is folded into the LayerNorm backward kernel (no add launch)
                 res, xn = ops.layer_norm_residual(x, norm.weight, norm.bias, norm.eps, out_dtype)
+                if fold:
+                    return sublayer(xn, res)
                 return res + self._dropout(sublayer(xn))
+        if fold:
+            return sublayer(norm(x), x)
         return x + self._dropout(sublayer(norm(x)))
 
 
@@ -532,7 +574,8 @@ class _TransformerLayer(torch.nn.Module):
         return ops.attention_bias(mask, self._attn._mask_tril, torch.bfloat16)
 
     def forward(self, x, mask, attn_bias=None):
-        x = self._sublayers["attn"](x, lambda y: self._attn(y, y, y, mask, attn_bias))
+        x = self._sublayers["attn"](x, lambda y, r=None: self._attn(y, y, y, mask, attn_bias, residual=r),
+                                    residual_aware=True)
         sub = self._sublayers["pos_ffn"]
         if USE_FUSED_FFN and ffn_block_supported(x, sub._norm, self._pos_ffn, sub):
             f = self._pos_ffn

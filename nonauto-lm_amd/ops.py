@@ -980,6 +980,17 @@ def linear_fwd(x2, w16, b16):
     return y
 
 
+def linear_fwd_residual(x2, w16, b16, res2):
+    """res2 + (x2 w16^T + b16) for x2 (N, Fi) bf16 and a residual (N, Fo) fp32 / bf16, the add as the product's epilogue
+    (the same sum torch forms from the bf16-rounded product)."""
+    N, Fi = x2.shape
+    Fo = w16.size(0)
+    out = torch.empty_like(res2)
+    L.call("mivae_linear_fwd_residual", L.ptr(x2), L.ptr(w16), L.ptr(b16), L.ptr(res2), L.ptr(out), N, Fi, Fo,
+           L.dtype_code(res2.dtype), L.stream())
+    return out
+
+
 def linear_dgrad(g2, w16):
     N, Fo = g2.shape
     Fi = w16.size(1)

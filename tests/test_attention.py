@@ -129,3 +129,25 @@ def test_multi_head_attention_module_uses_kernels_and_matches_explicit_path(caus
     assert (g1 - g0).abs().max() <= 3e-2 * max(g0.abs().max().item(), 1.0)
     for a, b in zip(p1, p0):
         assert (a - b).abs().max() <= 3e-2 * max(b.abs().max().item(), 1.0)
+
+
+@pytest.mark.parametrize("res_dtype", [torch.float32, torch.bfloat16])
+def test_linear_residual_epilogue_bit_equal(res_dtype):
+    """Linear.forward_residual (residual add as the epilogue of the libmivae product) == res + layer(x) bit for bit,
+    same gradients (the transformer layer's attention sublayer uses it for its output projection)"""
+    from nonauto_lm_amd import nn_bracket as nb
+    torch.manual_seed(5)
+    lin = nb.Linear(64, 64).cuda()
+    x = torch.randn(64, 64, 64, device="cuda").to(torch.bfloat16)
+    res = torch.randn(64, 64, 64, device="cuda").to(res_dtype)
+    outs = []
+    for fused in (True, False):
+        lin.zero_grad(set_to_none=True)
+        xx, rr = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = lin.forward_residual(xx, rr) if fused else rr + lin(xx)
+        assert y.dtype == res_dtype
+        y.float().square().sum().backward()
+        outs.append((y, xx.grad, rr.grad, lin.weight.grad.clone(), lin.bias.grad.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
