@@ -477,11 +477,13 @@ __global__ __launch_bounds__(64 * NW, HD == 128 ? 1 : 2) void k_att_bwd_dkv(AttA
 }
 
 // ---- backward for S <= 64 (head sizes up to 64): one launch, one staging --------------------------------------------
-// Q, K, V and dO of a (batch, head) fit one LDS tile each; wave w first plays the dQ kernel's part for queries
-// 32 w .. 32 w + 31, then, after one barrier (delta goes through LDS, not HBM), the dK / dV kernel's part for the same
-// keys.  At BASELINE config 2 (S = 64, d = 16) the two-kernel backward is launch- and latency-bound (8 + 9 us for 2 MB).
+// Q, K, V and dO of a (batch, head) fit one LDS tile each; the block is 2 NW waves: waves 0 .. NW - 1 play the dQ
+// kernel's part for queries 32 w .. 32 w + 31 while waves NW .. 2 NW - 1 play the dK / dV kernel's part for the same
+// keys, side by side after the single barrier (delta = rowsum(dO * O) is formed per row in the prologue and goes through
+// LDS, not HBM).  At BASELINE config 2 (S = 64, d = 16) the two-kernel backward is launch- and latency-bound (8 + 9 us
+// for 2 MB).
 template <int HD, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void k_att_bwd_small(AttArgs a) {
+__global__ __launch_bounds__(128 * NW, 2) void k_att_bwd_small(AttArgs a) {
   using G = Geo<HD>;
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
   constexpr int T = kChunk * G::PITCH;
@@ -493,42 +495,48 @@ __global__ __launch_bounds__(64 * NW, 2) void k_att_bwd_small(AttArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r32 = lane & 31, hh = lane >> 5;
   const int64_t b = blockIdx.z;
   const int head = blockIdx.y, S = a.S, W = a.heads * HD;
-  const int row = wave * 32 + r32;      // the lane's query in the first phase, its key in the second
-  Stage<HD, NW> sq, sk, sv, sd;
+  const bool dq_role = wave < NW;       // wave-uniform
+  const int row = (dq_role ? wave : wave - NW) * 32 + r32;      // the lane's query (dQ part) or key (dK / dV part)
+  Stage<HD, 2 * NW> sq, sk, sv, sd;
   sq.load(a.q + b * a.q_sb + head * HD, a.q_sr, 0, S);
   sk.load(a.k + b * a.k_sb + head * HD, a.k_sr, 0, S);
   sv.load(a.v + b * a.v_sb + head * HD, a.v_sr, 0, S);
   sd.load(a.dout + b * S * W + head * HD, W, 0, S);
-  bf16x8 of[G::NS];
-  load_rows<HD>(of, a.out + b * S * W + head * HD, W, row, S, hh);
-  if (threadIdx.x < kChunk) {           // 64 * NW >= kChunk threads
+  if (threadIdx.x < kChunk) {           // 128 * NW >= kChunk threads: the per-row scalars
     const int r = threadIdx.x;
     const bool ok = r < S;
+    float delta = 0.f;
+    if (ok) {
+      const unsigned short* orow = a.out + (b * S + r) * W + head * HD;
+      const unsigned short* drow = a.dout + (b * S + r) * W + head * HD;
+#pragma unroll
+      for (int c = 0; c < HD / 8; ++c) {
+        const u16x8 ov = *reinterpret_cast<const u16x8*>(orow + 8 * c), dv8 = *reinterpret_cast<const u16x8*>(drow + 8 * c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) delta += bf16_to_f32(ov[j]) * bf16_to_f32(dv8[j]);
+      }
+    }
     const float l = ok ? a.lse[(b * a.heads + head) * S + r] : 0.f;
     lses[r] = l;
+    dels[r] = delta;                    // rows beyond S: 0
     fuls[r] = l == INFINITY ? 1.f / (float)S : 0.f;
     kb[r] = !ok ? -INFINITY : (a.mask == nullptr || a.mask[b * S + r] != 0) ? 0.f : kFill2;
   }
-  zero_pad_columns<HD, NW>(lds, 4);
+  zero_pad_columns<HD, 2 * NW>(lds, 4);
   sq.store(qt);
   sk.store(kt);
   sv.store(vt);
   sd.store(dt);
   __syncthreads();
   const float c2 = a.scale * kLog2e;
-  {                                     // ---- dQ of queries 32 w .. (k_att_bwd_dq's tile body)
+  if (dq_role) {                        // ---- dQ of queries 32 w .. (k_att_bwd_dq's tile body)
     bf16x8 qf[G::NS], dof[G::NS];
-    float delta = 0.f;
 #pragma unroll
     for (int s = 0; s < G::NS; ++s) {
       qf[s] = row_frag<HD>(qt, row, 2 * s + hh);
       dof[s] = row_frag<HD>(dt, row, 2 * s + hh);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) delta += (float)dof[s][j] * (float)of[s][j];
     }
-    delta += __shfl_xor(delta, 32, 64);
-    if (hh == 0) dels[row] = delta;     // rows beyond S: dO = O = 0
-    const float lse2 = lses[row];
+    const float delta = dels[row], lse2 = lses[row];
     f32x16 dq[G::NDB];
 #pragma unroll
     for (int db = 0; db < G::NDB; ++db)
@@ -563,9 +571,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_att_bwd_small(AttArgs a) {
       }
     }
     if (row < S) store_rows<HD>(a.dq + (b * S + row) * W + head * HD, dq, a.scale, hh);
-  }
-  __syncthreads();                      // every delta is in LDS
-  {                                     // ---- dK, dV of keys 32 w .. (k_att_bwd_dkv's tile body)
+  } else {                              // ---- dK, dV of keys 32 w .. (k_att_bwd_dkv's tile body)
     bf16x8 kf[G::NS], vf[G::NS];
 #pragma unroll
     for (int s = 0; s < G::NS; ++s) {
@@ -638,7 +644,7 @@ void launch_nw(const AttArgs& a, int64_t B, int which, hipStream_t st) {
 template <int HD, int NW>
 void launch_small(const AttArgs& a, int64_t B, hipStream_t st) {
   const size_t lds = (size_t)4 * kChunk * Geo<HD>::PITCH * 2 + 4 * kChunk * 4;
-  hipLaunchKernelGGL((k_att_bwd_small<HD, NW>), dim3(1, a.heads, (unsigned)B), dim3(64 * NW), lds, st, a);
+  hipLaunchKernelGGL((k_att_bwd_small<HD, NW>), dim3(1, a.heads, (unsigned)B), dim3(128 * NW), lds, st, a);
 }
 
 // S <= 64 and head size <= 64: the one-launch backward
