@@ -68,7 +68,10 @@ int mivae_attn_bias(const int64_t* mask, void* out, int64_t B, int64_t S, int ca
  * q k^T / sqrt(d), masked_fill(-1e13) where mask == 0 or, with causal != 0, key > query, softmax over keys, probs v).
  * q, k, v: element (b, s, head, d) at base + b * batch_stride + s * row_stride + head * head_size + d (bf16; the
  * (B, S, heads * head_size) outputs of the projections, no head transposes); strides in elements, multiples of 8.
- * mask (B, S) int64 or NULL; out / dout / dq / dk / dv (B, S, heads * head_size) bf16 contiguous; lse and delta
+ * mask (B, S) int64 or NULL; out / dout (B, S, heads * head_size) bf16 contiguous; dq / dk / dv rows of heads *
+ * head_size bf16 every grad_row_stride elements (heads * head_size: contiguous; 3 x that with dk = dq + heads *
+ * head_size, dv = dk + heads * head_size: one packed dq|dk|dv row per token, the K-concatenated operand of a fused
+ * q|k|v projection's input gradient); lse and delta
  * (B, heads, S) fp32 (lse may be NULL in forward-only use; it holds log2-domain log-sum-exp, +inf for a query
  * without any valid key, which attends uniformly to all S keys like the reference's finite fill).
  * head_size in {16, 32, 64, 128}, 1 <= S <= 2048 (mivae_attention_supported). */
@@ -81,7 +84,7 @@ int mivae_attention_bwd(const void* q, const void* k, const void* v, const int64
                         const void* dout, const float* lse, float* delta, void* dq, void* dk, void* dv, int64_t B,
                         int64_t S, int64_t heads, int64_t head_size, int64_t q_batch_stride, int64_t q_row_stride,
                         int64_t k_batch_stride, int64_t k_row_stride, int64_t v_batch_stride, int64_t v_row_stride,
-                        int causal, float scale, void* stream);
+                        int64_t grad_row_stride, int causal, float scale, void* stream);
 /* last_idx[b] = sum_s mask[b,s] - 1; ctx[b,:] = out[b, last_idx[b], :] (index -1 wraps like torch).
  * Replaces Encoder.forward's gather, models/base/encoders/encoder.py:35-37.  last_idx may be NULL. */
 int mivae_gather_last(const void* out, const int64_t* mask, void* ctx, int64_t* last_idx, int64_t B,
@@ -244,8 +247,9 @@ int mivae_colsum_sink(const void* x, float* out0, float* out1, int64_t split, fl
 int mivae_embedding_bwd(const float* dy, const int64_t* ids, float* dW, int64_t N, int64_t V, int64_t E,
                         int64_t padding_idx, int accumulate, void* stream);
 
-/* mivae_colsum_sink for MANY short matrices in one launch: jobs = njobs x {x, out0, out1, rows (<= 512), D, split} as
- * 6 x int64 per job in device memory; bit-identical to njobs calls of mivae_colsum_sink (same summation order).
+/* mivae_colsum_sink for MANY short matrices in one launch: jobs = njobs x {x, out0, out1, rows (<= 512), D, split,
+ * stride} as 7 x int64 per job in device memory (stride = floats between the rows of x, >= D: x may be a column block
+ * of a wider partial matrix); bit-identical to njobs calls of mivae_colsum_sink (same summation order).
  * Folds the [dW | db] partials of every small Linear of a training step at the end of backward
  * (trainer.py:284, loss.backward()).  max_D = the largest D in the table. */
 int mivae_colsum_sink_multi(const void* jobs, int64_t njobs, int64_t max_D, void* stream);

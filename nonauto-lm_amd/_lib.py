@@ -28,7 +28,8 @@ SIGNATURES = {
     "mivae_attn_bias": [P, P, I64, I64, I32, I32, P],
     "mivae_attention_supported": [I64, I64],
     "mivae_attention_fwd": [P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I32, F32, P],
-    "mivae_attention_bwd": [P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I32, F32, P],
+    "mivae_attention_bwd": [P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I32, F32,
+                            P],
     "mivae_gather_last": [P, P, P, P, I64, I64, I64, I32, P],
     "mivae_reparam_logq_fwd": [P, P, P, P, P, P, I64, I64, I64, I64, I32, P],
     "mivae_reparam_logq_bwd": [P, P, P, P, P, P, P, I64, I64, I64, I64, I32, P],

@@ -47,7 +47,8 @@ struct AttArgs {
   float* lse;                         // (B, heads, S): log2-domain log-sum-exp of the scaled scores, +inf = no valid key
   const unsigned short* dout;         // (B, S, heads * HD) contiguous
   float* delta;                       // (B, heads, S): sum_d dout * out
-  unsigned short *dq, *dk, *dv;       // (B, S, heads * HD) contiguous
+  unsigned short *dq, *dk, *dv;       // element (b, s, head, d) at base + (b * S + s) * g_sr + head * HD + d
+  int g_sr;                           //   (g_sr = heads * HD: contiguous; 3 * heads * HD: column blocks of one dq|dk|dv row)
   int S, heads, causal;
   float scale;
 };
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_att_bwd_dq(AttArgs a) {
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  if (qrow < S) store_rows<HD>(a.dq + (b * S + qrow) * W + head * HD, dq, a.scale, hh);
+  if (qrow < S) store_rows<HD>(a.dq + (b * S + qrow) * a.g_sr + head * HD, dq, a.scale, hh);
 }
 
 // ---- backward, dK and dV: a wave owns 32 keys and walks the queries ------------------------------------------------
@@ -471,8 +472,8 @@ __global__ __launch_bounds__(64 * NW, HD == 128 ? 1 : 2) void k_att_bwd_dkv(AttA
     }
   }
   if (kok) {
-    store_rows<HD>(a.dk + (b * S + key) * W + head * HD, dk, a.scale, hh);
-    store_rows<HD>(a.dv + (b * S + key) * W + head * HD, dv, 1.f, hh);
+    store_rows<HD>(a.dk + (b * S + key) * a.g_sr + head * HD, dk, a.scale, hh);
+    store_rows<HD>(a.dv + (b * S + key) * a.g_sr + head * HD, dv, 1.f, hh);
   }
 }
 
@@ -570,7 +571,7 @@ __global__ __launch_bounds__(128 * NW, 2) void k_att_bwd_small(AttArgs a) {
         dq[db] = ATT_MFMA(tr_frag<HD>(kt, 32 * t + 16, db, lane), d1, dq[db]);
       }
     }
-    if (row < S) store_rows<HD>(a.dq + (b * S + row) * W + head * HD, dq, a.scale, hh);
+    if (row < S) store_rows<HD>(a.dq + (b * S + row) * a.g_sr + head * HD, dq, a.scale, hh);
   } else {                              // ---- dK, dV of keys 32 w .. (k_att_bwd_dkv's tile body)
     bf16x8 kf[G::NS], vf[G::NS];
 #pragma unroll
@@ -619,8 +620,8 @@ __global__ __launch_bounds__(128 * NW, 2) void k_att_bwd_small(AttArgs a) {
       }
     }
     if (row < S) {
-      store_rows<HD>(a.dk + (b * S + row) * W + head * HD, dk, a.scale, hh);
-      store_rows<HD>(a.dv + (b * S + row) * W + head * HD, dv, 1.f, hh);
+      store_rows<HD>(a.dk + (b * S + row) * a.g_sr + head * HD, dk, a.scale, hh);
+      store_rows<HD>(a.dv + (b * S + row) * a.g_sr + head * HD, dv, 1.f, hh);
     }
   }
 }
@@ -734,7 +735,7 @@ int mivae_attention_bwd(const void* q, const void* k, const void* v, const int64
                         const void* dout, const float* lse, float* delta, void* dq, void* dk, void* dv, int64_t B,
                         int64_t S, int64_t heads, int64_t head_size, int64_t q_batch_stride, int64_t q_row_stride,
                         int64_t k_batch_stride, int64_t k_row_stride, int64_t v_batch_stride, int64_t v_row_stride,
-                        int causal, float scale, void* stream) {
+                        int64_t grad_row_stride, int causal, float scale, void* stream) {
   AttArgs a = {};
   const int64_t strides[6] = {q_batch_stride, q_row_stride, k_batch_stride, k_row_stride, v_batch_stride, v_row_stride};
   const int rc = fill_args(a, "mivae_attention_bwd", q, k, v, mask, B, S, heads, head_size, strides, causal, scale);
@@ -749,6 +750,10 @@ int mivae_attention_bwd(const void* q, const void* k, const void* v, const int64
   a.dq = static_cast<unsigned short*>(dq);
   a.dk = static_cast<unsigned short*>(dk);
   a.dv = static_cast<unsigned short*>(dv);
+  MIVAE_REQUIRE(grad_row_stride >= heads * head_size && grad_row_stride % 8 == 0 && grad_row_stride < (1ll << 30),
+                "mivae_attention_bwd: gradient row stride %lld must be a multiple of 8 and >= heads * head size",
+                (long long)grad_row_stride);
+  a.g_sr = (int)grad_row_stride;
   if (dispatch_small(a, B, (int)head_size, S_(stream))) {
     MIVAE_CHECK_LAUNCH("mivae_attention_bwd (one launch)");
     return MIVAE_OK;

@@ -587,7 +587,7 @@ __global__ void __launch_bounds__(256) k_colsum_short(const T* __restrict__ x, f
 // k_colsum_short<float> with accumulate = 1 (same row split, same combine order -> bit-identical results): the
 // [dW | db] partials of every small Linear of a training step, folded once at the end of backward instead of by
 // one 3.7 us launch per layer.
-struct ColJob { const float* x; float* out0; float* out1; int64_t rows, D, split; };
+struct ColJob { const float* x; float* out0; float* out1; int64_t rows, D, split, stride; };   // stride: floats per row of x
 __global__ void __launch_bounds__(256) k_colsum_short_multi(const ColJob* __restrict__ jobs) {
   __shared__ float red[4][64];
   const ColJob j = jobs[blockIdx.y];
@@ -597,7 +597,7 @@ __global__ void __launch_bounds__(256) k_colsum_short_multi(const ColJob* __rest
   float sum = 0.f;
   if (c < j.D) {
 #pragma unroll 16
-    for (int r = grp; r < (int)j.rows; r += 4) sum += j.x[(int64_t)r * j.D + c];
+    for (int r = grp; r < (int)j.rows; r += 4) sum += j.x[(int64_t)r * j.stride + c];
   }
   red[grp][lane] = sum;
   __syncthreads();
@@ -1416,14 +1416,16 @@ extern "C" int mivae_colsum_sink(const void* x, float* out0, float* out1, int64_
   return colsum_impl(x, out0, out1, split, 1, workspace, rows, D, dtype, stream);
 }
 
-// njobs x {x (rows, D) fp32, out0, out1, rows <= 512, D, split} as 6 x int64 per job in DEVICE memory: for every
+// njobs x {x (rows, D) fp32 with `stride` floats between rows, out0, out1, rows <= 512, D, split, stride} as 7 x int64
+// per job in DEVICE memory (stride > D: a column block of a wider partial matrix, e.g. one layer of a fused q|k|v
+// weight-gradient product): for every
 // job, columns [0, split) of the column sums are added into out0 and columns [split, D) into out1 (mivae_colsum_sink
 // for many matrices in one launch, bit-identical to it).  max_D = the largest D in the table.
 extern "C" int mivae_colsum_sink_multi(const void* jobs, int64_t njobs, int64_t max_D, void* stream) {
   MIVAE_REQUIRE(njobs >= 0 && njobs < 65536 && max_D >= 0, "colsum_sink_multi: bad sizes");
   if (njobs == 0 || max_D == 0) return MIVAE_OK;
   MIVAE_REQUIRE(jobs, "colsum_sink_multi: null pointer");
-  static_assert(sizeof(ColJob) == 48, "ColJob must be 6 x 8 bytes");
+  static_assert(sizeof(ColJob) == 56, "ColJob must be 7 x 8 bytes");
   dim3 grid((unsigned)((max_D + 63) / 64), (unsigned)njobs);
   k_colsum_short_multi<<<grid, kBlock, 0, S_(stream)>>>(static_cast<const ColJob*>(jobs));
   MIVAE_CHECK_LAUNCH("colsum_sink_multi");

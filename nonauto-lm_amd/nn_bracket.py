@@ -229,9 +229,66 @@ class _GroupLinearFn(torch.autograd.Function):
         return (gx, None, *gws, *gbs, *([None] * (2 * G)))
 
 
-def linear_group(x, layers):
+class _WideGroupLinearFn(torch.autograd.Function):
+    """G same-shape Linear layers too wide for the MFMA small-Linear kernels on one input (q / k / v of self-attention at
+    256 / 512 features): ONE library product against the row-concatenated bf16 weights, the outputs are the column blocks
+    of its (N, G * Fo) result (the attention kernels take the row stride).  Backward: one input-gradient product over
+    K = G * Fo -- no per-layer products, no accumulation launches -- on the packed dq | dk | dv the attention backward
+    hands back, and one batched weight-gradient product whose partials every layer's fold job reads by column block."""
+
+    @staticmethod
+    def forward(ctx, x, G, *flat):
+        ws, bs = flat[:G], flat[G:2 * G]
+        wcat = torch.cat([_lp(w) for w in ws], 0)
+        bcat = torch.cat([_lp(b) for b in bs], 0)
+        x2 = x.contiguous().view(-1, x.size(-1))
+        with torch.autocast("cuda", enabled=False):
+            y = F.linear(x2, wcat, bcat)
+        ctx.save_for_backward(x2, wcat)
+        ctx.params, ctx.G, ctx.xshape, ctx.param_dtype = list(zip(ws, bs)), G, x.shape, ws[0].dtype
+        Fo = ws[0].size(0)
+        y3 = y.view(*x.shape[:-1], G * Fo)
+        return tuple(y3[..., i * Fo:(i + 1) * Fo] for i in range(G))
+
+    @staticmethod
+    def backward(ctx, *gys):
+        x2, wcat = ctx.saved_tensors
+        G, N = ctx.G, x2.size(0)
+        Fo = wcat.size(0) // G
+        g0 = gys[0]
+        packed = all(g is not None and g.dtype == torch.bfloat16 and g.dim() >= 2 and g.stride(-1) == 1
+                     and g.stride(-2) == G * Fo and g.numel() == N * Fo for g in gys)
+        if packed:
+            es = g0.element_size()
+            packed = all(g.data_ptr() == g0.data_ptr() + i * Fo * es for i, g in enumerate(gys)) and (
+                g0.dim() == 2 or g0.stride(0) == g0.size(1) * G * Fo)
+        if packed:               # the column blocks of one (N, G * Fo) buffer (ops.attention's packed gradients)
+            gcat = torch.as_strided(g0, (N, G * Fo), (G * Fo, 1), g0.storage_offset())
+        else:
+            gcat = torch.cat([torch.zeros(N, Fo, dtype=torch.bfloat16, device=x2.device) if g is None
+                              else g.reshape(N, Fo).to(torch.bfloat16) for g in gys], 1)
+        gx = gcat.matmul(wcat).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        S = 1                                       # token slabs of the weight-gradient product (as _SplitKLinearFn)
+        while S < 16 and N % (2 * S) == 0 and N // (2 * S) >= 128:
+            S *= 2
+        if S > 1 and all(ops.grad_sink_ok(w, b) for w, b in ctx.params) and \
+                ops.wide_group_wgrad_deferred(gcat, x2, [(w.grad, b.grad) for w, b in ctx.params], S):
+            return (gx, None, *([None] * (2 * G)))
+        gw = gcat.t().matmul(x2).float()
+        gb = ops.colsum(gcat)
+        gws = [gw[i * Fo:(i + 1) * Fo].to(ctx.param_dtype) for i in range(G)]
+        gbs = [gb[i * Fo:(i + 1) * Fo].to(ctx.param_dtype) for i in range(G)]
+        return (gx, None, *gws, *gbs)
+
+
+WIDE_GROUP = os.environ.get("MIVAE_WIDE_GROUP", "1") != "0"
+
+
+def linear_group(x, layers, strided_ok=False):
     """[layer(x) for layer in layers] for same-shape `Linear` layers sharing their input; under bf16 autocast with
-    many tokens the group runs as one forward and one input-gradient launch (libmivae), otherwise layer by layer."""
+    many tokens the group runs as one forward and one input-gradient launch (libmivae), otherwise layer by layer.
+    `strided_ok`: the caller takes outputs that are column blocks of one buffer (row stride = the group's width), which
+    lets layers too wide for the libmivae kernels run as one library product (`_WideGroupLinearFn`)."""
     if (x.is_cuda and torch.is_grad_enabled() and torch.is_autocast_enabled() and len(layers) >= 2
             and torch.get_autocast_dtype("cuda") == torch.bfloat16 and x.numel() // x.size(-1) >= 4096
             and all(isinstance(l, Linear) and l.bias is not None for l in layers)
@@ -246,9 +303,16 @@ def linear_group(x, layers):
         if ops.linear_group_supported(x16, wl):
             return list(_GroupLinearFn.apply(x16, len(layers), *[l.weight for l in layers], *[l.bias for l in layers],
                                              *wl, *bl))
-    if (x.is_cuda and x.dtype == torch.float32 and torch.is_autocast_enabled()
+    if (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and torch.is_autocast_enabled()
             and torch.get_autocast_dtype("cuda") == torch.bfloat16 and len(layers) >= 2):
         x = x.to(torch.bfloat16)        # one cast for the group instead of one per layer
+        l0 = layers[0]
+        if (WIDE_GROUP and strided_ok and torch.is_grad_enabled() and x.numel() // x.size(-1) >= 4096 and len(layers) <= 4
+                and all(isinstance(l, Linear) and l.bias is not None and l.weight.shape == l0.weight.shape
+                        and l.weight.dtype == torch.float32 for l in layers)
+                and l0.out_features % 8 == 0 and l0.out_features <= 1024 and l0.in_features <= 1024):
+            return list(_WideGroupLinearFn.apply(x, len(layers), *[l.weight for l in layers],
+                                                 *[l.bias for l in layers]))
     return [l(x) for l in layers]
 
 
@@ -435,7 +499,7 @@ class MultiHeadAttention(torch.nn.Module):
     def forward(self, query, key, value, mask=None, attn_bias=None, residual=None):
         """`residual` (optional): returns residual + attention(...), the add folded into the output projection"""
         if query is key and key is value:        # self-attention: the three projections share their input
-            q, k, v = linear_group(query, [self._projections[n] for n in ("query", "key", "value")])
+            q, k, v = linear_group(query, [self._projections[n] for n in ("query", "key", "value")], strided_ok=True)
         else:
             q = self._projections["query"](query)
             k = self._projections["key"](key)

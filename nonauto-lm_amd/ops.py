@@ -213,12 +213,22 @@ class _Attention(torch.autograd.Function):
         dout = dout.contiguous()
         if dout.dtype != torch.bfloat16:
             dout = dout.to(torch.bfloat16)
-        dqkv = torch.empty(3, B, S, W, dtype=torch.bfloat16, device=q.device)
         delta = torch.empty_like(lse)
+        es = q.element_size()
+        packed = (q.stride(1) == 3 * W and k.stride(1) == 3 * W and v.stride(1) == 3 * W
+                  and k.data_ptr() == q.data_ptr() + W * es and v.data_ptr() == k.data_ptr() + W * es)
+        if packed:
+            # q, k, v are the column blocks of one fused q|k|v projection: hand its backward ONE (B, S, 3 W) gradient
+            # (dq | dk | dv per token), the K-concatenated operand of a single input-gradient product
+            g = torch.empty(B, S, 3 * W, dtype=torch.bfloat16, device=q.device)
+            dq, dk, dv = g[..., :W], g[..., W:2 * W], g[..., 2 * W:]
+        else:
+            g = torch.empty(3, B, S, W, dtype=torch.bfloat16, device=q.device)
+            dq, dk, dv = g[0], g[1], g[2]
         L.call("mivae_attention_bwd", L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(mask), L.ptr(out), L.ptr(dout), L.ptr(lse),
-               L.ptr(delta), L.ptr(dqkv[0]), L.ptr(dqkv[1]), L.ptr(dqkv[2]), B, S, heads, hd, q.stride(0), q.stride(1),
-               k.stride(0), k.stride(1), v.stride(0), v.stride(1), causal, scale, L.stream())
-        return dqkv[0], dqkv[1], dqkv[2], None, None, None
+               L.ptr(delta), L.ptr(dq), L.ptr(dk), L.ptr(dv), B, S, heads, hd, q.stride(0), q.stride(1),
+               k.stride(0), k.stride(1), v.stride(0), v.stride(1), 3 * W if packed else W, causal, scale, L.stream())
+        return dq, dk, dv, None, None, None
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask: Optional[torch.Tensor], heads: int,
@@ -905,7 +915,7 @@ def flush_grad_sinks(lo: Optional[int] = None, hi: Optional[int] = None):
         jobs = {k: _DEFER.pop(k) for k in keys}
     if not jobs:
         return
-    rows = [(part.data_ptr(), g0.data_ptr(), g1.data_ptr(), part.size(0), part.size(1), split)
+    rows = [(part.data_ptr(), g0.data_ptr(), g1.data_ptr(), part.size(0), part.size(1), split, part.stride(0))
             for part, g0, g1, split in jobs.values()]
     key = tuple(rows)
     table = _JOB_TABLES.get(key)
@@ -913,6 +923,7 @@ def flush_grad_sinks(lo: Optional[int] = None, hi: Optional[int] = None):
         dev = next(iter(jobs.values()))[0].device
         if torch.cuda.is_current_stream_capturing():      # no host-to-device copy inside a capture: fold one by one
             for part, g0, g1, split in jobs.values():
+                part = part if part.stride(0) == part.size(1) else part.contiguous()
                 ws = torch.empty(max(1, L.query("mivae_col_workspace_floats", part.size(0), part.size(1), 0)),
                                  dtype=torch.float32, device=dev)
                 L.call("mivae_colsum_sink", L.ptr(part), L.ptr(g0), L.ptr(g1), split, L.ptr(ws), part.size(0), part.size(1), 0,
@@ -1091,6 +1102,51 @@ def wide_linear_wgrad_deferred(g2, x2, w_grad, b_grad, G: int) -> bool:
     _DEFER[kw] = (part.view(G, Fo * Fi), wflat, wflat, Fo * Fi)
     _DEFER[kb] = (wsb[:nblk * Fo].view(nblk, Fo), b_grad, b_grad, Fo)
     sink_arrived(w_grad, b_grad)
+    return True
+
+
+def wide_group_wgrad_deferred(gcat, x2, sinks, G: int) -> bool:
+    """wide_linear_wgrad_deferred for a group of same-shape layers sharing x2 whose output gradients are the column
+    blocks of gcat (n, len(sinks) * Fo): ONE batched product for the token-slab partials of all d W, one partial column
+    sum for all d b; every layer's fold job reads its column block of the shared partials (row stride in the job)."""
+    n, Fi = x2.shape
+    L3 = gcat.size(1)
+    ng = len(sinks)
+    Fo = L3 // ng
+    if _DEFER is None or n % G or G > 512 or not gcat.is_contiguous() or not x2.is_contiguous():
+        return False
+    code = L.dtype_code(gcat.dtype)
+    kw, kb = (sinks[0][0].data_ptr(), G, -L3 * Fi), (sinks[0][1].data_ptr(), n, -L3)
+    kws = [(w.data_ptr(), G, Fo * Fi) for w, _ in sinks]
+    kbs = [(b.data_ptr(), n, -Fo) for _, b in sinks]
+    if any(k in _DEFER for k in kws + kbs):
+        return False
+    nws = L.query("mivae_col_workspace_floats", n, L3, code)
+    if nws <= 0 or nws // L3 > 2 * 512:
+        return False
+    part = _PART_BUFS.get(kw)
+    if part is None or part.device != gcat.device:
+        part = _PART_BUFS[kw] = torch.empty(G, L3, Fi, dtype=torch.float32, device=gcat.device)
+    wsb = _PART_BUFS.get(kb)
+    if wsb is None or wsb.device != gcat.device:
+        wsb = _PART_BUFS[kb] = torch.empty(nws, dtype=torch.float32, device=gcat.device)
+    ga, xa = gcat.view(G, n // G, L3).transpose(1, 2), x2.view(G, n // G, Fi)
+    try:
+        torch.bmm(ga, xa, out_dtype=torch.float32, out=part)
+    except (TypeError, RuntimeError):
+        part.copy_(torch.bmm(ga, xa, out_dtype=torch.float32))
+    nblk = L.query("mivae_colsum_partial", L.ptr(gcat), L.ptr(wsb), n, L3, code, L.stream())
+    if nblk <= 0:
+        raise RuntimeError(f"mivae_colsum_partial failed ({nblk}): {L.lib().mivae_last_error().decode()}")
+    if nblk > 512:
+        raise RuntimeError("wide_group_wgrad_deferred: partial count exceeds the fold kernel's limit")
+    pw = part.view(G, ng, Fo * Fi)
+    pb = wsb[:nblk * L3].view(nblk, ng, Fo)
+    for i, (w_grad, b_grad) in enumerate(sinks):
+        wflat = w_grad.view(-1)
+        _DEFER[kws[i]] = (pw[:, i], wflat, wflat, Fo * Fi)         # (G, Fo * Fi) with row stride ng * Fo * Fi
+        _DEFER[kbs[i]] = (pb[:, i], b_grad, b_grad, Fo)
+        sink_arrived(w_grad, b_grad)
     return True
 
 

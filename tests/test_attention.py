@@ -151,3 +151,42 @@ def test_linear_residual_epilogue_bit_equal(res_dtype):
         outs.append((y, xx.grad, rr.grad, lin.weight.grad.clone(), lin.bias.grad.clone()))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def test_wide_qkv_group_matches_layerwise(monkeypatch):
+    """MultiHeadAttention at 256 features under bf16 autocast with gradient sinks: the fused q|k|v product (one forward
+    GEMM, packed dq|dk|dv -> one input-gradient GEMM, one batched weight-gradient product folded by column block) ==
+    the three separate projections, outputs and every parameter gradient"""
+    from nonauto_lm_amd import nn_bracket as nb, ops
+    torch.manual_seed(7)
+    B, S, D, heads = 64, 64, 256, 4
+    mha = nb.MultiHeadAttention(heads, D, dropout=0.0).cuda()
+    x = torch.randn(B, S, D, device="cuda")
+    lens = torch.randint(1, S + 1, (B,), device="cuda")
+    mask = (torch.arange(S, device="cuda")[None, :] < lens[:, None]).long()
+    res = {}
+    for wide in (True, False):
+        monkeypatch.setattr(nb, "WIDE_GROUP", wide)
+        for sink in (False, True):
+            for p in mha.parameters():
+                p.grad = torch.zeros_like(p)
+            xx = x.clone().requires_grad_(True)
+            ops.GRAD_SINK = sink
+            if sink:
+                ops.begin_deferred_sinks()
+            try:
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    y = mha(xx, xx, xx, mask)
+                (y.float() * mask[..., None]).square().sum().backward()
+                ops.flush_grad_sinks()
+            finally:
+                ops.GRAD_SINK = False
+                ops._DEFER = None
+            res[(wide, sink)] = (y.float(), xx.grad.float(), [p.grad.clone() for p in mha.parameters()])
+    ref = res[(False, False)]
+    for key in ((True, False), (True, True), (False, True)):
+        y, gx, gp = res[key]
+        torch.testing.assert_close(y, ref[0], rtol=2e-2, atol=2e-2)
+        assert (gx - ref[1]).abs().max() <= 2e-2 * max(ref[1].abs().max().item(), 1.0), key
+        for a, b in zip(gp, ref[2]):
+            assert (a - b).abs().max() <= 2e-2 * max(b.abs().max().item(), 1.0), key
