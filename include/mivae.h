@@ -399,6 +399,11 @@ int mivae_linear_dgrad_group(const void* const* dy, const void* const* w, void* 
 int mivae_ffn_fwd(const void* x, const float* gamma, const float* beta, const void* w1, const void* b1, const void* w2,
                   const void* b2, void* y, void* xn, void* hmid, float* mean, float* rstd, int64_t N, int64_t D,
                   int64_t H, float eps, int x_dtype, void* stream);
+/* mivae_linear_wgrad for the two Linear layers of PositionwiseFeedForward (nn/transformer.py:120-133) in one launch:
+ * problem 0 = (x0 (N, Fi0), dy0 (N, Fo0)) -> partial0, problem 1 likewise, same N.  Instantiated for (Fi0, Fo0) =
+ * (128, 64), (Fi1, Fo1) = (64, 128); MIVAE_EUNSUPPORTED (-3) otherwise. */
+int mivae_linear_wgrad_pair(const void* x0, const void* dy0, float* partial0, int64_t Fi0, int64_t Fo0, const void* x1,
+                            const void* dy1, float* partial1, int64_t Fi1, int64_t Fo1, int64_t N, void* stream);
 /* mivae_linear_wgrad for G (2..4) same-shape layers sharing x in one launch (x staged once): partial[g] as above for
  * layer g; dy / partial are host arrays of G device pointers.  Fi = Fo in {32, 64}, else MIVAE_EUNSUPPORTED (-3). */
 int mivae_linear_wgrad_group(const void* x, const void* const* dy, float* const* partial, int64_t G, int64_t N,

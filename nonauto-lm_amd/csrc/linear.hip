@@ -157,8 +157,7 @@ __device__ __forceinline__ lin_bf16x8 lin_tr_frag(const unsigned short* tile, in
 constexpr int kSlab = 128;    // tokens staged per block and pass
 
 template <int MO, int NI>
-__global__ __launch_bounds__(256) void k_lin_wgrad2(WgArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+__device__ __forceinline__ void wgrad2_body(const WgArgs& a, unsigned short* lds, const unsigned bx) {
   constexpr int Fo = 32 * MO, Fi = 32 * NI;
   constexpr int SG = Fo + (MO == 1 ? 0 : 32), SX = Fi + (NI == 1 ? 0 : 32);   // row strides (elements)
   constexpr int T = MO * NI, TPW = (T + 3) / 4;
@@ -175,7 +174,7 @@ __global__ __launch_bounds__(256) void k_lin_wgrad2(WgArgs a) {
   const lin_bf16x8 ones = __builtin_bit_cast(lin_bf16x8, ones_raw);
   const int slabs = a.tiles_per_wave;             // 128-token slabs per block (= 4 waves x tiles_per_wave tiles)
   for (int sl = 0; sl < slabs; ++sl) {
-    const int64_t tb = ((int64_t)blockIdx.x * slabs + sl) * kSlab;
+    const int64_t tb = ((int64_t)bx * slabs + sl) * kSlab;
     if (tb >= a.N) break;                         // block-uniform
     if (sl) __syncthreads();                      // the previous slab has been consumed
     for (int idx = threadIdx.x; idx < kSlab * (Fo >> 3); idx += 256) {
@@ -206,7 +205,7 @@ __global__ __launch_bounds__(256) void k_lin_wgrad2(WgArgs a) {
     }
   }
   // partial[block][row * Fi + col] (row = output feature, col = input feature), db at [Fo * Fi + row]
-  float* out = a.partial + (int64_t)blockIdx.x * ((int64_t)Fo * Fi + Fo);
+  float* out = a.partial + (int64_t)bx * ((int64_t)Fo * Fi + Fo);
 #pragma unroll
   for (int i = 0; i < TPW; ++i) {
     const int t = wave * TPW + i;
@@ -219,6 +218,21 @@ __global__ __launch_bounds__(256) void k_lin_wgrad2(WgArgs a) {
       for (int r = 0; r < 16; ++r) out[Fo * Fi + 32 * m + lin_row(r, hh)] = accb[i][r];
     }
   }
+}
+
+template <int MO, int NI>
+__global__ __launch_bounds__(256) void k_lin_wgrad2(WgArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  wgrad2_body<MO, NI>(a, lds, blockIdx.x);
+}
+
+// Two independent weight-gradient problems over the same tokens in one launch (blockIdx.y picks the problem): the two
+// Linear layers of a feed-forward sublayer, dW2 = dy^T hmid and dW1 = dh^T xn, otherwise two ~7 us launches each way.
+template <int MO0, int NI0, int MO1, int NI1>
+__global__ __launch_bounds__(256) void k_lin_wgrad2_pair(WgArgs a0, WgArgs a1) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  if (blockIdx.y == 0) wgrad2_body<MO0, NI0>(a0, lds, blockIdx.x);
+  else wgrad2_body<MO1, NI1>(a1, lds, blockIdx.x);
 }
 
 // The same for a GROUP of G layers that share x (q / k / v, mu / sigma heads): x is staged once, the G dy tiles next to
@@ -620,6 +634,34 @@ extern "C" int mivae_linear_wgrad(const void* x, const void* dy, float* partial,
   else if (mo == 4 && ni == 1) WG(4, 1); else if (mo == 4 && ni == 2) WG(4, 2); else WG(4, 4);
 #undef WG
   MIVAE_CHECK_LAUNCH("linear_wgrad");
+  return MIVAE_OK;
+}
+
+// mivae_linear_wgrad for the two layers of a feed-forward sublayer in one launch: (x0, dy0) with (Fi0, Fo0) = (H, D) and
+// (x1, dy1) with (Fi1, Fo1) = (D, H) over the same N tokens; instantiated for D = 64, H = 128 (MIVAE_EUNSUPPORTED
+// otherwise: call mivae_linear_wgrad twice).  partial0 / partial1 as mivae_linear_wgrad writes them.
+extern "C" int mivae_linear_wgrad_pair(const void* x0, const void* dy0, float* partial0, int64_t Fi0, int64_t Fo0,
+                                       const void* x1, const void* dy1, float* partial1, int64_t Fi1, int64_t Fo1,
+                                       int64_t N, void* stream) {
+  MIVAE_REQUIRE(N >= 1 && N < (1ll << 31), "linear_wgrad_pair: bad N");
+  if (!(Fi0 == 128 && Fo0 == 64 && Fi1 == 64 && Fo1 == 128)) {
+    mivae_set_error("linear_wgrad_pair: unsupported shapes (%lld, %lld) / (%lld, %lld)", (long long)Fi0, (long long)Fo0,
+                    (long long)Fi1, (long long)Fo1);
+    return MIVAE_EUNSUPPORTED;
+  }
+  MIVAE_REQUIRE(x0 && dy0 && partial0 && x1 && dy1 && partial1, "linear_wgrad_pair: null pointer");
+  MIVAE_REQUIRE(aligned16(x0) && aligned16(dy0) && aligned16(partial0) && aligned16(x1) && aligned16(dy1) &&
+                    aligned16(partial1), "linear_wgrad_pair: operands must be 16-byte aligned");
+  WgArgs a0 = {(const unsigned short*)x0, (const unsigned short*)dy0, partial0, N, (int)Fo0, (int)Fi0, 0};
+  WgArgs a1 = {(const unsigned short*)x1, (const unsigned short*)dy1, partial1, N, (int)Fo1, (int)Fi1, 0};
+  int64_t P;
+  wgrad_geom(N, a0.tiles_per_wave, P);
+  a1.tiles_per_wave = a0.tiles_per_wave;
+  const size_t lds = (size_t)kSlab * ((64 + 32) + (128 + 32)) * 2;      // both problems stage a 64- and a 128-wide tile
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)k_lin_wgrad2_pair<2, 4, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  k_lin_wgrad2_pair<2, 4, 4, 2><<<dim3((unsigned)P, 2), 256, lds, S_(stream)>>>(a0, a1);
+  MIVAE_CHECK_LAUNCH("linear_wgrad_pair");
   return MIVAE_OK;
 }
 

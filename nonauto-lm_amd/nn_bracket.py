@@ -344,6 +344,11 @@ class _FfnBlockFn(torch.autograd.Function):
         dy16 = dy2 if dy2.dtype == torch.bfloat16 else dy2.to(torch.bfloat16)
         dh = ops.linear_dgrad_relu(dy16, w2l, hmid)                        # (N, H), relu' applied on store
         grads = {}
+        if (ops.grad_sink_ok(w1, b1) and ops.grad_sink_ok(w2, b2)
+                and ops.linear_wgrad_pair_deferred(hmid, dy16, (w2.grad, b2.grad), xn, dh, (w1.grad, b1.grad))):
+            dxn = ops.linear_dgrad(dh, w1l)          # both weight gradients are queued: one launch
+            dx, gg, gb_ = ops.layer_norm_bwd(dxn, x2, gamma, stats, (g, be), add=dy2)
+            return dx.view(ctx.xshape), gg, gb_, None, None, None, None, None
         for name, (xin, gout, w, b) in (("2", (hmid, dy16, w2, b2)), ("1", (xn, dh, w1, b1))):
             small = w.size(0) <= 128 and w.size(1) <= 128
             if small and ops.grad_sink_ok(w, b):

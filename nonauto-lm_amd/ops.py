@@ -1159,6 +1159,32 @@ def linear_dgrad_relu(g2, w16, relu_out):
     return dx
 
 
+def linear_wgrad_pair_deferred(x0, g0, sink0, x1, g1, sink1) -> bool:
+    """linear_wgrad(x0, g0, sink=sink0) and linear_wgrad(x1, g1, sink=sink1) -- the two layers of a feed-forward
+    sublayer -- as ONE launch in deferred-sink mode; False when the caller has to issue them separately."""
+    N = x0.size(0)
+    (Fi0, Fo0), (Fi1, Fo1) = (x0.size(1), g0.size(1)), (x1.size(1), g1.size(1))
+    rows = L.query("mivae_linear_wgrad_rows", N)
+    if _DEFER is None or rows > 512 or (Fi0, Fo0, Fi1, Fo1) != (128, 64, 64, 128) or x1.size(0) != N:
+        return False
+    k0, k1 = (sink0[0].data_ptr(), rows, Fo0 * Fi0 + Fo0), (sink1[0].data_ptr(), rows, Fo1 * Fi1 + Fo1)
+    if k0 in _DEFER or k1 in _DEFER or k0 == k1:
+        return False
+    parts = []
+    for k in (k0, k1):
+        part = _PART_BUFS.get(k)
+        if part is None or part.device != x0.device:
+            part = _PART_BUFS[k] = torch.empty(rows, k[2], dtype=torch.float32, device=x0.device)
+        parts.append(part)
+    L.call("mivae_linear_wgrad_pair", L.ptr(x0), L.ptr(g0), L.ptr(parts[0]), Fi0, Fo0, L.ptr(x1), L.ptr(g1), L.ptr(parts[1]),
+           Fi1, Fo1, N, L.stream())
+    _DEFER[k0] = (parts[0], sink0[0], sink0[1], Fo0 * Fi0)
+    _DEFER[k1] = (parts[1], sink1[0], sink1[1], Fo1 * Fi1)
+    sink_arrived(sink0[0], sink0[1])
+    sink_arrived(sink1[0], sink1[1])
+    return True
+
+
 def linear_wgrad(x2, g2, sink=None):
     """(dW (Fo, Fi), db (Fo)) fp32 from x2 (N, Fi), g2 (N, Fo) bf16; Fi, Fo <= 128.  `sink` = (weight.grad,
     bias.grad): the sums are added there instead and None is returned."""

@@ -190,3 +190,32 @@ def test_wide_qkv_group_matches_layerwise(monkeypatch):
         assert (gx - ref[1]).abs().max() <= 2e-2 * max(ref[1].abs().max().item(), 1.0), key
         for a, b in zip(gp, ref[2]):
             assert (a - b).abs().max() <= 2e-2 * max(b.abs().max().item(), 1.0), key
+
+
+def test_linear_wgrad_pair_bit_equal_to_two_launches():
+    """mivae_linear_wgrad_pair (both weight gradients of a feed-forward sublayer in one launch, deferred sinks) folds to
+    exactly what two mivae_linear_wgrad launches fold to"""
+    from nonauto_lm_amd import ops
+    torch.manual_seed(11)
+    N, D, H = 16384, 64, 128
+    hmid, dy = torch.randn(N, H, device="cuda").to(torch.bfloat16), torch.randn(N, D, device="cuda").to(torch.bfloat16)
+    xn, dh = torch.randn(N, D, device="cuda").to(torch.bfloat16), torch.randn(N, H, device="cuda").to(torch.bfloat16)
+    outs = []
+    for pair in (True, False):
+        gw2, gb2 = torch.zeros(D, H, device="cuda"), torch.zeros(D, device="cuda")
+        gw1, gb1 = torch.zeros(H, D, device="cuda"), torch.zeros(H, device="cuda")
+        ops.begin_deferred_sinks()
+        try:
+            if pair:
+                assert ops.linear_wgrad_pair_deferred(hmid, dy, (gw2, gb2), xn, dh, (gw1, gb1))
+            else:
+                ops.linear_wgrad(hmid, dy, sink=(gw2, gb2))
+                ops.linear_wgrad(xn, dh, sink=(gw1, gb1))
+            ops.flush_grad_sinks()
+        finally:
+            ops._DEFER = None
+        outs.append((gw2, gb2, gw1, gb1))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    ref = dy.float().t() @ hmid.float()
+    assert (outs[0][0] - ref).abs().max() <= 1e-3 * ref.abs().max()
