@@ -399,6 +399,11 @@ int mivae_linear_dgrad_group(const void* const* dy, const void* const* w, void* 
 int mivae_ffn_fwd(const void* x, const float* gamma, const float* beta, const void* w1, const void* b1, const void* w2,
                   const void* b2, void* y, void* xn, void* hmid, float* mean, float* rstd, int64_t N, int64_t D,
                   int64_t H, float eps, int x_dtype, void* stream);
+/* mivae_linear_wgrad(x0, dy0) -> partial0 and mivae_linear_wgrad_group(x, dy[0..G)) -> partial[0..G) in one launch, every
+ * layer F x F over the same N tokens: the output projection of MultiHeadAttention and its q / k / v projections
+ * (nn/transformer.py:41-48).  dy / partial: host arrays of G device pointers.  F in {32, 64}, G = 3; else -3. */
+int mivae_linear_wgrad_single_group(const void* x0, const void* dy0, float* partial0, const void* x, const void* const* dy,
+                                    float* const* partial, int64_t G, int64_t N, int64_t F, void* stream);
 /* mivae_linear_wgrad for the two Linear layers of PositionwiseFeedForward (nn/transformer.py:120-133) in one launch:
  * problem 0 = (x0 (N, Fi0), dy0 (N, Fo0)) -> partial0, problem 1 likewise, same N.  Instantiated for (Fi0, Fo0) =
  * (128, 64), (Fi1, Fo1) = (64, 128); MIVAE_EUNSUPPORTED (-3) otherwise. */

@@ -246,8 +246,7 @@ struct WgGroupArgs {
 };
 
 template <int MO, int NI, int G>
-__global__ __launch_bounds__(256) void k_lin_wgrad2g(WgGroupArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+__device__ __forceinline__ void wgrad2g_body(const WgGroupArgs& a, unsigned short* lds, const unsigned bx) {
   constexpr int Fo = 32 * MO, Fi = 32 * NI;
   constexpr int SG = Fo + (MO == 1 ? 0 : 32), SX = Fi + (NI == 1 ? 0 : 32);
   constexpr int T = G * MO * NI, TPW = (T + 3) / 4;
@@ -264,7 +263,7 @@ __global__ __launch_bounds__(256) void k_lin_wgrad2g(WgGroupArgs a) {
   const lin_bf16x8 ones = __builtin_bit_cast(lin_bf16x8, ones_raw);
   const int slabs = a.tiles_per_wave;
   for (int sl = 0; sl < slabs; ++sl) {
-    const int64_t tb = ((int64_t)blockIdx.x * slabs + sl) * kSlab;
+    const int64_t tb = ((int64_t)bx * slabs + sl) * kSlab;
     if (tb >= a.N) break;
     if (sl) __syncthreads();
     for (int idx = threadIdx.x; idx < kSlab * (Fi >> 3); idx += 256) {
@@ -301,7 +300,7 @@ __global__ __launch_bounds__(256) void k_lin_wgrad2g(WgGroupArgs a) {
     const int t = wave * TPW + i;
     if (t >= T) continue;
     const int g = t / (MO * NI), m = (t % (MO * NI)) / NI, n = t % NI;
-    float* out = a.partial[g] + (int64_t)blockIdx.x * ((int64_t)Fo * Fi + Fo);
+    float* out = a.partial[g] + (int64_t)bx * ((int64_t)Fo * Fi + Fo);
 #pragma unroll
     for (int r = 0; r < 16; ++r) out[(32 * m + lin_row(r, hh)) * Fi + 32 * n + r32] = acc[i][r];
     if (n == 0 && r32 == 0) {
@@ -309,6 +308,21 @@ __global__ __launch_bounds__(256) void k_lin_wgrad2g(WgGroupArgs a) {
       for (int r = 0; r < 16; ++r) out[Fo * Fi + 32 * m + lin_row(r, hh)] = accb[i][r];
     }
   }
+}
+
+template <int MO, int NI, int G>
+__global__ __launch_bounds__(256) void k_lin_wgrad2g(WgGroupArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  wgrad2g_body<MO, NI, G>(a, lds, blockIdx.x);
+}
+
+// A single layer and a group of G layers (different inputs, same tokens, all F x F) in one launch: the output projection
+// of self-attention and its q / k / v projections (blockIdx.y = 0 / 1).
+template <int MO, int G>
+__global__ __launch_bounds__(256) void k_lin_wgrad2_sg(WgArgs a0, WgGroupArgs a1) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  if (blockIdx.y == 0) wgrad2_body<MO, MO>(a0, lds, blockIdx.x);
+  else wgrad2g_body<MO, MO, G>(a1, lds, blockIdx.x);
 }
 
 // ---- pre-norm feed-forward sublayer, forward, in one launch ----------------------------------------------------
@@ -662,6 +676,45 @@ extern "C" int mivae_linear_wgrad_pair(const void* x0, const void* dy0, float* p
     (void)hipFuncSetAttribute((const void*)k_lin_wgrad2_pair<2, 4, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   k_lin_wgrad2_pair<2, 4, 4, 2><<<dim3((unsigned)P, 2), 256, lds, S_(stream)>>>(a0, a1);
   MIVAE_CHECK_LAUNCH("linear_wgrad_pair");
+  return MIVAE_OK;
+}
+
+// mivae_linear_wgrad(x0, dy0) and mivae_linear_wgrad_group(x, dy[0..G)) in ONE launch, all layers F x F over the same N
+// tokens: the output projection of MultiHeadAttention and its q / k / v projections.  Instantiated for F in {32, 64},
+// G = 3; MIVAE_EUNSUPPORTED (-3) otherwise.
+extern "C" int mivae_linear_wgrad_single_group(const void* x0, const void* dy0, float* partial0, const void* x,
+                                               const void* const* dy, float* const* partial, int64_t G, int64_t N,
+                                               int64_t F, void* stream) {
+  MIVAE_REQUIRE(N >= 1 && N < (1ll << 31), "linear_wgrad_single_group: bad N");
+  if (!(G == 3 && (F == 32 || F == 64))) {
+    mivae_set_error("linear_wgrad_single_group: unsupported G=%lld F=%lld", (long long)G, (long long)F);
+    return MIVAE_EUNSUPPORTED;
+  }
+  MIVAE_REQUIRE(x0 && dy0 && partial0 && x && dy && partial && aligned16(x0) && aligned16(dy0) && aligned16(partial0) &&
+                    aligned16(x), "linear_wgrad_single_group: null or misaligned pointer");
+  WgArgs a0 = {(const unsigned short*)x0, (const unsigned short*)dy0, partial0, N, (int)F, (int)F, 0};
+  WgGroupArgs a1 = {};
+  a1.x = (const unsigned short*)x; a1.N = N;
+  for (int g = 0; g < G; ++g) {
+    MIVAE_REQUIRE(dy[g] && partial[g] && aligned16(dy[g]) && aligned16(partial[g]),
+                  "linear_wgrad_single_group: null or misaligned pointer");
+    a1.dy[g] = (const unsigned short*)dy[g]; a1.partial[g] = partial[g];
+  }
+  int64_t P;
+  wgrad_geom(N, a0.tiles_per_wave, P);
+  a1.tiles_per_wave = a0.tiles_per_wave;
+  const int pad = F == 32 ? 0 : 32;
+  const size_t lds = (size_t)kSlab * (F + pad) * 2 * (size_t)(G + 1);       // the group's tiles; the single layer needs 2
+  const dim3 grid((unsigned)P, 2);
+  hipStream_t st = S_(stream);
+  if (F == 64) {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)k_lin_wgrad2_sg<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    k_lin_wgrad2_sg<2, 3><<<grid, 256, lds, st>>>(a0, a1);
+  } else {
+    k_lin_wgrad2_sg<1, 3><<<grid, 256, lds, st>>>(a0, a1);
+  }
+  MIVAE_CHECK_LAUNCH("linear_wgrad_single_group");
   return MIVAE_OK;
 }
 

@@ -54,7 +54,8 @@ class _SplitKLinearFn(torch.autograd.Function):
             if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
                 if weight.size(0) <= 128 and weight.size(1) <= 128:
                     if ctx.has_bias and all(ctx.needs_input_grad[1:3]) and ops.grad_sink_ok(*ctx.params):
-                        ops.linear_wgrad(x, g2, sink=(ctx.params[0].grad, ctx.params[1].grad))
+                        ops.linear_wgrad(x, g2, sink=(ctx.params[0].grad, ctx.params[1].grad),
+                                         hold=getattr(ctx, "hold_wgrad", False))
                         return gx, None, None, None, None
                     gw, gb = ops.linear_wgrad(x, g2)
                     gw, gb = gw.to(ctx.param_dtype), (gb.to(ctx.param_dtype) if ctx.has_bias else None)
@@ -135,6 +136,7 @@ class _LinearResidualFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, w_lp, b_lp, res):       # argument order of _SplitKLinearFn, the residual last
         ctx.has_bias, ctx.param_dtype, ctx.params, ctx.small = True, weight.dtype, (weight, bias), True
+        ctx.hold_wgrad = True       # attention's output projection: its weight gradient shares the q / k / v group's launch
         x2 = x.contiguous().view(-1, x.size(-1))
         ctx.save_for_backward(x2, w_lp)
         ctx.xshape = x.shape

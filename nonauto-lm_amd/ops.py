@@ -896,9 +896,30 @@ def sink_arrived(*grads) -> None:
                 SINK_NOTIFY(g)
 
 
+# A deferred small weight-gradient launch held back for a partner (the output projection of self-attention waits for
+# the q / k / v group of the same sublayer: one launch for both, mivae_linear_wgrad_single_group).  Its arrival is
+# reported when it is stashed; whoever folds or reduces gradients goes through flush_grad_sinks(), which enqueues a
+# still-pending launch first, on the same stream, so the order partials -> fold -> reduce holds either way.
+_PENDING = None
+
+
+def _launch_pending() -> None:
+    global _PENDING
+    if _PENDING is None:
+        return
+    x2, g2, key, part, sink = _PENDING
+    _PENDING = None
+    N, Fi = x2.shape
+    Fo = g2.size(1)
+    L.call("mivae_linear_wgrad", L.ptr(x2), L.ptr(g2), L.ptr(part), N, Fi, Fo, L.stream())
+    if _DEFER is not None:
+        _DEFER[key] = (part, sink[0], sink[1], Fo * Fi)
+
+
 def begin_deferred_sinks():
-    global _DEFER
+    global _DEFER, _PENDING
     _DEFER = {}
+    _PENDING = None
 
 
 def flush_grad_sinks(lo: Optional[int] = None, hi: Optional[int] = None):
@@ -908,6 +929,7 @@ def flush_grad_sinks(lo: Optional[int] = None, hi: Optional[int] = None):
     global _DEFER
     if _DEFER is None:
         return
+    _launch_pending()
     if lo is None:
         jobs, _DEFER = _DEFER, None
     else:
@@ -1059,7 +1081,17 @@ def linear_wgrad_group_deferred(x2, gs, sinks) -> bool:
         if part is None or part.device != x2.device:
             part = _PART_BUFS[k] = torch.empty(rows, D, dtype=torch.float32, device=x2.device)
         parts.append(part)
-    L.call("mivae_linear_wgrad_group", L.ptr(x2), _ptr_array(gs), _ptr_array(parts), len(gs), N, Fi, Fo, L.stream())
+    global _PENDING
+    pend = _PENDING
+    if (pend is not None and len(gs) == 3 and pend[0].shape == (N, Fi) and pend[1].shape == (N, Fo)
+            and pend[2] not in keys):
+        _PENDING = None          # the held-back single layer (output projection) rides along: one launch for four layers
+        L.call("mivae_linear_wgrad_single_group", L.ptr(pend[0]), L.ptr(pend[1]), L.ptr(pend[3]), L.ptr(x2), _ptr_array(gs),
+               _ptr_array(parts), len(gs), N, Fi, L.stream())
+        _DEFER[pend[2]] = (pend[3], pend[4][0], pend[4][1], Fo * Fi)
+    else:
+        _launch_pending()
+        L.call("mivae_linear_wgrad_group", L.ptr(x2), _ptr_array(gs), _ptr_array(parts), len(gs), N, Fi, Fo, L.stream())
     for k, part, (s0, s1) in zip(keys, parts, sinks):
         _DEFER[k] = (part, s0, s1, Fo * Fi)
         sink_arrived(s0, s1)
@@ -1185,18 +1217,25 @@ def linear_wgrad_pair_deferred(x0, g0, sink0, x1, g1, sink1) -> bool:
     return True
 
 
-def linear_wgrad(x2, g2, sink=None):
+def linear_wgrad(x2, g2, sink=None, hold=False):
     """(dW (Fo, Fi), db (Fo)) fp32 from x2 (N, Fi), g2 (N, Fo) bf16; Fi, Fo <= 128.  `sink` = (weight.grad,
-    bias.grad): the sums are added there instead and None is returned."""
+    bias.grad): the sums are added there instead and None is returned.  `hold` (deferred sinks, square 32 / 64-wide
+    layers): the launch may wait for the q / k / v group of the same attention sublayer and share its launch."""
+    global _PENDING
     N, Fi = x2.shape
     Fo = g2.size(1)
     rows = L.query("mivae_linear_wgrad_rows", N)
     if sink is not None and _DEFER is not None and rows <= 512:
         key = (sink[0].data_ptr(), rows, Fo * Fi + Fo)
+        _launch_pending()                          # at most one launch is held back at a time
         if key not in _DEFER:                      # a layer applied twice in one step takes the direct path below
             part = _PART_BUFS.get(key)
             if part is None or part.device != x2.device:
                 part = _PART_BUFS[key] = torch.empty(rows, Fo * Fi + Fo, dtype=torch.float32, device=x2.device)
+            if hold and Fi == Fo and Fi in (32, 64):
+                _PENDING = (x2, g2, key, part, sink)
+                sink_arrived(sink[0], sink[1])
+                return None
             L.call("mivae_linear_wgrad", L.ptr(x2), L.ptr(g2), L.ptr(part), N, Fi, Fo, L.stream())
             _DEFER[key] = (part, sink[0], sink[1], Fo * Fi)
             sink_arrived(sink[0], sink[1])

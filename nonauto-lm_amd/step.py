@@ -74,6 +74,7 @@ class TrainStep:
         finally:
             ops.GRAD_SINK = False
             ops._DEFER = None
+            ops._PENDING = None
             ops.SINK_NOTIFY = None
             self.reducer.before_launch = None
             self.reducer.compute_stream = None
