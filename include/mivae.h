@@ -399,6 +399,13 @@ int mivae_linear_dgrad_group(const void* const* dy, const void* const* w, void* 
 int mivae_ffn_fwd(const void* x, const float* gamma, const float* beta, const void* w1, const void* b1, const void* w2,
                   const void* b2, void* y, void* xn, void* hmid, float* mean, float* rstd, int64_t N, int64_t D,
                   int64_t H, float eps, int x_dtype, void* stream);
+/* Up to 16 weight-gradient problems over the same N tokens in one launch: every small-Linear weight gradient a training
+ * step's backward pass queued (nn/transformer.py:41-48, 129-130; posterior.py:19-27), issued together right before the
+ * partials are folded.  desc: nprob rows of 12 int64 in HOST memory, {Fo, Fi, G, x, dy[0..4), partial[0..4)} (device
+ * addresses); group == 0: single layers (G = 1), (Fo, Fi) in {(32,32), (32,64), (64,32), (64,64), (64,128), (128,64)};
+ * group != 0: groups of G in {2, 3} square layers (32 or 64 wide) sharing x.  Outputs as mivae_linear_wgrad /
+ * mivae_linear_wgrad_group write them; MIVAE_EUNSUPPORTED (-3) and no launch if a problem is outside those shapes. */
+int mivae_linear_wgrad_multi(const int64_t* desc, int64_t nprob, int64_t N, int group, void* stream);
 /* mivae_linear_wgrad(x0, dy0) -> partial0 and mivae_linear_wgrad_group(x, dy[0..G)) -> partial[0..G) in one launch, every
  * layer F x F over the same N tokens: the output projection of MultiHeadAttention and its q / k / v projections
  * (nn/transformer.py:41-48).  dy / partial: host arrays of G device pointers.  F in {32, 64}, G = 3; else -3. */

@@ -79,6 +79,7 @@ SIGNATURES = {
     "mivae_linear_wgrad_rows": [I64],
     "mivae_colsum_sink_multi": [P, I64, I64, P],
     "mivae_linear_wgrad_group": [P, P, P, I64, I64, I64, I64, P],
+    "mivae_linear_wgrad_multi": [P, I64, I64, I32, P],
     "mivae_linear_wgrad_single_group": [P, P, P, P, P, P, I64, I64, I64, P],
     "mivae_linear_wgrad_pair": [P, P, P, I64, I64, P, P, P, I64, I64, I64, P],
     "mivae_linear_dgrad_relu": [P, P, P, P, I64, I64, I64, P],

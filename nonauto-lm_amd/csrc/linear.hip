@@ -325,6 +325,55 @@ __global__ __launch_bounds__(256) void k_lin_wgrad2_sg(WgArgs a0, WgGroupArgs a1
   else wgrad2g_body<MO, MO, G>(a1, lds, blockIdx.x);
 }
 
+// Many weight-gradient problems over the same N tokens in one launch (blockIdx.y = problem): the training step queues
+// every small-Linear weight gradient of the backward pass and issues them together right before the partials are folded
+// (they feed nothing else), instead of one ~7 us latency-bound launch per layer / group.  Descriptors travel by value in
+// the kernel arguments (a captured graph bakes them in; no device table to keep alive).
+constexpr int kMaxMulti = 16;
+struct MultiWgArgs {
+  struct Prob {
+    const unsigned short* x;
+    const unsigned short* dy[kMaxGroup];
+    float* partial[kMaxGroup];
+    int Fo, Fi, G;
+  } p[kMaxMulti];
+  int64_t N;
+  int tiles_per_wave;
+};
+
+__global__ __launch_bounds__(256) void k_lin_wgrad_multi_single(MultiWgArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  const MultiWgArgs::Prob& p = a.p[blockIdx.y];
+  const WgArgs w = {p.x, p.dy[0], p.partial[0], a.N, p.Fo, p.Fi, a.tiles_per_wave};
+  const int code = (p.Fo / 32) * 8 + p.Fi / 32;          // block-uniform
+  switch (code) {
+    case 1 * 8 + 1: wgrad2_body<1, 1>(w, lds, blockIdx.x); break;
+    case 1 * 8 + 2: wgrad2_body<1, 2>(w, lds, blockIdx.x); break;
+    case 2 * 8 + 1: wgrad2_body<2, 1>(w, lds, blockIdx.x); break;
+    case 2 * 8 + 2: wgrad2_body<2, 2>(w, lds, blockIdx.x); break;
+    case 2 * 8 + 4: wgrad2_body<2, 4>(w, lds, blockIdx.x); break;
+    case 4 * 8 + 2: wgrad2_body<4, 2>(w, lds, blockIdx.x); break;
+    default: break;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_lin_wgrad_multi_group(MultiWgArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  const MultiWgArgs::Prob& p = a.p[blockIdx.y];
+  WgGroupArgs w = {};
+  w.x = p.x; w.N = a.N; w.tiles_per_wave = a.tiles_per_wave;
+#pragma unroll
+  for (int g = 0; g < kMaxGroup; ++g) { w.dy[g] = p.dy[g]; w.partial[g] = p.partial[g]; }
+  const int code = (p.Fo / 32) * 8 + p.G;                 // square layers: Fo == Fi
+  switch (code) {
+    case 1 * 8 + 2: wgrad2g_body<1, 1, 2>(w, lds, blockIdx.x); break;
+    case 1 * 8 + 3: wgrad2g_body<1, 1, 3>(w, lds, blockIdx.x); break;
+    case 2 * 8 + 2: wgrad2g_body<2, 2, 2>(w, lds, blockIdx.x); break;
+    case 2 * 8 + 3: wgrad2g_body<2, 2, 3>(w, lds, blockIdx.x); break;
+    default: break;
+  }
+}
+
 // ---- pre-norm feed-forward sublayer, forward, in one launch ----------------------------------------------------
 // y = x + W2 relu(W1 LN(x) + b1) + b2   (nn/transformer.py:147-162 SublayerConnection around :120-144
 // PositionwiseFeedForward; dropout inactive).  Everything is per token: a wave owns 32 tokens, normalises its rows in
@@ -676,6 +725,60 @@ extern "C" int mivae_linear_wgrad_pair(const void* x0, const void* dy0, float* p
     (void)hipFuncSetAttribute((const void*)k_lin_wgrad2_pair<2, 4, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   k_lin_wgrad2_pair<2, 4, 4, 2><<<dim3((unsigned)P, 2), 256, lds, S_(stream)>>>(a0, a1);
   MIVAE_CHECK_LAUNCH("linear_wgrad_pair");
+  return MIVAE_OK;
+}
+
+// nprob (<= 16) weight-gradient problems over the same N tokens in one launch.  desc: nprob rows of 12 int64 on the HOST:
+// {Fo, Fi, G, x, dy[0..4), partial[0..4)}.  group == 0: every problem is a single layer (G = 1) with (Fo, Fi) in
+// {(32,32), (32,64), (64,32), (64,64), (64,128), (128,64)}; group != 0: every problem is a group of G in {2, 3} square
+// layers (Fo = Fi in {32, 64}) sharing x.  Results as mivae_linear_wgrad / mivae_linear_wgrad_group write them.
+// Returns MIVAE_EUNSUPPORTED (-3) if any problem is outside those shapes (nothing is launched then).
+extern "C" int mivae_linear_wgrad_multi(const int64_t* desc, int64_t nprob, int64_t N, int group, void* stream) {
+  MIVAE_REQUIRE(N >= 1 && N < (1ll << 31), "linear_wgrad_multi: bad N");
+  MIVAE_REQUIRE(desc && nprob >= 1 && nprob <= kMaxMulti, "linear_wgrad_multi: 1 .. %d problems", kMaxMulti);
+  MultiWgArgs a = {};
+  a.N = N;
+  int64_t P;
+  wgrad_geom(N, a.tiles_per_wave, P);
+  size_t lds = 0;
+  for (int i = 0; i < nprob; ++i) {
+    const int64_t* d = desc + 12 * i;
+    const int64_t Fo = d[0], Fi = d[1], G = d[2];
+    bool ok;
+    if (group) ok = Fo == Fi && (Fo == 32 || Fo == 64) && (G == 2 || G == 3);
+    else ok = G == 1 && ((Fo == 32 && (Fi == 32 || Fi == 64)) || (Fo == 64 && (Fi == 32 || Fi == 64 || Fi == 128)) ||
+                         (Fo == 128 && Fi == 64));
+    if (!ok) {
+      mivae_set_error("linear_wgrad_multi: unsupported problem %d (Fo=%lld Fi=%lld G=%lld)", i, (long long)Fo, (long long)Fi,
+                      (long long)G);
+      return MIVAE_EUNSUPPORTED;
+    }
+    MultiWgArgs::Prob& p = a.p[i];
+    p.Fo = (int)Fo; p.Fi = (int)Fi; p.G = (int)G;
+    p.x = reinterpret_cast<const unsigned short*>(d[3]);
+    MIVAE_REQUIRE(p.x && aligned16(p.x), "linear_wgrad_multi: null or misaligned x");
+    for (int g = 0; g < G; ++g) {
+      p.dy[g] = reinterpret_cast<const unsigned short*>(d[4 + g]);
+      p.partial[g] = reinterpret_cast<float*>(d[8 + g]);
+      MIVAE_REQUIRE(p.dy[g] && p.partial[g] && aligned16(p.dy[g]) && aligned16(p.partial[g]),
+                    "linear_wgrad_multi: null or misaligned pointer");
+    }
+    const size_t so = (size_t)Fo + (Fo == 32 ? 0 : 32), si = (size_t)Fi + (Fi == 32 ? 0 : 32);
+    const size_t need = group ? (size_t)kSlab * si * 2 * (size_t)(G + 1) : (size_t)kSlab * (so + si) * 2;
+    if (need > lds) lds = need;
+  }
+  const dim3 grid((unsigned)P, (unsigned)nprob);
+  hipStream_t st = S_(stream);
+  if (group) {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)k_lin_wgrad_multi_group, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    k_lin_wgrad_multi_group<<<grid, 256, lds, st>>>(a);
+  } else {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)k_lin_wgrad_multi_single, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    k_lin_wgrad_multi_single<<<grid, 256, lds, st>>>(a);
+  }
+  MIVAE_CHECK_LAUNCH("linear_wgrad_multi");
   return MIVAE_OK;
 }
 

@@ -896,30 +896,64 @@ def sink_arrived(*grads) -> None:
                 SINK_NOTIFY(g)
 
 
-# A deferred small weight-gradient launch held back for a partner (the output projection of self-attention waits for
-# the q / k / v group of the same sublayer: one launch for both, mivae_linear_wgrad_single_group).  Its arrival is
-# reported when it is stashed; whoever folds or reduces gradients goes through flush_grad_sinks(), which enqueues a
-# still-pending launch first, on the same stream, so the order partials -> fold -> reduce holds either way.
-_PENDING = None
+# Queued weight gradients.  In deferred-sink mode the small-Linear weight-gradient problems of a backward pass are not
+# launched where autograd reaches them: they feed nothing but the gradient buckets, so they are queued (inputs kept
+# alive, partial buffers registered with the fold, arrival reported to the reducer) and issued together -- up to 16
+# problems per launch, mivae_linear_wgrad_multi -- by flush_grad_sinks() right before anything is folded or reduced,
+# on the same stream: partials -> fold -> reduce keeps its order.  WGRAD_QUEUE = False restores launch-at-once (with the
+# hand-paired launches: feed-forward pair, output projection + q / k / v group).
+WGRAD_QUEUE = True
+_QUEUE = []               # (x2, [dy...], [partial...])
+_SINGLE_SHAPES = {(32, 32), (32, 64), (64, 32), (64, 64), (64, 128), (128, 64)}      # (Fo, Fi) of the multi launch
+_PENDING = None           # WGRAD_QUEUE off: the output projection's launch waiting for its q / k / v group
+
+
+def _launch_one(x2, gs, parts):
+    N, Fi = x2.shape
+    Fo = gs[0].size(1)
+    if len(gs) == 1:
+        L.call("mivae_linear_wgrad", L.ptr(x2), L.ptr(gs[0]), L.ptr(parts[0]), N, Fi, Fo, L.stream())
+    else:
+        L.call("mivae_linear_wgrad_group", L.ptr(x2), _ptr_array(gs), _ptr_array(parts), len(gs), N, Fi, Fo, L.stream())
 
 
 def _launch_pending() -> None:
-    global _PENDING
-    if _PENDING is None:
+    global _PENDING, _QUEUE
+    if _PENDING is not None:
+        x2, g2, key, part, sink = _PENDING
+        _PENDING = None
+        _launch_one(x2, [g2], [part])
+        if _DEFER is not None:
+            _DEFER[key] = (part, sink[0], sink[1], g2.size(1) * x2.size(1))
+    if not _QUEUE:
         return
-    x2, g2, key, part, sink = _PENDING
-    _PENDING = None
-    N, Fi = x2.shape
-    Fo = g2.size(1)
-    L.call("mivae_linear_wgrad", L.ptr(x2), L.ptr(g2), L.ptr(part), N, Fi, Fo, L.stream())
-    if _DEFER is not None:
-        _DEFER[key] = (part, sink[0], sink[1], Fo * Fi)
+    import ctypes
+    probs, _QUEUE = _QUEUE, []
+    by = {}
+    for pr in probs:
+        by.setdefault((pr[0].size(0), len(pr[1]) > 1), []).append(pr)
+    for (N, group), lst in by.items():
+        for i in range(0, len(lst), 16):
+            chunk = lst[i:i + 16]
+            flat = []
+            for x2, gs, parts in chunk:
+                flat += [gs[0].size(1), x2.size(1), len(gs), x2.data_ptr()]
+                flat += [g.data_ptr() for g in gs] + [0] * (4 - len(gs))
+                flat += [p_.data_ptr() for p_ in parts] + [0] * (4 - len(parts))
+            desc = (ctypes.c_int64 * len(flat))(*flat)
+            rc = L.query("mivae_linear_wgrad_multi", desc, len(chunk), N, int(group), L.stream())
+            if rc == -3:                       # a shape the multi launch is not instantiated for: one by one
+                for x2, gs, parts in chunk:
+                    _launch_one(x2, gs, parts)
+            elif rc != 0:
+                raise RuntimeError(f"mivae_linear_wgrad_multi failed ({rc}): {L.lib().mivae_last_error().decode()}")
 
 
 def begin_deferred_sinks():
-    global _DEFER, _PENDING
+    global _DEFER, _PENDING, _QUEUE
     _DEFER = {}
     _PENDING = None
+    _QUEUE = []
 
 
 def flush_grad_sinks(lo: Optional[int] = None, hi: Optional[int] = None):
@@ -1083,7 +1117,9 @@ def linear_wgrad_group_deferred(x2, gs, sinks) -> bool:
         parts.append(part)
     global _PENDING
     pend = _PENDING
-    if (pend is not None and len(gs) == 3 and pend[0].shape == (N, Fi) and pend[1].shape == (N, Fo)
+    if WGRAD_QUEUE and len(gs) in (2, 3):
+        _QUEUE.append((x2, list(gs), parts))
+    elif (pend is not None and len(gs) == 3 and pend[0].shape == (N, Fi) and pend[1].shape == (N, Fo)
             and pend[2] not in keys):
         _PENDING = None          # the held-back single layer (output projection) rides along: one launch for four layers
         L.call("mivae_linear_wgrad_single_group", L.ptr(pend[0]), L.ptr(pend[1]), L.ptr(pend[3]), L.ptr(x2), _ptr_array(gs),
@@ -1208,8 +1244,12 @@ def linear_wgrad_pair_deferred(x0, g0, sink0, x1, g1, sink1) -> bool:
         if part is None or part.device != x0.device:
             part = _PART_BUFS[k] = torch.empty(rows, k[2], dtype=torch.float32, device=x0.device)
         parts.append(part)
-    L.call("mivae_linear_wgrad_pair", L.ptr(x0), L.ptr(g0), L.ptr(parts[0]), Fi0, Fo0, L.ptr(x1), L.ptr(g1), L.ptr(parts[1]),
-           Fi1, Fo1, N, L.stream())
+    if WGRAD_QUEUE:
+        _QUEUE.append((x0, [g0], [parts[0]]))
+        _QUEUE.append((x1, [g1], [parts[1]]))
+    else:
+        L.call("mivae_linear_wgrad_pair", L.ptr(x0), L.ptr(g0), L.ptr(parts[0]), Fi0, Fo0, L.ptr(x1), L.ptr(g1),
+               L.ptr(parts[1]), Fi1, Fo1, N, L.stream())
     _DEFER[k0] = (parts[0], sink0[0], sink0[1], Fo0 * Fi0)
     _DEFER[k1] = (parts[1], sink1[0], sink1[1], Fo1 * Fi1)
     sink_arrived(sink0[0], sink0[1])
@@ -1227,11 +1267,17 @@ def linear_wgrad(x2, g2, sink=None, hold=False):
     rows = L.query("mivae_linear_wgrad_rows", N)
     if sink is not None and _DEFER is not None and rows <= 512:
         key = (sink[0].data_ptr(), rows, Fo * Fi + Fo)
-        _launch_pending()                          # at most one launch is held back at a time
+        if not WGRAD_QUEUE:
+            _launch_pending()                      # at most one launch is held back at a time
         if key not in _DEFER:                      # a layer applied twice in one step takes the direct path below
             part = _PART_BUFS.get(key)
             if part is None or part.device != x2.device:
                 part = _PART_BUFS[key] = torch.empty(rows, Fo * Fi + Fo, dtype=torch.float32, device=x2.device)
+            if WGRAD_QUEUE and (Fo, Fi) in _SINGLE_SHAPES:
+                _QUEUE.append((x2, [g2], [part]))
+                _DEFER[key] = (part, sink[0], sink[1], Fo * Fi)
+                sink_arrived(sink[0], sink[1])
+                return None
             if hold and Fi == Fo and Fi in (32, 64):
                 _PENDING = (x2, g2, key, part, sink)
                 sink_arrived(sink[0], sink[1])

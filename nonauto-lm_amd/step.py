@@ -75,6 +75,7 @@ class TrainStep:
             ops.GRAD_SINK = False
             ops._DEFER = None
             ops._PENDING = None
+            ops._QUEUE = []
             ops.SINK_NOTIFY = None
             self.reducer.before_launch = None
             self.reducer.compute_stream = None

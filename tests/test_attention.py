@@ -192,7 +192,7 @@ def test_wide_qkv_group_matches_layerwise(monkeypatch):
             assert (a - b).abs().max() <= 2e-2 * max(b.abs().max().item(), 1.0), key
 
 
-def test_linear_wgrad_pair_bit_equal_to_two_launches():
+def test_linear_wgrad_pair_bit_equal_to_two_launches(monkeypatch):
     """mivae_linear_wgrad_pair (both weight gradients of a feed-forward sublayer in one launch, deferred sinks) folds to
     exactly what two mivae_linear_wgrad launches fold to"""
     from nonauto_lm_amd import ops
@@ -201,7 +201,8 @@ def test_linear_wgrad_pair_bit_equal_to_two_launches():
     hmid, dy = torch.randn(N, H, device="cuda").to(torch.bfloat16), torch.randn(N, D, device="cuda").to(torch.bfloat16)
     xn, dh = torch.randn(N, D, device="cuda").to(torch.bfloat16), torch.randn(N, H, device="cuda").to(torch.bfloat16)
     outs = []
-    for pair in (True, False):
+    for pair, queue in ((True, True), (True, False), (False, True), (False, False)):    # queued multi launch / hand-paired
+        monkeypatch.setattr(ops, "WGRAD_QUEUE", queue)
         gw2, gb2 = torch.zeros(D, H, device="cuda"), torch.zeros(D, device="cuda")
         gw1, gb1 = torch.zeros(H, D, device="cuda"), torch.zeros(H, device="cuda")
         ops.begin_deferred_sinks()
@@ -215,7 +216,38 @@ def test_linear_wgrad_pair_bit_equal_to_two_launches():
         finally:
             ops._DEFER = None
         outs.append((gw2, gb2, gw1, gb1))
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
     ref = dy.float().t() @ hmid.float()
     assert (outs[0][0] - ref).abs().max() <= 1e-3 * ref.abs().max()
+
+
+def test_queued_weight_gradients_match_immediate_launches(monkeypatch):
+    """a transformer layer's backward with deferred sinks: the queued weight gradients (one multi-problem launch per kind at
+    flush) give bit-identical parameter gradients to launching them where autograd reaches them"""
+    from nonauto_lm_amd import nn_bracket as nb, ops
+    torch.manual_seed(13)
+    layer = nb._TransformerLayer(64, 128, 4, dropout=0.0).cuda()
+    x = torch.randn(256, 64, 64, device="cuda")
+    mask = torch.ones(256, 64, dtype=torch.long, device="cuda")
+    grads = []
+    for queue in (True, False):
+        monkeypatch.setattr(ops, "WGRAD_QUEUE", queue)
+        for p in layer.parameters():
+            p.grad = torch.zeros_like(p)
+        xx = x.clone().requires_grad_(True)
+        ops.GRAD_SINK = True
+        ops.begin_deferred_sinks()
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = layer(xx, mask)
+            y.float().square().mean().backward()
+            ops.flush_grad_sinks()
+        finally:
+            ops.GRAD_SINK = False
+            ops._DEFER = None
+        grads.append([p.grad.clone() for p in layer.parameters()] + [xx.grad.clone()])
+    assert any(g.abs().max() > 0 for g in grads[0][:-1])
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
