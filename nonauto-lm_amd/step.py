@@ -50,6 +50,12 @@ class TrainStep:
         self.graph_a = self.graph_b = None
         self.comm_in_graph = False
         self.grad_sink = True
+        self._seed = None
+        # device-side metric sums (batch-nll, batch-kl) updated by ONE launch inside graph B; the model's RunningMean
+        # accumulators point at them (was: two clones + two adds launched after every replay)
+        self._acc = torch.zeros(2, dtype=torch.float32, device=tokens.device) if tokens.is_cuda else None
+        self._acc_views = None if self._acc is None else (self._acc[0], self._acc[1])
+        self._want_track = False
         self._pinned = None
         # scheduler weights on the device (read by mivae_elbo_fwd / _bwd)
         self._w_dev = torch.zeros(2, dtype=torch.float32, device=tokens.device)
@@ -84,7 +90,10 @@ class TrainStep:
         with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
             out = self.model(self.tokens, self.tokens, eps=self.eps)
         info = out["loss_info"]
-        info["batch-loss"].backward()
+        loss = info["batch-loss"]
+        if self._seed is None or self._seed.device != loss.device or self._seed.dtype != loss.dtype:
+            self._seed = torch.ones((), dtype=loss.dtype, device=loss.device)
+        loss.backward(gradient=self._seed)       # a cached seed: no ones_like launch per step
         return {k: info[k] for k in ("batch-loss", "batch-kl", "batch-nll")}
 
     def _update(self):
@@ -153,7 +162,8 @@ class TrainStep:
         m = self.model
         m.device_weights = self._w_dev
         track = m.track_metrics
-        m.track_metrics = False                   # host-side accumulators: fed from the static outputs in __call__
+        m.track_metrics = False                   # the accumulators are fed by graph B (see _acc), counted in __call__
+        self._want_track = bool(track)
         # the AccumulateGrad nodes (kept alive by the reducer's hooks) were created on the default stream while
         # capture runs on torch's capture stream: intentional, the buckets are only touched inside the graphs
         quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
@@ -216,6 +226,9 @@ class TrainStep:
             graph_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph_b, pool=graph_a.pool(), capture_error_mode="thread_local"):
                 self._update()
+                if self._want_track and self._acc is not None:
+                    torch._foreach_add_(list(self._acc_views), [self.info["batch-nll"].detach().float(),
+                                                                self.info["batch-kl"].detach().float()])
             self.graph_a, self.graph_b, self.comm_in_graph = graph_a, graph_b, comm
             return True
         except RuntimeError as err:
@@ -248,6 +261,15 @@ class TrainStep:
             self._update()
             return self.info
         m = self.model
+        if self._track:                           # (re)attach the model's running sums to the graph's accumulators
+            for name, view in zip(("nll", "avg-kl"), self._acc_views):
+                rm = m._metrics[name]
+                if rm.total is not view:
+                    if isinstance(rm.total, torch.Tensor):
+                        view.copy_(rm.total)
+                    else:
+                        view.fill_(0.0 if rm.total is None else float(rm.total))
+                    rm.total = view
         self._push_weights()                      # the weights this step is computed with
         self.graph_a.replay()
         if self.world > 1 and not self.comm_in_graph:
@@ -257,8 +279,9 @@ class TrainStep:
         if m.training:                            # what VAELmModel.forward does after the loss (model.py:180-184)
             m.kl_scheduler_step()
             m._recon_scheduler.step()
-        if self._track:
-            # (clones: the static graph outputs are overwritten by the next replay)
-            m.update_metrics(self.info["batch-nll"].clone(), self.info["batch-kl"].clone(),
-                             m._recon_scheduler.weight, m._kl_scheduler.weight)
+        if self._track:                           # graph B added batch-nll / batch-kl into the running sums
+            m._metrics["nll"].count += 1
+            m._metrics["avg-kl"].count += 1
+            m._metrics["avg-recon-weight"].update(m._recon_scheduler.weight)
+            m._metrics["avg-kl-weight"].update(m._kl_scheduler.weight)
         return self.info

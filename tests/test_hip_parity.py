@@ -650,6 +650,36 @@ def test_train_step_graph_replay(M):
     assert abs(losses[True][-1] - losses[False][-1]) < 0.25 * abs(losses[False][0])
 
 
+def test_train_step_graph_metrics(M):
+    """the graph-replayed step keeps the model's running metrics (models/base/model.py:200-210) on the device: graph B
+    adds batch-nll / batch-kl into the accumulators; get_metrics() == the mean of the per-step values, also after a
+    reset"""
+    import math
+    import bench
+    from nonauto_lm_amd import dp
+    from nonauto_lm_amd.step import TrainStep
+    torch.manual_seed(13)
+    model = M.VAELmModel.from_params(vocab=M.SimpleVocab(200), **bench.model_config(32, 32, 2)).to(DEV).train()
+    model.training_outputs_only = True
+    reducer = dp.GradReducer(model.parameters())
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, foreach=True, capturable=True)
+    tokens = bench.synthetic_tokens(16, 12, True, 7)
+    tokens = torch.where(tokens > 0, tokens % 196 + 4, tokens).to(DEV)
+    step = TrainStep(model, reducer, opt, tokens, None, 5.0, 2.0, graph=True, warmup=1)
+    if step.graph_a is None:
+        pytest.skip("graph capture unavailable")
+    for rounds in (3, 2):
+        nll, kl = [], []
+        for _ in range(rounds):
+            info = step()
+            nll.append(float(info["batch-nll"]))
+            kl.append(float(info["batch-kl"]))
+        got = model.get_metrics(reset=True)
+        assert abs(got["avg-nll"] - sum(nll) / rounds) <= 1e-4 * abs(sum(nll) / rounds)
+        assert abs(got["avg-kl"] - sum(kl) / rounds) <= 1e-4 * abs(sum(kl) / rounds) + 1e-6
+        assert abs(got["ppl"] - math.exp(got["avg-nll"])) <= 1e-3 * got["ppl"] or got["ppl"] == float("inf")
+
+
 @pytest.mark.parametrize("max_norm,max_value,wd", [(5.0, 2.0, 0.0), (0.05, None, 0.0), (None, 0.01, 0.01), (None, None, 0.0)])
 def test_fused_adam_matches_torch(M, max_norm, max_value, wd):
     """dp.FusedAdam (clip_grad_norm_ + clip_grad_value_ + Adam + zero_grad in one pass over the flat buckets) vs
