@@ -458,6 +458,12 @@ int64_t mivae_layernorm_bwd_partial(const void* dy, const void* x, const float* 
 int64_t mivae_layernorm_bwd_partial_add(const void* dy, const void* x, const float* gamma, const float* mean,
                                         const float* rstd, const void* add, void* dx, float* workspace, int64_t rows,
                                         int64_t D, int in_dtype, int out_dtype, void* stream);
+/* mivae_layernorm_bwd_partial_add that also writes dx rounded to bf16 into dx16 (rows, D): the gradient of the fp32
+ * residual stream in the dtype the previous sublayer's projection backward works in (SublayerConnection,
+ * nn/transformer.py:147-162), so that backward launches no cast. */
+int64_t mivae_layernorm_bwd_partial_add_twin(const void* dy, const void* x, const float* gamma, const float* mean,
+                                             const float* rstd, const void* add, void* dx, void* dx16, float* workspace,
+                                             int64_t rows, int64_t D, int in_dtype, int out_dtype, void* stream);
 
 /* ---- step-harness tail on flat buffers ---------------------------------------------------------- */
 /* Gradient clipping + Adam + zero_grad of DefaultTrainer._train_batch (training/trainers/trainer.py:286-289

@@ -89,6 +89,7 @@ SIGNATURES = {
     "mivae_linear_dgrad_group": [P, P, P, I64, I64, I64, I64, P],
     "mivae_layernorm_bwd_partial": [P, P, P, P, P, P, P, I64, I64, I32, I32, P],
     "mivae_layernorm_bwd_partial_add": [P, P, P, P, P, P, P, P, I64, I64, I32, I32, P],
+    "mivae_layernorm_bwd_partial_add_twin": [P, P, P, P, P, P, P, P, P, I64, I64, I32, I32, P],
     "mivae_lce_pack2": [P, P, P, P, I64, I64, P],
     "mivae_lce_dh_workspace_floats": [I64, I64, I64],
     "mivae_lce_bwd_dh": [P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P],
@@ -136,6 +137,7 @@ _RET = {
     "mivae_lce_pack_elems": I64,
     "mivae_layernorm_bwd_partial": I64,
     "mivae_layernorm_bwd_partial_add": I64,
+    "mivae_layernorm_bwd_partial_add_twin": I64,
     "mivae_lce_dh_workspace_floats": I64,
     "mivae_linear_wgrad_rows": I64,
     "mivae_layernorm_workspace_floats": I64,

@@ -68,7 +68,8 @@ __global__ __launch_bounds__(kBlock) void k_ln_bwd(const TO* __restrict__ dy, co
                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
                                                     const float* __restrict__ rstd, TI* __restrict__ dx,
                                                     float* __restrict__ partial, int64_t rows, int rows_per_block,
-                                                    int D, int L, const TI* __restrict__ add) {
+                                                    int D, int L, const TI* __restrict__ add,
+                                                    unsigned short* __restrict__ dx16) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // [rif][2][L * VEC * kMaxChunks]
   const int rif = kBlock / L;
   const int rg = threadIdx.x / L, lig = threadIdx.x % L;
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(kBlock) void k_ln_bwd(const TO* __restrict__ dy, co
             for (int i = 0; i < VEC; ++i) o[i] += r[i];
           }
           RowIO<TI, VEC>::store(dx + row * D + c, o);
+          if (dx16) RowIO<unsigned short, VEC>::store(dx16 + row * D + c, o);   // bf16 twin for the next projection's backward
         }
       }
     }
@@ -200,14 +202,14 @@ void launch_fwd(int vec, const void* x, const float* g, const float* b, void* y,
 }
 template <typename TI, typename TO>
 void launch_bwd(const LnCfg& c, const void* dy, const void* x, const float* g, const float* mean, const float* rstd,
-                void* dx, float* partial, int64_t rows, int D, hipStream_t st, const void* add) {
+                void* dx, float* partial, int64_t rows, int D, hipStream_t st, const void* add, void* dx16) {
   const size_t smem = (size_t)(kBlock / c.L) * 2 * c.L * c.vec * kMaxChunks * sizeof(float);
   if (c.vec == 4)
     k_ln_bwd<TI, TO, 4><<<c.nblk, kBlock, smem, st>>>((const TO*)dy, (const TI*)x, g, mean, rstd, (TI*)dx, partial,
-                                                      rows, c.rows_per_block, D, c.L, (const TI*)add);
+                                                      rows, c.rows_per_block, D, c.L, (const TI*)add, (unsigned short*)dx16);
   else
     k_ln_bwd<TI, TO, 1><<<c.nblk, kBlock, smem, st>>>((const TO*)dy, (const TI*)x, g, mean, rstd, (TI*)dx, partial,
-                                                      rows, c.rows_per_block, D, c.L, (const TI*)add);
+                                                      rows, c.rows_per_block, D, c.L, (const TI*)add, (unsigned short*)dx16);
 }
 
 }  // namespace
@@ -244,7 +246,7 @@ extern "C" int mivae_layernorm_fwd(const void* x, const float* gamma, const floa
 static int layernorm_bwd_impl(const void* dy, const void* x, const float* gamma, const float* mean,
                               const float* rstd, void* dx, float* dgamma_dbeta, float* dbeta_sink, float* workspace,
                               int64_t rows, int64_t D, int in_dtype, int out_dtype, void* stream,
-                              int* nblk_out = nullptr, const void* add = nullptr) {
+                              int* nblk_out = nullptr, const void* add = nullptr, void* dx16 = nullptr) {
   MIVAE_REQUIRE(rows >= 1 && D >= 1, "layernorm_bwd: bad shape");
   MIVAE_REQUIRE((in_dtype == MIVAE_F32 || in_dtype == MIVAE_BF16) && (out_dtype == MIVAE_F32 || out_dtype == MIVAE_BF16),
                 "layernorm_bwd: dtype must be 0 (f32) or 1 (bf16)");
@@ -254,10 +256,10 @@ static int layernorm_bwd_impl(const void* dy, const void* x, const float* gamma,
   MIVAE_REQUIRE(ln_cfg(rows, D, D % 4 == 0 && aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(add), c),
                 "layernorm_bwd: D = %lld too wide for this kernel", (long long)D);
   hipStream_t st = S_(stream);
-  if (in_dtype == MIVAE_F32 && out_dtype == MIVAE_F32) launch_bwd<float, float>(c, dy, x, gamma, mean, rstd, dx, workspace, rows, (int)D, st, add);
-  else if (in_dtype == MIVAE_F32) launch_bwd<float, unsigned short>(c, dy, x, gamma, mean, rstd, dx, workspace, rows, (int)D, st, add);
-  else if (out_dtype == MIVAE_F32) launch_bwd<unsigned short, float>(c, dy, x, gamma, mean, rstd, dx, workspace, rows, (int)D, st, add);
-  else launch_bwd<unsigned short, unsigned short>(c, dy, x, gamma, mean, rstd, dx, workspace, rows, (int)D, st, add);
+  if (in_dtype == MIVAE_F32 && out_dtype == MIVAE_F32) launch_bwd<float, float>(c, dy, x, gamma, mean, rstd, dx, workspace, rows, (int)D, st, add, dx16);
+  else if (in_dtype == MIVAE_F32) launch_bwd<float, unsigned short>(c, dy, x, gamma, mean, rstd, dx, workspace, rows, (int)D, st, add, dx16);
+  else if (out_dtype == MIVAE_F32) launch_bwd<unsigned short, float>(c, dy, x, gamma, mean, rstd, dx, workspace, rows, (int)D, st, add, dx16);
+  else launch_bwd<unsigned short, unsigned short>(c, dy, x, gamma, mean, rstd, dx, workspace, rows, (int)D, st, add, dx16);
   MIVAE_CHECK_LAUNCH("layernorm_bwd");
   if (nblk_out) { *nblk_out = c.nblk; return MIVAE_OK; }    // partials only: the caller folds them
   const int total = 2 * (int)D;
@@ -303,5 +305,22 @@ extern "C" int64_t mivae_layernorm_bwd_partial_add(const void* dy, const void* x
   int nblk = 0;
   const int rc = layernorm_bwd_impl(dy, x, gamma, mean, rstd, dx, nullptr, nullptr, workspace, rows, D, in_dtype,
                                     out_dtype, stream, &nblk, add);
+  return rc == MIVAE_OK ? (int64_t)nblk : (int64_t)rc;
+}
+
+// mivae_layernorm_bwd_partial_add that also writes dx rounded to bf16 into dx16 (rows, D): the fp32 residual stream's
+// gradient feeds the previous sublayer's projections, whose backward works on bf16 (one cast launch less per sublayer).
+extern "C" int64_t mivae_layernorm_bwd_partial_add_twin(const void* dy, const void* x, const float* gamma,
+                                                        const float* mean, const float* rstd, const void* add, void* dx,
+                                                        void* dx16, float* workspace, int64_t rows, int64_t D,
+                                                        int in_dtype, int out_dtype, void* stream) {
+  if (!add || !dx16) { mivae_set_error("layernorm_bwd_partial_add_twin: null pointer"); return MIVAE_EINVAL; }
+  if (D % 4 == 0 && (reinterpret_cast<uintptr_t>(dx16) & 7)) {
+    mivae_set_error("layernorm_bwd_partial_add_twin: dx16 must be 8-byte aligned");
+    return MIVAE_EINVAL;
+  }
+  int nblk = 0;
+  const int rc = layernorm_bwd_impl(dy, x, gamma, mean, rstd, dx, nullptr, nullptr, workspace, rows, D, in_dtype,
+                                    out_dtype, stream, &nblk, add, dx16);
   return rc == MIVAE_OK ? (int64_t)nblk : (int64_t)rc;
 }

@@ -144,7 +144,7 @@ class _LinearResidualFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        g16 = gy if gy.dtype == torch.bfloat16 else gy.to(torch.bfloat16)    # the cast autograd makes for `res + y`
+        g16 = ops.to_bf16(gy.contiguous())       # the cast autograd makes for `res + y` (or the LayerNorm backward's twin)
         gx, gw, gb, _, _ = _SplitKLinearFn.backward(ctx, g16)
         return gx, gw, gb, None, None, (gy if ctx.needs_input_grad[5] else None)
 
@@ -343,7 +343,7 @@ class _FfnBlockFn(torch.autograd.Function):
         x2, gamma, xn, hmid, stats, w1l, w2l = ctx.saved_tensors
         g, be, w1, b1, w2, b2 = ctx.params
         dy2 = dy.contiguous().view(-1, dy.size(-1))
-        dy16 = dy2 if dy2.dtype == torch.bfloat16 else dy2.to(torch.bfloat16)
+        dy16 = ops.to_bf16(dy2)                  # fp32 stream: the bf16 twin the LayerNorm backward wrote, if any
         dh = ops.linear_dgrad_relu(dy16, w2l, hmid)                        # (N, H), relu' applied on store
         grads = {}
         if (ops.grad_sink_ok(w1, b1) and ops.grad_sink_ok(w2, b2)

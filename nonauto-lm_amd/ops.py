@@ -771,6 +771,29 @@ def layer_norm_bwd(dy2, x2, weight, stats, params, add=None):
     return _layer_norm_bwd(dy2, x2, weight, stats, params, None)
 
 
+# bf16 twin of the latest fp32 residual-stream gradient (written by the LayerNorm backward kernel).  The cache holds the
+# fp32 tensor itself, so its storage cannot be handed to another tensor while the entry lives; a consumer gets the twin
+# only for a tensor with the same storage start, shape, dtype and version -- i.e. the same, unmodified values.
+BF16_TWIN = True
+_TWIN = None
+
+
+def _set_twin(t32, t16) -> None:
+    global _TWIN
+    _TWIN = (t32, t32._version, t16)
+
+
+def to_bf16(t: torch.Tensor) -> torch.Tensor:
+    """t.to(bfloat16), without a launch when `t` is the fp32 gradient whose bf16 twin the LayerNorm backward just wrote"""
+    if t.dtype == torch.bfloat16:
+        return t
+    tw = _TWIN
+    if (tw is not None and t.dtype == torch.float32 and t.data_ptr() == tw[0].data_ptr() and t.numel() == tw[0].numel()
+            and t.is_contiguous() and t._version == tw[1] and tw[0]._version == tw[1]):
+        return tw[2].view(t.shape)
+    return t.to(torch.bfloat16)
+
+
 def _layer_norm_bwd(dy2, x2, weight, stats, params, add):
     rows, D = x2.shape
     dx = torch.empty_like(x2)
@@ -782,7 +805,15 @@ def _layer_norm_bwd(dy2, x2, weight, stats, params, add):
             wsp = _PART_BUFS.get(key)
             if wsp is None or wsp.device != x2.device:
                 wsp = _PART_BUFS[key] = torch.empty_like(ws)
-            if add is not None:
+            if add is not None and BF16_TWIN and x2.dtype == torch.float32 and D <= 128:     # widths of the small-Linear kernels,
+                                                                                        # whose backward asks for it (to_bf16)
+                # fp32 residual stream: dx also lands as bf16, for the previous sublayer's projection backward
+                dx16 = torch.empty(rows, D, dtype=torch.bfloat16, device=x2.device)
+                nblk = L.query("mivae_layernorm_bwd_partial_add_twin", L.ptr(dy2), L.ptr(x2), L.ptr(weight), L.ptr(stats[0]),
+                               L.ptr(stats[1]), L.ptr(add), L.ptr(dx), L.ptr(dx16), L.ptr(wsp), rows, D,
+                               L.dtype_code(x2.dtype), L.dtype_code(dy2.dtype), L.stream())
+                _set_twin(dx, dx16)
+            elif add is not None:
                 nblk = L.query("mivae_layernorm_bwd_partial_add", L.ptr(dy2), L.ptr(x2), L.ptr(weight), L.ptr(stats[0]),
                                L.ptr(stats[1]), L.ptr(add), L.ptr(dx), L.ptr(wsp), rows, D, L.dtype_code(x2.dtype),
                                L.dtype_code(dy2.dtype), L.stream())
@@ -950,10 +981,11 @@ def _launch_pending() -> None:
 
 
 def begin_deferred_sinks():
-    global _DEFER, _PENDING, _QUEUE
+    global _DEFER, _PENDING, _QUEUE, _TWIN
     _DEFER = {}
     _PENDING = None
     _QUEUE = []
+    _TWIN = None
 
 
 def flush_grad_sinks(lo: Optional[int] = None, hi: Optional[int] = None):

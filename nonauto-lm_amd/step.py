@@ -82,6 +82,7 @@ class TrainStep:
             ops._DEFER = None
             ops._PENDING = None
             ops._QUEUE = []
+            ops._TWIN = None
             ops.SINK_NOTIFY = None
             self.reducer.before_launch = None
             self.reducer.compute_stream = None

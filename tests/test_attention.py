@@ -251,3 +251,42 @@ def test_queued_weight_gradients_match_immediate_launches(monkeypatch):
     assert any(g.abs().max() > 0 for g in grads[0][:-1])
     for a, b in zip(*grads):
         assert torch.equal(a, b)
+
+
+def test_bf16_twin_of_residual_gradient(monkeypatch):
+    """encoder-style fp32 residual stream: with the bf16 twin written by the LayerNorm backward the layer's backward is
+    bit-identical to casting the fp32 gradient (and the twin is only handed out for the very tensor it mirrors)"""
+    from nonauto_lm_amd import nn_bracket as nb, ops
+    torch.manual_seed(17)
+    layers = torch.nn.ModuleList([nb._TransformerLayer(64, 128, 4, dropout=0.0) for _ in range(2)]).cuda()
+    x = torch.randn(256, 64, 64, device="cuda")
+    mask = torch.ones(256, 64, dtype=torch.long, device="cuda")
+    grads = []
+    for twin in (True, False):
+        monkeypatch.setattr(ops, "BF16_TWIN", twin)
+        for p in layers.parameters():
+            p.grad = torch.zeros_like(p)
+        xx = x.clone().requires_grad_(True)
+        ops.GRAD_SINK = True
+        ops.begin_deferred_sinks()
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = xx
+                for l in layers:
+                    y = l(y, mask)
+            y.float().square().mean().backward()
+            ops.flush_grad_sinks()
+        finally:
+            ops.GRAD_SINK = False
+            ops._DEFER = None
+        grads.append([p.grad.clone() for p in layers.parameters()] + [xx.grad.clone()])
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
+    t32 = torch.randn(8, 64, device="cuda")
+    ops._set_twin(t32, t32.to(torch.bfloat16))
+    other = torch.randn(8, 64, device="cuda")
+    assert ops.to_bf16(other).data_ptr() != ops._TWIN[2].data_ptr()
+    assert ops.to_bf16(t32).data_ptr() == ops._TWIN[2].data_ptr()
+    t32.add_(1.0)                                         # modified in place: the twin is stale, a fresh cast is returned
+    assert ops.to_bf16(t32).data_ptr() != ops._TWIN[2].data_ptr()
+    ops._TWIN = None
