@@ -247,6 +247,10 @@ int mivae_colsum_sink(const void* x, float* out0, float* out1, int64_t split, fl
 int mivae_embedding_bwd(const float* dy, const int64_t* ids, float* dW, int64_t N, int64_t V, int64_t E,
                         int64_t padding_idx, int accumulate, void* stream);
 
+/* Fold of the vocabulary projection's weight gradient (nonauto_lm/model.py:105-112, the Linear behind the decoder):
+ * part (G, V, E + A) fp32 = G token-slab partials of dlogits^T [h | 1 ... 1] (A ones columns appended to h);
+ * dW (V, E) += sum_g part[g][:, :E], db (V) += sum_g part[g][:, E], fixed order, straight into the gradient buffers. */
+int mivae_fold_aug_sink(const float* part, int64_t G, int64_t V, int64_t E, int64_t A, float* dW, float* db, void* stream);
 /* mivae_colsum_sink for MANY short matrices in one launch: jobs = njobs x {x, out0, out1, rows (<= 512), D, split,
  * stride} as 7 x int64 per job in device memory (stride = floats between the rows of x, >= D: x may be a column block
  * of a wider partial matrix); bit-identical to njobs calls of mivae_colsum_sink (same summation order).

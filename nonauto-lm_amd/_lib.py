@@ -78,6 +78,7 @@ SIGNATURES = {
     "mivae_linear_dgrad": [P, P, P, I64, I64, I64, P],
     "mivae_linear_wgrad_rows": [I64],
     "mivae_colsum_sink_multi": [P, I64, I64, P],
+    "mivae_fold_aug_sink": [P, I64, I64, I64, I64, P, P, P],
     "mivae_linear_wgrad_group": [P, P, P, I64, I64, I64, I64, P],
     "mivae_linear_wgrad_multi": [P, I64, I64, I32, P],
     "mivae_linear_wgrad_single_group": [P, P, P, P, P, P, I64, I64, I64, P],

@@ -608,6 +608,23 @@ __global__ void __launch_bounds__(256) k_colsum_short_multi(const ColJob* __rest
   }
 }
 
+// Fold of the vocabulary projection's weight-gradient partials: part (G, V, E + A) fp32, G token-slab partials of
+// dl^T [h | 1 ... 1] (A ones columns appended to h so that d b rides on the same product).  dW[v][e] += sum_g
+// part[g][v][e], db[v] += sum_g part[g][v][E], fixed order: one launch instead of a column sum + two accumulations.
+__global__ void __launch_bounds__(256) k_fold_aug(const float* __restrict__ part, int G, int64_t V, int E, int A,
+                                                  float* __restrict__ dW, float* __restrict__ db) {
+  const int64_t W = E + A, n = V * W;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n) return;
+  const int64_t v = idx / W;
+  const int e = (int)(idx - v * W);
+  if (e > E) return;                      // the other ones columns repeat d b
+  float s = 0.f;
+  for (int g = 0; g < G; ++g) s += part[(int64_t)g * n + idx];
+  if (e < E) dW[v * E + e] += s;
+  else db[v] += s;
+}
+
 // Embedding weight gradient (torch.nn.Embedding inside the reference's Embedder, the first op of VAELmModel.encode):
 // dW[v] = sum over tokens with id v of dy[token], deterministic without a sort and without atomics.  A block owns
 // kEmbRows consecutive vocabulary ids; its 4 waves scan one contiguous quarter of the token ids each (all blocks read
@@ -1429,6 +1446,16 @@ extern "C" int mivae_colsum_sink_multi(const void* jobs, int64_t njobs, int64_t 
   dim3 grid((unsigned)((max_D + 63) / 64), (unsigned)njobs);
   k_colsum_short_multi<<<grid, kBlock, 0, S_(stream)>>>(static_cast<const ColJob*>(jobs));
   MIVAE_CHECK_LAUNCH("colsum_sink_multi");
+  return MIVAE_OK;
+}
+
+extern "C" int mivae_fold_aug_sink(const float* part, int64_t G, int64_t V, int64_t E, int64_t A, float* dW, float* db,
+                                   void* stream) {
+  MIVAE_REQUIRE(G >= 1 && G <= 4096 && V >= 1 && E >= 1 && A >= 1 && V * (E + A) < (1ll << 40), "fold_aug_sink: bad sizes");
+  MIVAE_REQUIRE(part && dW && db, "fold_aug_sink: null pointer");
+  const int64_t n = V * (E + A);
+  k_fold_aug<<<(unsigned)((n + 255) / 256), 256, 0, S_(stream)>>>(part, (int)G, V, (int)E, (int)A, dW, db);
+  MIVAE_CHECK_LAUNCH("fold_aug_sink");
   return MIVAE_OK;
 }
 

@@ -1590,6 +1590,7 @@ class _LinearNLL(torch.autograd.Function):
         ctx.save_for_backward(h2, w16, wp, tgt, aux)
         ctx.wtp = wtp
         ctx.meta = (Bn, S, E, V, float(smoothing), h.shape, h.dtype, weight.dtype, bias is not None)
+        ctx.params = (weight, bias)
         return per_seq
 
     @staticmethod
@@ -1615,6 +1616,26 @@ class _LinearNLL(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 dh = dl.matmul(w16).view(hshape).to(hdtype)
         want_db = has_bias and ctx.needs_input_grad[2]
+        wpar, bpar = ctx.params
+        n = h2.size(0)
+        if (ctx.needs_input_grad[1] and want_db and n % 8 == 0 and n // 8 >= 1024 and grad_sink_ok(wpar, bpar)
+                and wpar.grad.shape == (V, E)):
+            # gradient sinks: [h | 1] lives in a persistent buffer whose ones block is written once, the 8 token-slab
+            # partials of dl^T [h | 1] are folded straight into weight.grad / bias.grad (one launch, no accumulations)
+            key = ("lce_haug", n, E, h2.device)
+            h_aug = _PART_BUFS.get(key)
+            if h_aug is None:
+                h_aug = _PART_BUFS[key] = torch.ones(n, E + 8, dtype=torch.bfloat16, device=h2.device)
+            h_aug[:, :E].copy_(h2)
+            try:
+                part = torch.bmm(dl.view(8, n // 8, V).transpose(1, 2), h_aug.view(8, n // 8, E + 8),
+                                 out_dtype=torch.float32)
+            except (TypeError, RuntimeError):
+                part = None
+            if part is not None:
+                L.call("mivae_fold_aug_sink", L.ptr(part), 8, V, E, 8, L.ptr(wpar.grad), L.ptr(bpar.grad), L.stream())
+                sink_arrived(wpar.grad, bpar.grad)
+                return dh, None, None, None, None, None, None
         if ctx.needs_input_grad[1] and want_db:
             # one dense product for both: d W = dl^T h and d b = dl^T 1 (a ones block appended to h)
             h_aug = torch.nn.functional.pad(h2, (0, 8), value=1.0)          # one launch (was ones + cat)

@@ -290,3 +290,31 @@ def test_bf16_twin_of_residual_gradient(monkeypatch):
     t32.add_(1.0)                                         # modified in place: the twin is stale, a fresh cast is returned
     assert ops.to_bf16(t32).data_ptr() != ops._TWIN[2].data_ptr()
     ops._TWIN = None
+
+
+def test_linear_nll_weight_gradient_sink_matches_autograd():
+    """ops.linear_nll (fused vocabulary projection + NLL) with gradient sinks: dW / db folded straight into .grad by
+    mivae_fold_aug_sink == the gradients autograd accumulates without sinks (same partial products, same fold order)"""
+    from nonauto_lm_amd import ops
+    torch.manual_seed(19)
+    Bn, S, E, V = 128, 64, 64, 1024
+    h = torch.randn(Bn, S, E, device="cuda")
+    W = (torch.randn(V, E, device="cuda") * 0.1).requires_grad_(True)
+    b = torch.zeros(V, device="cuda").requires_grad_(True)
+    tgt = torch.randint(4, V, (Bn, S), device="cuda")
+    wts = torch.ones(Bn, S, device="cuda")
+    res = []
+    for sink in (False, True):
+        W.grad, b.grad = torch.zeros_like(W), torch.zeros_like(b)
+        hh = h.clone().requires_grad_(True)
+        ops.GRAD_SINK = sink
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = ops.linear_nll(hh.to(torch.bfloat16), W, b, tgt, wts, 0.1)
+            loss.sum().backward()
+        finally:
+            ops.GRAD_SINK = False
+        res.append((W.grad.clone(), b.grad.clone(), hh.grad.clone()))
+    assert res[0][0].abs().max() > 0 and res[0][1].abs().max() > 0
+    for a, c in zip(*res):
+        torch.testing.assert_close(a, c, rtol=1e-5, atol=1e-6)
