@@ -46,6 +46,9 @@ const char* mivae_last_error(void);
 /* ---- integer helpers (bit exact) ------------------------------------------------------------ */
 /* mask[i] = tokens[i] != 0.  Replaces get_tokens_mask, nn/utils.py:12-14. */
 int mivae_tokens_mask(const int64_t* tokens, int64_t* mask, int64_t n, void* stream);
+/* The same, plus the mask as fp32 in mask_f32 (n): the per-token weights of LabelSmoothingNLL
+ * (models/base/losses.py:128-164) without a cast launch. */
+int mivae_tokens_mask_f32(const int64_t* tokens, int64_t* mask, float* mask_f32, int64_t n, void* stream);
 /* sigma head of the posterior in one launch: sigma = Hardtanh(Softplus(pre), lo, hi) elementwise over n values of the
  * latent dtype (models/nonauto_lm/posteriors/posterior.py:23-27, auto posterior.py:23-27: Softplus(beta 1, threshold
  * 20) + Hardtanh(1e-4, 5)); backward: d pre = d sigma * sigmoid(pre) where lo < softplus(pre) < hi, else 0. */

@@ -22,6 +22,7 @@ SIGNATURES = {
     "mivae_version": [],
     "mivae_last_error": [],
     "mivae_tokens_mask": [P, P, I64, P],
+    "mivae_tokens_mask_f32": [P, P, P, I64, P],
     "mivae_sigma_head_fwd": [P, P, I64, F32, F32, I32, P],
     "mivae_sigma_head_bwd": [P, P, P, I64, F32, F32, I32, P],
     "mivae_posenc_mask": [P, P, P, P, I64, I64, I64, I32, I32, P],

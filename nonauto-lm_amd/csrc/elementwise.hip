@@ -58,10 +58,15 @@ static RowCfg row_cfg(int64_t rows, int64_t width, int dtype, bool aligned) {
 
 // ------------------------------------------------------------------------------------------------
 // a1: get_tokens_mask  (vae_lm/nn/utils.py:12-14)  -- integer, bit exact
-__global__ void k_tokens_mask(const int64_t* __restrict__ tok, int64_t* __restrict__ mask, int64_t n) {
+__global__ void k_tokens_mask(const int64_t* __restrict__ tok, int64_t* __restrict__ mask, float* __restrict__ maskf,
+                              int64_t n) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) mask[i] = tok[i] != 0 ? 1 : 0;
+  for (; i < n; i += stride) {
+    const bool keep = tok[i] != 0;
+    mask[i] = keep ? 1 : 0;
+    if (maskf) maskf[i] = keep ? 1.f : 0.f;        // the same mask as fp32 token weights (the loss takes it as such)
+  }
 }
 
 // a2: last-token gather (encoders/encoder.py:35-37).  One block per batch row.
@@ -824,8 +829,21 @@ extern "C" int mivae_tokens_mask(const int64_t* tokens, int64_t* mask, int64_t n
   MIVAE_REQUIRE(tokens && mask, "tokens_mask: null pointer");
   unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
   if (grid > 4096) grid = 4096;
-  k_tokens_mask<<<grid, kBlock, 0, S_(stream)>>>(tokens, mask, n);
+  k_tokens_mask<<<grid, kBlock, 0, S_(stream)>>>(tokens, mask, nullptr, n);
   MIVAE_CHECK_LAUNCH("tokens_mask");
+  return MIVAE_OK;
+}
+
+// mivae_tokens_mask that also writes the mask as fp32 (the per-token weights LabelSmoothingNLL multiplies by,
+// models/base/losses.py:128-164): one launch instead of the mask kernel + a cast.
+extern "C" int mivae_tokens_mask_f32(const int64_t* tokens, int64_t* mask, float* mask_f32, int64_t n, void* stream) {
+  MIVAE_REQUIRE(n >= 0, "tokens_mask_f32: bad size");
+  if (n == 0) return MIVAE_OK;
+  MIVAE_REQUIRE(tokens && mask && mask_f32, "tokens_mask_f32: null pointer");
+  unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
+  if (grid > 4096) grid = 4096;
+  k_tokens_mask<<<grid, kBlock, 0, S_(stream)>>>(tokens, mask, mask_f32, n);
+  MIVAE_CHECK_LAUNCH("tokens_mask_f32");
   return MIVAE_OK;
 }
 

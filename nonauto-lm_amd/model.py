@@ -198,7 +198,7 @@ class NonAutoModel(VAELmModel):
             # training step under bf16 autocast: projection + NLL fused, the (N, V) logits are never written
             # (SURVEY 8f-1); `logits` / `probs` / `preds` are not produced in this mode
             proj = self._vocab_projection
-            weights = (mask if mask is not None and mask.shape == target.shape else ops.tokens_mask(target)).float()
+            weights = ops.mask_f32(mask if mask is not None and mask.shape == target.shape else ops.tokens_mask(target))
             smoothing = self._loss._smoothing if (self._loss._smoothing and self.training) else 0.0
             return {"loss": ops.linear_nll(decoded, proj.weight, proj.bias, target, weights, smoothing,
                                            getattr(proj.weight, "_mivae_lp", None))}

@@ -68,8 +68,19 @@ def tokens_mask(tokens: torch.Tensor) -> torch.Tensor:
     if tokens.dtype != torch.int64:
         tokens = tokens.to(torch.int64)
     out = torch.empty_like(tokens)
-    L.call("mivae_tokens_mask", L.ptr(tokens), L.ptr(out), tokens.numel(), L.stream())
+    outf = torch.empty(tokens.shape, dtype=torch.float32, device=tokens.device)
+    L.call("mivae_tokens_mask_f32", L.ptr(tokens), L.ptr(out), L.ptr(outf), tokens.numel(), L.stream())
+    out._mivae_f32 = outf          # the same mask as fp32 token weights (mask_f32(): no cast launch for the loss)
     return out
+
+
+def mask_f32(mask: torch.Tensor) -> torch.Tensor:
+    """mask.float(); free when `mask` is the tensor tokens_mask() returned (its fp32 twin was written by the same kernel
+    and the integer mask is never modified in place on this path: checked through the version counter)."""
+    tw = getattr(mask, "_mivae_f32", None)
+    if tw is not None and mask._version == 0 and tw.shape == mask.shape:
+        return tw
+    return mask.float()
 
 
 class _GatherLast(torch.autograd.Function):
