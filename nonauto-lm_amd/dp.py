@@ -250,7 +250,7 @@ class FusedAdam:
                 for sh, fp in zip(self.shadow, self.reducer.flat_params):
                     sh.copy_(fp)
 
-    def step(self, max_norm: Optional[float] = None, max_value: Optional[float] = None) -> torch.Tensor:
+    def step(self, max_norm: Optional[float] = None, max_value: Optional[float] = None, bump: bool = True) -> torch.Tensor:
         """Clip (global L2 norm, then value), Adam update, zero the gradient buckets.  Returns the pre-clip
         gradient norm as a device scalar."""
         L = self._L
@@ -267,7 +267,8 @@ class FusedAdam:
                    L.ptr(self.exp_avg_sq[i]), L.ptr(self._partial), off, L.ptr(self.step_count),
                    L.ptr(self.grad_norm) if i == 0 else None, b.numel(), self.lr, self.betas[0], self.betas[1],
                    self.eps, self.weight_decay, float(max_norm or 0.0), float(max_value or 0.0), gscale, st)
-        L.call("mivae_scalar_add", L.ptr(self.step_count), 1.0, st)
+        if bump:                   # bump=False: the caller advances step_count itself (TrainStep folds it into another launch)
+            L.call("mivae_scalar_add", L.ptr(self.step_count), 1.0, st)
         from . import ops
         ops.params_changed()       # raw-pointer writes: torch's version counters did not move
         return self.grad_norm

@@ -97,9 +97,9 @@ class TrainStep:
         loss.backward(gradient=self._seed)       # a cached seed: no ones_like launch per step
         return {k: info[k] for k in ("batch-loss", "batch-kl", "batch-nll")}
 
-    def _update(self):
+    def _update(self, bump: bool = True):
         if isinstance(self.opt, dp.FusedAdam):      # clip + Adam + zero_grad in one pass over the flat buckets
-            self.opt.step(self.max_norm, self.max_value)
+            self.opt.step(self.max_norm, self.max_value, bump=bump)
             return
         self.reducer.clip_(self.max_norm, self.max_value)
         self.opt.step()
@@ -226,10 +226,15 @@ class TrainStep:
                     self.reducer.finish()         # remaining buckets + join RCCL's stream: all inside the capture
             graph_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph_b, pool=graph_a.pool(), capture_error_mode="thread_local"):
-                self._update()
-                if self._want_track and self._acc is not None:
-                    torch._foreach_add_(list(self._acc_views), [self.info["batch-nll"].detach().float(),
-                                                                self.info["batch-kl"].detach().float()])
+                track = self._want_track and self._acc is not None
+                fold = track and isinstance(self.opt, dp.FusedAdam)     # the optimizer's step counter rides along
+                self._update(bump=not fold)
+                if track:
+                    if self._seed is None:
+                        self._seed = torch.ones((), dtype=torch.float32, device=self._acc.device)
+                    dst = list(self._acc_views) + ([self.opt.step_count] if fold else [])
+                    src = [self.info["batch-nll"].detach().float(), self.info["batch-kl"].detach().float()]
+                    torch._foreach_add_(dst, src + ([self._seed.float()] if fold else []))
             self.graph_a, self.graph_b, self.comm_in_graph = graph_a, graph_b, comm
             return True
         except RuntimeError as err:
