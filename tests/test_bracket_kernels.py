@@ -1,7 +1,11 @@
-"""libmivae attention kernels (csrc/attention.hip) against the reference's attention core restated in fp32 torch:
-MultiHeadAttention.forward, nn/transformer.py:62-117 (scores / sqrt(d), masked_fill(-1e13), softmax, probs @ v).
-bf16 operands: outputs within 2e-2 absolute / relative of the fp32 restatement on the same bf16-rounded inputs
-(the probabilities are rounded to bf16 before the second product, like every fused attention)."""
+"""Round-2 kernels of the transformer bracket and of the step's gradient plumbing, through the C ABI:
+  * libmivae attention kernels (csrc/attention.hip) against the reference's attention core restated in fp32 torch:
+    MultiHeadAttention.forward, nn/transformer.py:62-117 (scores / sqrt(d), masked_fill(-1e13), softmax, probs @ v).
+    bf16 operands: outputs within 2e-2 absolute / relative of the fp32 restatement on the same bf16-rounded inputs
+    (the probabilities are rounded to bf16 before the second product, like every fused attention);
+  * residual epilogue of the output projection, fused wide q|k|v projection, paired / queued weight gradients,
+    the bf16 twin of the residual-stream gradient, the vocabulary projection's gradient sink: each against the
+    unfused form it replaces (bit-equal where the arithmetic is the same, stated tolerance otherwise)."""
 import math
 
 import pytest
