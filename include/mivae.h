@@ -230,8 +230,12 @@ int mivae_colsum(const void* x, float* out, float* workspace, int64_t rows, int6
  * GPU the library runs on holds until the process ends (resolved once per device with hipGetSymbolAddress).  Limit:
  * mivae_col_workspace_floats(rows, D, dtype) <= mivae_colsum_static_max_floats() (= 2^20), else MIVAE_EUNSUPPORTED (-3)
  * with a message.  Calls no hipMalloc / hipFree.  Calls on one GPU share the array: calls that overlap in time on the
- * same GPU (different streams) race. */
+ * same GPU (different streams) race.  The array used is the one of the STREAM's device, which must be the current
+ * device (EINVAL otherwise).  mivae_colsum_static_init() resolves the current device's array eagerly: call it once per
+ * device before the first use under HIP-graph capture (a first use inside a capture is rejected with EINVAL, since
+ * module load / hipGetSymbolAddress are not capture-safe); eager callers may skip it. */
 int64_t mivae_colsum_static_max_floats(void);
+int mivae_colsum_static_init(void);
 int mivae_colsum_static(const void* x, float* out, int64_t rows, int64_t D, int dtype, void* stream);
 
 /* First stage of mivae_colsum only: per-block partial column sums of x (rows, D) into workspace (count, D) fp32, count

@@ -48,6 +48,7 @@ SIGNATURES = {
     "mivae_colsum_partial": [P, P, I64, I64, I32, P],
     "mivae_colsum_sink": [P, P, P, I64, P, I64, I64, I32, P],
     "mivae_colsum_static_max_floats": [],
+    "mivae_colsum_static_init": [],
     "mivae_colsum_static": [P, P, I64, I64, I32, P],
     "mivae_kl_fwd": [P, P, P, I64, I32, F32, P],
     "mivae_kl_bwd": [P, P, P, P, P, I64, I32, F32, P],

@@ -1414,6 +1414,43 @@ static float* g_scratch_ptr[kMaxDevices] = {};
 
 extern "C" int64_t mivae_colsum_static_max_floats(void) { return kStaticScratchFloats; }
 
+// Address of this device's copy of the array, resolved with `dev` current (restored afterwards).
+static int static_scratch_resolve(int dev, float** out) {
+  float* ws = __atomic_load_n(&g_scratch_ptr[dev], __ATOMIC_ACQUIRE);
+  if (!ws) {   // first use on this device (racing first uses resolve the same address)
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) cur = -1;
+    if (cur != dev && hipSetDevice(dev) != hipSuccess) {
+      mivae_set_error("colsum_static: cannot make device %d current", dev);
+      return MIVAE_ELAUNCH;
+    }
+    void* p = nullptr;
+    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (cur != dev && cur >= 0) (void)hipSetDevice(cur);
+    if (e != hipSuccess || !p) {
+      mivae_set_error("colsum_static: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+      return MIVAE_ELAUNCH;
+    }
+    ws = static_cast<float*>(p);
+    __atomic_store_n(&g_scratch_ptr[dev], ws, __ATOMIC_RELEASE);
+  }
+  *out = ws;
+  return MIVAE_OK;
+}
+
+// Set-up call: resolves the scratch array of the CURRENT device (module load + hipGetSymbolAddress, neither of which is
+// safe inside a stream capture).  Call it once per device before the first mivae_colsum_static under HIP-graph capture;
+// eager callers may skip it (the first eager call resolves lazily).
+extern "C" int mivae_colsum_static_init(void) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+    mivae_set_error("colsum_static_init: cannot identify the current device");
+    return MIVAE_ELAUNCH;
+  }
+  float* ws = nullptr;
+  return static_scratch_resolve(dev, &ws);
+}
+
 extern "C" int mivae_colsum_static(const void* x, float* out, int64_t rows, int64_t D, int dtype, void* stream) {
   MIVAE_REQUIRE(rows >= 1 && D > 0 && D < (1ll << 31), "colsum_static: bad shape");
   MIVAE_REQUIRE(dtype == MIVAE_F32 || dtype == MIVAE_BF16, "colsum_static: bad dtype");
@@ -1424,21 +1461,36 @@ extern "C" int mivae_colsum_static(const void* x, float* out, int64_t rows, int6
                     (long long)rows, (long long)D);
     return MIVAE_EUNSUPPORTED;
   }
-  int dev = -1;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+  // the device whose copy of the array the kernels will see is the STREAM's device (the current device only for the
+  // null stream); launching on another device's stream is rejected rather than handed the wrong copy
+  int dev = -1, cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess || cur < 0 || cur >= kMaxDevices) {
     mivae_set_error("colsum_static: cannot identify the current device");
     return MIVAE_ELAUNCH;
   }
-  float* ws = __atomic_load_n(&g_scratch_ptr[dev], __ATOMIC_ACQUIRE);
-  if (!ws) {   // first call on this device (racing first calls resolve the same address)
-    void* p = nullptr;
-    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
-    if (e != hipSuccess || !p) {
-      mivae_set_error("colsum_static: hipGetSymbolAddress failed: %s", hipGetErrorString(e));
+  dev = cur;
+  if (stream) {
+    hipDevice_t sd = -1;
+    if (hipStreamGetDevice(S_(stream), &sd) != hipSuccess || sd < 0 || sd >= kMaxDevices) {
+      mivae_set_error("colsum_static: cannot identify the stream's device");
       return MIVAE_ELAUNCH;
     }
-    ws = static_cast<float*>(p);
-    __atomic_store_n(&g_scratch_ptr[dev], ws, __ATOMIC_RELEASE);
+    dev = (int)sd;
+    if (dev != cur) {
+      mivae_set_error("colsum_static: the stream belongs to device %d but device %d is current", dev, cur);
+      return MIVAE_EINVAL;
+    }
+  }
+  float* ws = __atomic_load_n(&g_scratch_ptr[dev], __ATOMIC_ACQUIRE);
+  if (!ws) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (stream && hipStreamIsCapturing(S_(stream), &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+      mivae_set_error("colsum_static: first use on device %d inside a stream capture: call mivae_colsum_static_init() "
+                      "(or one eager mivae_colsum_static) on this device before capturing", dev);
+      return MIVAE_EINVAL;
+    }
+    const int rc = static_scratch_resolve(dev, &ws);
+    if (rc) return rc;
   }
   return colsum_impl(x, out, nullptr, 0, 0, ws, rows, D, dtype, stream);
 }

@@ -380,7 +380,10 @@ class _InvLinearBase(Flow):
         # are ONE product with a small square matrix on the matrix cores (csrc/invlinear.hip)
         lead = z.shape[:-1]
         hs = z.size(-1) // heads
-        out = ops.rowgemm(z.reshape(*lead, heads, hs), w).reshape(*lead, z.size(-1))
+        if hs <= ops.ROWGEMM_MAX and z.dtype in (torch.float32, torch.bfloat16):
+            out = ops.rowgemm(z.reshape(*lead, heads, hs), w).reshape(*lead, z.size(-1))
+        else:       # matrices wider than the MFMA kernel's 512 / other latent dtypes: the library product
+            out = torch.matmul(z.reshape(*lead, heads, hs), w.to(z.dtype).t()).reshape(*lead, z.size(-1))
         logdet = torch.linalg.slogdet(w)[1]
         if z.dim() > 2:
             cnt = ops.mask_count(mask, z.size(0))        # integer token count (HIP), bit exact

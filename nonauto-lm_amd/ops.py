@@ -999,9 +999,19 @@ def begin_deferred_sinks():
     _TWIN = None
 
 
+def deferred_jobs_in_range(defer, lo: int, hi: int):
+    """Keys of the deferred fold jobs (part, g0, g1, split) that write into the address range [lo, hi).  A combined
+    [dW | db] / [d gamma | d beta] job has TWO destinations (g0 = weight.grad, g1 = bias.grad) and a byte-limit bucket
+    split can put them into different buckets (bias at the end of bucket i, weight at the start of bucket i + 1): the job
+    is selected when EITHER lies in the range, so it is folded whole before the EARLIER of its two buckets is reduced --
+    the other bucket cannot have gone out yet, because the job's arrival was counted for it at the same time and its own
+    flush would have selected the job."""
+    return [k for k, j in defer.items() if lo <= j[1].data_ptr() < hi or lo <= j[2].data_ptr() < hi]
+
+
 def flush_grad_sinks(lo: Optional[int] = None, hi: Optional[int] = None):
-    """Fold the queued [dW | db] partials into their gradient buffers.  With an address range only the jobs whose
-    gradient lies in [lo, hi) are folded and the queue stays open (the reducer flushes a bucket right before its
+    """Fold the queued [dW | db] partials into their gradient buffers.  With an address range only the jobs with a
+    destination in [lo, hi) are folded and the queue stays open (the reducer flushes a bucket right before its
     all-reduce); without one everything left is folded and deferred mode ends."""
     global _DEFER
     if _DEFER is None:
@@ -1010,8 +1020,7 @@ def flush_grad_sinks(lo: Optional[int] = None, hi: Optional[int] = None):
     if lo is None:
         jobs, _DEFER = _DEFER, None
     else:
-        keys = [k for k, j in _DEFER.items() if lo <= j[1].data_ptr() < hi]
-        jobs = {k: _DEFER.pop(k) for k in keys}
+        jobs = {k: _DEFER.pop(k) for k in deferred_jobs_in_range(_DEFER, lo, hi)}
     if not jobs:
         return
     rows = [(part.data_ptr(), g0.data_ptr(), g1.data_ptr(), part.size(0), part.size(1), split, part.stride(0))

@@ -187,7 +187,10 @@ class TrainStep:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):             # warm-up on a side stream (allocator, lazy init, autotune)
-            for _ in range(warmup):
+            # at least two iterations after relearn(): the first learns the per-bucket contribution counts, the second is
+            # the first one that folds per bucket and so builds (and caches) the per-bucket job tables -- a table first
+            # needed inside the capture cannot be uploaded there and would bake the one-by-one fold into graph A
+            for _ in range(max(warmup, 2)):
                 self._fwd_bwd()
                 self.reducer.finish()
                 self._update()
@@ -209,8 +212,12 @@ class TrainStep:
             self.graph_a = self.graph_b = None
             self.reducer.overlap = True
             ops.pin_tables(False)
-            m.track_metrics = track
-            m.device_weights = None               # by-value weights again (nothing is captured)
+        # Outside the replays the model is an ordinary module again (validation / evaluation forwards between training
+        # steps, models/base/model.py:200-210): its plain forward feeds the running metrics itself and reads the
+        # schedulers' CURRENT weights by value.  The captured kernels keep reading self._w_dev (the address is baked in),
+        # which __call__ refreshes before every replay; replays never run the Python forward, so neither flag is read.
+        m.track_metrics = track
+        m.device_weights = None
         self._track = track
         self._restore(snap)
 

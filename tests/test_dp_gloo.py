@@ -243,6 +243,94 @@ def test_grad_reducer_sinks_and_learned_counts_world2():
         assert np.array_equal(a, b)
 
 
+def _straddle_worker(rank, world, port, q):
+    """a combined [dW | db] fold job whose two destinations sit in DIFFERENT buckets (bias at the end of
+    bucket i, weight at the start of bucket i + 1).  The jobs are selected by the product's own
+    ops.deferred_jobs_in_range; the fold itself (a HIP kernel in the product) is emulated with torch adds."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nonauto_lm_amd import dp, ops
+    torch.set_num_threads(1)
+    model = _make_model()
+    dp.broadcast_parameters(model)
+    # reversed registration order: unused.bias, unused.weight, body.4.bias, body.4.weight, body.2.bias (772 B) |
+    # body.2.weight (6400 B), body.0.bias (160 B) | body.0.weight: both wide layers straddle a bucket boundary, and bucket 0
+    # (holding body.2.bias) is complete BEFORE bucket 1 (body.2.weight + body.0.bias, which arrives later): with a
+    # weight-only selection bucket 0 would be reduced without d b and receive it after its all-reduce
+    reducer = dp.GradReducer(model.parameters(), bucket_bytes=6600)
+    reducer.fold_average = True
+    layers = [model.body[2], model.body[0]]          # the order backward reaches them
+    out = {"straddle": [reducer._bucket_of[id(l.weight)] != reducer._bucket_of[id(l.bias)] for l in layers],
+           "early": []}
+    defer = {}
+    launches = []
+
+    def before_launch(lo, hi):
+        launches.append((lo, hi))
+        for k in ops.deferred_jobs_in_range(defer, lo, hi):
+            part, g0, g1, split = defer.pop(k)
+            s = part.sum(0)
+            g0.view(-1).add_(s[:split])
+            g1.view(-1).add_(s[split:])
+    reducer.before_launch = before_launch
+    x, y = _data()
+    shard = slice(rank * 8, (rank + 1) * 8)
+    sinked = [p for l in layers for p in (l.weight, l.bias)]
+    hooked = [model.body[4].weight, model.body[4].bias]
+    for it in range(3):
+        launches.clear()
+        loss = ((model(x[shard]) - y[shard]) ** 2).mean()
+        gs = torch.autograd.grad(loss, sinked, retain_graph=True)
+        loss.backward(inputs=hooked)
+        for i, l in enumerate(layers):
+            gw, gb = gs[2 * i], gs[2 * i + 1]
+            flat = torch.cat([gw.reshape(-1), gb.reshape(-1)])
+            defer[i] = (torch.stack([0.25 * flat, 0.75 * flat]), l.weight.grad, l.bias.grad, gw.numel())
+            reducer.notify_sink(l.weight.grad)       # ops.sink_arrived(gw, gb) of the product
+            reducer.notify_sink(l.bias.grad)
+        out["early"].append(len(launches))
+        reducer.finish()
+        assert not defer
+        out[f"grads{it}"] = [(p.grad.clone() / world).numpy().copy() for p in model.parameters()]
+        reducer.zero_grad()
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_combined_fold_job_straddling_two_buckets_world2():
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_straddle_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        rank, out = q.get(timeout=100)
+        res[rank] = out
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    model = _make_model()
+    x, y = _data()
+    ((model(x) - y) ** 2).mean().backward()
+    ref = [p.grad.clone() if p.grad is not None else torch.zeros_like(p) for p in model.parameters()]
+    for rank in (0, 1):
+        r = res[rank]
+        assert r["straddle"] == [True, True]
+        assert r["early"][0] == 0 and r["early"][1] >= 1       # steps 2, 3 launch buckets from the arrivals
+        for it in range(3):
+            for a, b in zip(r[f"grads{it}"], ref):
+                assert torch.allclose(torch.from_numpy(np.asarray(a)), b, rtol=1e-5, atol=1e-7)
+    for a, b in zip(res[0]["grads2"], res[1]["grads2"]):
+        assert np.array_equal(a, b)
+
+
 def test_grad_reducer_late_contribution_raises():
     """world > 1 only matters for the exchange; the guard itself is rank-count independent: simulate world 2."""
     sys.path.insert(0, ROOT)

@@ -1251,6 +1251,40 @@ def test_train_step_reports_post_step_weights(M):
     assert model.get_metrics()["avg-kl-weight"] == pytest.approx(1 / 6)
 
 
+def test_plain_forward_between_graph_steps_tracks_metrics_and_current_weights(M):
+    """after a captured TrainStep the model must still behave like the reference's module in a plain
+    forward (the validation loop, models/base/model.py:200-210): the running metrics move, and the loss is formed with
+    the schedulers' CURRENT weights, not with the ones pushed for the last replayed step."""
+    from nonauto_lm_amd import dp
+    from nonauto_lm_amd.step import TrainStep
+    model, tokens = _small_step_model(M, "linear")
+    reducer = dp.GradReducer(model.parameters(), flatten_params=True)
+    opt = dp.FusedAdam(reducer, lr=1e-3)
+    step = TrainStep(model, reducer, opt, tokens, None, 5.0, 2.0, graph=True, warmup=1)
+    if step.graph_a is None:
+        pytest.skip("graph capture unavailable")
+    assert model.track_metrics and model.device_weights is None
+    for _ in range(5):
+        step()
+    got = model.get_metrics()
+    assert got["avg-nll"] > 0.0
+    n_before = model._metrics["nll"].count
+    w_now = model._kl_scheduler.weight                     # 3 annealed steps of 6: 0.5
+    assert 0.0 < w_now < 1.0
+    model.eval()
+    eps = torch.randn(16, 1, 12, 32, device=DEV)
+    with torch.no_grad():
+        out = model(tokens, tokens, eps=eps)["loss_info"]
+    model.train()
+    assert model._metrics["nll"].count == n_before + 1     # the plain forward fed the metrics
+    want = float(out["batch-nll"]) + w_now * float(out["batch-kl"])
+    assert abs(float(out["batch-loss"]) - want) <= 1e-5 * abs(want), (float(out["batch-loss"]), want, w_now)
+    # ... and the graph steps carry on from the merged running sums
+    step()
+    assert model._metrics["nll"].count == n_before + 2
+    assert model.get_metrics()["avg-nll"] > 0.0
+
+
 # ------------------------------------------------------------------------------------ prior sampling (a7), mutual info (f4)
 @pytest.mark.parametrize("name", ["prior_sample_default", "prior_sample_one_length", "prior_sample_flow"])
 def test_prior_sample_golden(M, name):
@@ -1426,6 +1460,24 @@ def test_rowgemm_rejects_wide_and_mismatched(M):
     with pytest.raises(ValueError):
         M.ops.rowgemm(torch.zeros(4, 16, device=DEV), torch.zeros(8, 8, device=DEV))
     assert M.ops.rowgemm(torch.zeros(0, 16, device=DEV), torch.eye(16, device=DEV)).shape == (0, 16)
+
+
+@pytest.mark.parametrize("D,dtype", [(520, torch.float32), (64, torch.float64)])
+def test_invlinear_module_falls_back_beyond_the_kernel_limits(M, D, dtype):
+    """InvertibleLinearFlow on a matrix wider than the MFMA kernel's 512, or a latent dtype it does not take,
+    runs the library product (invertible_flows.py:26-44 semantics) instead of raising."""
+    torch.manual_seed(5)
+    flow = M.flows.InvertibleLinearFlow(D).to(DEV)
+    z = torch.randn(3, 5, D, device=DEV, dtype=dtype)
+    mask = (torch.arange(5, device=DEV)[None, :] < torch.tensor([5, 2, 1], device=DEV)[:, None]).long()
+    out, ld = flow(z, mask)
+    w = flow._weight.detach()
+    ref = torch.nn.functional.linear(z.double(), w.double())
+    assert rel_err(out.double(), ref) < 1e-5
+    want = torch.linalg.slogdet(w)[1] * mask.sum(1)
+    assert rel_err(ld, want) < 1e-5 or float((ld - want).abs().max()) < 1e-5
+    back, _ = flow.backward(out, mask)
+    assert rel_err(back.double(), z.double()) < 1e-3
 
 
 # ------------------------------------------------------------------------------------ in-kernel posterior noise (a4)
