@@ -496,6 +496,11 @@ int mivae_adam_clip_step(float* p, void* p_bf16, float* g, float* m, float* v, c
                          double beta2, float eps, float weight_decay, float max_norm, float max_value,
                          float grad_scale, void* stream);
 int mivae_scalar_add(float* x, float delta, void* stream);
+/* Measurement aid, no counterpart in the reference: dst[0:bytes] = src[0:bytes] as a plain streaming copy (16 bytes per
+ * lane).  bench.py times it on 256 MiB to report the HBM bandwidth this box reaches beside the datasheet peak
+ * (both denominators).  bytes % 16 == 0, 16-byte aligned buffers.  mode bit 0: non-temporal loads / stores;
+ * mode / 16 = workgroups per CU (0: 16). */
+int mivae_hbm_copy(const void* src, void* dst, int64_t bytes, int mode, void* stream);
 
 /* ---- masked autoregressive flows ----------------------------------------------- */
 /* Tail of MAFlow.forward (vae_lm/models/base/flows/maf.py:35-45) given st = MADE(z) as one (rows, 2D) tensor

@@ -110,6 +110,7 @@ SIGNATURES = {
     "mivae_sumsq_partial": [P, P, I64, P],
     "mivae_adam_clip_step": [P, P, P, P, P, P, I64, P, P, I64, F64, F64, F64, F32, F32, F32, F32, F32, P],
     "mivae_scalar_add": [P, F32, P],
+    "mivae_hbm_copy": [P, P, I64, I32, P],
     "mivae_nice_pack_bytes": [I64, I64, I32],
     "mivae_nice_pack": [P, P, I64, I64, I64, I32, I32, P],
     "mivae_nice_stack_fwd": [P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I32, I32, I32, F32, F32, I32, P],

@@ -165,3 +165,45 @@ extern "C" int mivae_scalar_add(float* x, float delta, void* stream) {
   MIVAE_CHECK_LAUNCH("scalar_add");
   return MIVAE_OK;
 }
+
+// ---- measurement aid: a plain streaming copy (16 bytes per lane, 4 loads in flight per lane) ----------------------
+// bench.py times it on a 256 MiB buffer to report the copy bandwidth THIS box reaches next to the 8 TB/s datasheet
+// figure (SURVEY 8d asks for both denominators).  Not part of the product path.  A block walks a contiguous segment,
+// 16 KiB per iteration (4 x 256 lanes x 16 B); mode 1 uses non-temporal loads / stores.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+template <bool NT>
+__global__ void __launch_bounds__(256) k_hbm_copy(const u32x4_t* __restrict__ src, u32x4_t* __restrict__ dst, int64_t n16,
+                                                  int64_t per_block) {
+  const int64_t lo = (int64_t)blockIdx.x * per_block;
+  int64_t hi = lo + per_block;
+  if (hi > n16) hi = n16;
+  int64_t i = lo + threadIdx.x;
+  for (; i + 768 < hi; i += 1024) {
+    u32x4_t a, b, c, d;
+    if (NT) {
+      a = __builtin_nontemporal_load(src + i); b = __builtin_nontemporal_load(src + i + 256);
+      c = __builtin_nontemporal_load(src + i + 512); d = __builtin_nontemporal_load(src + i + 768);
+      __builtin_nontemporal_store(a, dst + i); __builtin_nontemporal_store(b, dst + i + 256);
+      __builtin_nontemporal_store(c, dst + i + 512); __builtin_nontemporal_store(d, dst + i + 768);
+    } else {
+      a = src[i]; b = src[i + 256]; c = src[i + 512]; d = src[i + 768];
+      dst[i] = a; dst[i + 256] = b; dst[i + 512] = c; dst[i + 768] = d;
+    }
+  }
+  for (; i < hi; i += 256) dst[i] = src[i];
+}
+
+extern "C" int mivae_hbm_copy(const void* src, void* dst, int64_t bytes, int mode, void* stream) {
+  MIVAE_REQUIRE(src && dst && bytes >= 0 && bytes % 16 == 0, "hbm_copy: bad arguments");
+  MIVAE_REQUIRE(aligned16(src) && aligned16(dst), "hbm_copy: buffers must be 16-byte aligned");
+  if (bytes == 0) return MIVAE_OK;
+  const int64_t n16 = bytes / 16;
+  int64_t blocks = (n16 + 1023) / 1024;
+  const int64_t cap = mode >= 16 ? (int64_t)256 * (mode / 16) : 256 * 16;   // mode / 16 = blocks per CU (default 16)
+  if (blocks > cap) blocks = cap;
+  const int64_t per_block = ((n16 + blocks - 1) / blocks + 1023) / 1024 * 1024;
+  if (mode & 1) k_hbm_copy<true><<<(unsigned)blocks, 256, 0, S_(stream)>>>((const u32x4_t*)src, (u32x4_t*)dst, n16, per_block);
+  else k_hbm_copy<false><<<(unsigned)blocks, 256, 0, S_(stream)>>>((const u32x4_t*)src, (u32x4_t*)dst, n16, per_block);
+  MIVAE_CHECK_LAUNCH("hbm_copy");
+  return MIVAE_OK;
+}

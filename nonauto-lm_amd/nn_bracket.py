@@ -751,6 +751,11 @@ class RecurrentCore(torch.nn.Module, Registrable):
         packed = pack_padded_sequence(tokens, lengths.detach().cpu(), batch_first=True, enforce_sorted=False)
         encoded, _ = self._module(packed)
         output, _ = pad_packed_sequence(encoded, batch_first=True, total_length=mask.size(1))
+        if (output.dtype == torch.float16 and torch.is_autocast_enabled()
+                and torch.get_autocast_dtype("cuda") == torch.bfloat16):
+            # this PyTorch-ROCm build runs the MIOpen recurrent kernels in fp16 whatever the autocast dtype is; the
+            # latent path takes fp32 / bf16 (bug fix for BASELINE config 4 under bf16 autocast, bracket otherwise frozen)
+            output = output.to(torch.bfloat16)
         return output
 
     def get_input_size(self) -> int:

@@ -1424,6 +1424,53 @@ def test_whole_model_bf16_c2_vs_fp32_oracle(M):
     assert max(worst.values()) < 2e-2, sorted(worst.items(), key=lambda kv: -kv[1])[:5]
 
 
+# ------------------------------------------------------------------------------------ whole model, C4 shape (auto family)
+def test_whole_model_auto_c4_vs_oracle(M):
+    """BASELINE config 4 at the bench shape (AutoModel: LSTM encoder, LSTM-cell decoder with teacher
+    forcing 1.0, K = 4 NICE-FF steps on the sentence latent (B = 256, D = 64), S = 64, V = 8192; auto_lm/model.py:100-119,
+    173, auto_lm/priors/flow_prior.py:36-50) in fp32 on the GPU against the host: the same stock recurrent bracket on
+    CPU ops + oracle/latent_path.py for gather-last, posterior sample / log q, the flow prior on 2-D latents, KL, NLL and
+    the ELBO tail, posterior noise injected.  fp32 bound of the model goldens: scalars <= 2e-5, latent-path gradients
+    <= 5e-4 of their tensor scale (they pass through the library LSTM in both directions)."""
+    import bench
+    B, S, D, H, K, _, _ = bench.CONFIGS["c4"]
+    V = bench.VOCAB
+    cfg = bench.config_model_params("c4")
+    torch.manual_seed(13)
+    model = M.VAELmModel.from_params(vocab=M.SimpleVocab(V), **cfg).to(DEV).train()
+    model.training_outputs_only = True
+    tokens = bench.synthetic_tokens(B, S, True, 13)         # ragged: the context is gathered at each sentence's last token
+    eps = torch.randn(B, 1, D, generator=torch.Generator().manual_seed(3))
+    out = model(tokens.to(DEV), tokens.to(DEV), eps=eps.to(DEV))
+    info = out["loss_info"]
+    info["batch-loss"].backward()
+    # ---- host reference
+    m = M.VAELmModel.from_params(vocab=M.SimpleVocab(V), **cfg).train()
+    m.load_state_dict({k: v.detach().float().cpu() for k, v in model.state_dict().items()})
+    torch.set_num_threads(8)
+    mask = O.tokens_mask(tokens)
+    enc = m._encoder.encoder(m._encoder._preprocess_embedding(m._embedder(tokens)), mask)
+    ctx = O.gather_last(enc, mask)
+    mu, sigma = m._posterior._mu_net(ctx), O.sigma_head(m._posterior._sigma_net[0](ctx))
+    z, _ = O.posterior_sample(mu, sigma, eps, None, 1)
+    logq = O.posterior_log_prob(z, mu, sigma, None, 1)
+    logits, _ = m._decoder(z, tokens)
+    recon = O.label_smoothing_nll(logits, tokens[:, 1:], mask[:, 1:].float(), 0.0, True)
+    sd = dict(m._prior.named_parameters())
+    ps = [O.NiceParams.from_state_dict(sd, f"_flows.{k}.") for k in range(K)]
+    _, logp = O.flow_prior_forward(z, O.nice_steps(ps), None)
+    ref = O.elbo_tail(recon, O.kl_default(logq, logp), B, 1)
+    ref["batch-loss"].backward()
+    assert rel_err(out["latent"], z) < 2e-5
+    errs = {k: rel_err(info[k], ref[k]) for k in ("batch-loss", "batch-kl", "batch-nll")}
+    assert max(errs.values()) < 2e-5, errs
+    got = dict(model.named_parameters())
+    worst = {name: rel_err(got[name].grad, p.grad) for name, p in m.named_parameters()
+             if name.startswith("_prior.") or name.startswith("_posterior.")}
+    print("C4 whole model vs oracle:", errs, "worst latent-path gradient", max(worst.values()))
+    assert max(worst.values()) < 5e-4, sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+
+
 # ------------------------------------------------------------------------------------ invertible linear kernels (a14)
 @pytest.mark.parametrize("N,D,heads,dtype", [
     (1, 8, 1, torch.float32), (77, 24, 3, torch.float32), (4099, 64, 4, torch.float32), (300, 70, 1, torch.float32),

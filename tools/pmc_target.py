@@ -16,7 +16,9 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 B, S, D, H, K, dtype_name, ragged = bench.CONFIGS[cfg]
 dev = torch.device("cuda", 0)
 torch.manual_seed(13)
-model = M.VAELmModel.from_params(vocab=M.SimpleVocab(bench.VOCAB), **bench.model_config(D, H, K)).to(dev).train()
+model = M.VAELmModel.from_params(vocab=M.SimpleVocab(bench.VOCAB), **bench.config_model_params(cfg)).to(dev).train()
 tokens = bench.synthetic_tokens(B, S, ragged, 13).to(dev)
-bench.flow_kernel_times(model, tokens, torch.bfloat16 if dtype_name == "bf16" else torch.float32, reps=reps, graph=False)
+auto = bench.FAMILY.get(cfg) == "auto"
+bench.flow_kernel_times(model, tokens, torch.bfloat16 if dtype_name == "bf16" else torch.float32, reps=reps, graph=False,
+                        family="auto" if auto else "nonauto", loss_kernels=not auto)
 print("done", cfg, reps)
