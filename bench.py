@@ -252,7 +252,7 @@ def flow_kernel_times(model, tokens, dtype, reps=50, graph=True, family="nonauto
                                              L.ptr(pk_f), L.ptr(pk_b), L.ptr(tok), B, 1, S, D, H, K, actid, 0, 1, 0.0, 1.0,
                                              L.stream()),
             "nice_stack_bwd": lambda: L.call("mivae_nice_big_bwd", L.ptr(z), L.ptr(z_out), L.ptr(hist), L.ptr(mask),
-                                             L.ptr(ptab), L.ptr(pk_c), L.ptr(pk_n), L.ptr(pk_b), L.ptr(dz_out), L.ptr(dlog),
+                                             L.ptr(ptab), L.ptr(pk_c), L.ptr(pk_n), L.ptr(pk_b), L.ptr(dz_out), L.ptr(dlog[:B]),
                                              L.ptr(dz_in), L.ptr(dsdt), L.ptr(hid), L.ptr(ws), L.ptr(dW1), L.ptr(db1), L.ptr(dW2),
                                              L.ptr(db2), None, B, 1, S, D, H, K, actid, 1, 0.0, 1.0, L.stream()),
         })
@@ -261,22 +261,23 @@ def flow_kernel_times(model, tokens, dtype, reps=50, graph=True, family="nonauto
             "nice_stack_fwd": lambda: L.call("mivae_nice_stack_fwd", L.ptr(z), L.ptr(z_out), L.ptr(hist), L.ptr(mask),
                                              L.ptr(packed), L.ptr(tok), B, 1, S, D, H, K, actid, 0, 1, 0.0, 1.0, code, L.stream()),
             "nice_stack_bwd": lambda: L.call("mivae_nice_stack_bwd", L.ptr(z), L.ptr(z_out), L.ptr(hist), L.ptr(mask),
-                                             L.ptr(packed), L.ptr(dz_out), L.ptr(dlog), L.ptr(dz_in), L.ptr(Gt), L.ptr(Ht),
-                                             L.ptr(dSt), L.ptr(x0t), N, 1, 1, D, H, K, actid, 1, 0.0, 1.0, code, L.stream()),
+                                             L.ptr(packed), L.ptr(dz_out), L.ptr(dlog[:B]), L.ptr(dz_in), L.ptr(Gt), L.ptr(Ht),
+                                             L.ptr(dSt), L.ptr(x0t), B, 1, S, D, H, K, actid, 1, 0.0, 1.0, code, L.stream()),
             "nice_dw": lambda: L.call("mivae_nice_dw", L.ptr(Gt), L.ptr(Ht), L.ptr(dSt), L.ptr(x0t), L.ptr(ws), L.ptr(dW1),
                                       L.ptr(db1), L.ptr(dW2), L.ptr(db2), N, h, H, K, code, L.stream()),
         })
-    # posterior sample + log q (a4 / a5), in-kernel noise: the other HBM-bound kernel of the latent path
-    mu_t, sg_t = torch.randn(B, S, D, device=dev).to(dtype), (torch.rand(B, S, D, device=dev) + 0.5).to(dtype)
-    zq, tokq, used = e(B, S, D), e(N, dt=torch.float32), torch.empty(2, dtype=torch.int64, device=dev)
+    # posterior: sigma head + sample + log q (a3 tail, a4, a5), in-kernel noise -- the other HBM-bound kernel of the path
+    mu_t, pre_t = torch.randn(B, S, D, device=dev).to(dtype), torch.randn(B, S, D, device=dev).to(dtype)
+    zq, sgq, tokq, used = e(B, S, D), e(B, S, D), e(N, dt=torch.float32), torch.empty(2, dtype=torch.int64, device=dev)
     dmu, dsg = e(B, S, D), e(B, S, D)
     dlq = torch.randn(B, device=dev)
     state = ops.philox_state(dev)
     calls.update({
-        "reparam_fwd": lambda: L.call("mivae_reparam_logq_fwd_rng", L.ptr(mu_t), L.ptr(sg_t), L.ptr(state), L.ptr(used),
-                                      L.ptr(mask), L.ptr(zq), L.ptr(tokq), B, 1, S, D, code, L.stream()),
-        "reparam_bwd": lambda: L.call("mivae_reparam_logq_bwd_rng", L.ptr(dz_out), L.ptr(dlq), L.ptr(sg_t), L.ptr(used),
-                                      L.ptr(mask), L.ptr(dmu), L.ptr(dsg), B, 1, S, D, code, L.stream()),
+        "reparam_fwd": lambda: L.call("mivae_posterior_fwd", L.ptr(mu_t), L.ptr(pre_t), 1, 1e-4, 5.0, None, L.ptr(state),
+                                      L.ptr(used), L.ptr(mask), L.ptr(zq), L.ptr(sgq), L.ptr(tokq), B, 1, S, D, code,
+                                      L.stream()),
+        "reparam_bwd": lambda: L.call("mivae_posterior_bwd", L.ptr(dz_out), L.ptr(dlq), 0, L.ptr(pre_t), 1, 1e-4, 5.0, None,
+                                      L.ptr(used), L.ptr(mask), L.ptr(dmu), L.ptr(dsg), B, 1, S, D, code, L.stream()),
     })
     return _time_calls(calls, reps, graph)
 
@@ -340,8 +341,8 @@ def kernel_rooflines(name, model, tokens, kern, hbm_measured):
         "lce_fwd": N * D * 2 + VOCAB * D * 2 + 32 * N,
         "lce_bwd": N * VOCAB * 2 + N * D * 2 + VOCAB * D * 2 + 16 * N,
         "lce_bwd_dh": N * VOCAB * 2 + N * D * 2 + 2 * VOCAB * D * 2 + 16 * N + N * D * 2,
-        # mu, sigma in, z out (noise drawn in-kernel) + per-token log q; backward: dz, sigma in, d mu, d sigma out
-        "reparam_fwd": 3 * n_real * D * e + mask_bytes + 4 * N,
+        # mu, pre-sigma in, z and sigma out (noise drawn in-kernel) + per-token log q; backward: dz, pre in, d mu, d pre out
+        "reparam_fwd": 4 * n_real * D * e + mask_bytes + 4 * N,
         "reparam_bwd": 4 * n_real * D * e + mask_bytes,
     }
     flops = {"nll_fwd": 0, "nll_bwd": 0, "lce_fwd": 2 * N * VOCAB * D, "lce_bwd": 2 * N * VOCAB * D,

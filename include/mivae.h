@@ -130,6 +130,22 @@ int mivae_reparam_logq_bwd_rng(const void* dz, const float* dlogq, const void* s
                                int64_t D, int dtype, void* stream);
 int mivae_philox_normal(const int64_t* rng_used, float* out, int64_t count, void* stream);
 
+/* a3 tail + a4 + a5 in ONE launch each way (posterior.py:23-27 sigma head Hardtanh(Softplus(.), lo, hi); :86-133 sample;
+ * :135-172 log q).  sigma_or_pre (B, S, D) is sigma itself (sigma_is_pre = 0) or the sigma head's pre-activation (1; sigma
+ * is then also written to sigma_out when that is not NULL).  Noise: eps ((B n), S, D) injected; or drawn in-kernel from
+ * rng_state = device int64[2] {seed, offset}: the launch copies the state to rng_used (int64[2], for the backward) and
+ * does not advance it -- follow up with mivae_rng_advance(rng_state), or hand rng_state to mivae_latent_tail_fwd of the
+ * same forward (the training step: no launch spent on the generator); both NULL: eps = 0.  tok_logq ((B n) S) fp32 =
+ * per-token log q (sum per sentence: mivae_segment_sum / mivae_latent_tail_fwd).
+ * Backward: d mu, and d sigma or d pre, (B, S, D); dlogq per sentence (B n) or, dlogq_per_token = 1, per token. */
+int mivae_rng_advance(int64_t* rng_state, void* stream);
+int mivae_posterior_fwd(const void* mu, const void* sigma_or_pre, int sigma_is_pre, float lo, float hi, const void* eps,
+                        const int64_t* rng_state, int64_t* rng_used, const int64_t* mask, void* z, void* sigma_out,
+                        float* tok_logq, int64_t B, int64_t n, int64_t S, int64_t D, int dtype, void* stream);
+int mivae_posterior_bwd(const void* dz, const float* dlogq, int dlogq_per_token, const void* sigma_or_pre, int sigma_is_pre,
+                        float lo, float hi, const void* eps, const int64_t* rng_used, const int64_t* mask, void* dmu,
+                        void* dsigma, int64_t B, int64_t n, int64_t S, int64_t D, int dtype, void* stream);
+
 /* ---- base distribution ----------------------------------------------------------------------- */
 /* tok[bn, s] = mask * sum_d Normal(mu, std).log_prob(z).  Replaces DefaultPrior.masked_log_prob,
  * nonauto priors/prior.py:148-158; auto priors/prior.py:93. */
@@ -327,6 +343,20 @@ int mivae_elbo_fwd(const float* recon, const float* kl, float* out3, int64_t B, 
 int mivae_elbo_bwd(const float* recon, const float* kl, const float* gout3, float* drecon, float* dkl,
                    int64_t B, int64_t n, float recon_weight, float kl_weight, int iwae,
                    const float* weights_dev, void* stream);
+/* The per-sentence reductions of log q / log p (posterior.py:157-172, priors/prior.py:148-158: sums of the per-token
+ * values), DefaultKLLoss (nn/kl_loss.py:38-49) and the ELBO tail (models/base/model.py:171-193) in ONE launch each way:
+ * tok_logq, tok_logp ((B n), S) fp32, recon (B n) -> logq, logp, kl (B n) and out3 = {batch-loss, batch-kl, batch-nll};
+ * the backward turns gout3 into d recon, d log q, d log p per sentence.  rng_state (or NULL): a generator state whose
+ * offset the forward advances by one (see mivae_posterior_fwd).  One block: B n <= 16384, (B n) S <= 2^21
+ * (mivae_latent_tail_supported); larger shapes use mivae_segment_sum + mivae_kl_* + mivae_elbo_*. */
+int mivae_latent_tail_supported(int64_t B, int64_t n, int64_t S);
+int mivae_latent_tail_fwd(const float* tok_logq, const float* tok_logp, const float* recon, float* logq, float* logp,
+                          float* kl, float* out3, int64_t B, int64_t n, int64_t S, int use_free_bits, float free_bits,
+                          float recon_weight, float kl_weight, int iwae, const float* weights_dev, int64_t* rng_state,
+                          void* stream);
+int mivae_latent_tail_bwd(const float* recon, const float* logq, const float* logp, const float* gout3, float* drecon,
+                          float* dlogq, float* dlogp, int64_t B, int64_t n, int use_free_bits, float free_bits,
+                          float recon_weight, float kl_weight, int iwae, const float* weights_dev, void* stream);
 
 /* ---- reconstruction term: label-smoothing NLL over the vocabulary ------------------------------ */
 /* per_seq[b] = sum_s w[b,s] * nll[b,s] / clamp(sum_s w[b,s], 1e-13) with
@@ -554,8 +584,8 @@ int mivae_nice_big_fwd(const void* z_in, void* z_out, void* x1_hist, const int64
 int64_t mivae_nice_big_dw_workspace_floats(int64_t N, int64_t h, int64_t H, int64_t K);
 /* autograd of mivae_nice_big_fwd (forward direction) in three launches + a fixed-order slab fold: dz_in (N, D) and the
  * gradients of all 4K Linear layers -- written to dW1 (K,2,H,h), db1 (K,2,H), dW2 (K,2,h,H), db2 (K,2,h), or ADDED
- * into the buffers of grad_ptrs (device int64[K][8], mivae_nice_pack's order) when that is given.  dlogp (N) = per-token
- * cotangent of tok_val; ptr_table = the device pointer table given to mivae_nice_big_pack (the weight-gradient kernel reads
+ * into the buffers of grad_ptrs (device int64[K][8], mivae_nice_pack's order) when that is given.  dlogp (Bn) = cotangent
+ * of every sentence's sum of tok_val, as mivae_nice_stack_bwd (per-token cotangents: Bn = N, S = 1, mask flattened); ptr_table = the device pointer table given to mivae_nice_big_pack (the weight-gradient kernel reads
  * its stationary operands from the fp32 parameters); dSdT = scratch (K, 2, N, h) in the latent dtype; workspace:
  * mivae_nice_big_dw_workspace_floats.  hidden = scratch of mivae_nice_big_hidden_elems(N, h, H, K) elements of the
  * latent dtype, or NULL: with it the nets launch saves the hidden activations and d pre and the weight gradients are two

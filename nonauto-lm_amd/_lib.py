@@ -55,6 +55,12 @@ SIGNATURES = {
     "mivae_reparam_logq_fwd_rng": [P, P, P, P, P, P, P, I64, I64, I64, I64, I32, P],
     "mivae_reparam_logq_bwd_rng": [P, P, P, P, P, P, P, I64, I64, I64, I64, I32, P],
     "mivae_philox_normal": [P, P, I64, P],
+    "mivae_posterior_fwd": [P, P, I32, F32, F32, P, P, P, P, P, P, P, I64, I64, I64, I64, I32, P],
+    "mivae_posterior_bwd": [P, P, I32, P, I32, F32, F32, P, P, P, P, P, I64, I64, I64, I64, I32, P],
+    "mivae_latent_tail_supported": [I64, I64, I64],
+    "mivae_latent_tail_fwd": [P, P, P, P, P, P, P, I64, I64, I64, I32, F32, F32, F32, I32, P, P, P],
+    "mivae_rng_advance": [P, P],
+    "mivae_latent_tail_bwd": [P, P, P, P, P, P, P, I64, I64, I32, F32, F32, F32, I32, P, P],
     "mivae_maf_sequential_bwd": [P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I32, I32, I32, P],
     "mivae_maf_sequential_bwd_supported": [I64, I64],
     "mivae_maf_sequential_bwd_blocks": [I64],

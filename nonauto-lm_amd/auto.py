@@ -165,6 +165,13 @@ class AutoModel(VAELmModel):
     def _get_prior_log_prob(self, z, mask=None):
         return self._prior.log_probability(z, None)
 
+    def _posterior_inputs(self, encoded):
+        return encoded.ctx, None
+
+    def _prior_token_log_prob(self, z, mask=None):
+        fn = getattr(self._prior, "token_log_prob", None)
+        return None if fn is None else fn(z, None)
+
     def calc_mutual_info(self, src_tokens, random: bool = True):
         encoded = self.encode(src_tokens)
         latent, log_q = self.sample_from_posterior(encoded, random=True)

@@ -27,6 +27,23 @@ namespace {
 
 constexpr int kBlock = 256;
 
+// Single-instruction transcendentals (v_log_f32 / v_exp_f32 / v_rcp_f32: ~1 ulp): the elementwise kernels of the latent
+// path draw noise (Philox + Box-Muller), take a softplus, a log and a reciprocal PER ELEMENT -- with the IEEE-exact libm
+// forms (logf, expf, log1pf, sincospif, division: 20-60 instructions each) they were VALU-bound at 2-3x their HBM time.
+// Relative error <= ~3e-7 on the values used here, two orders inside the 1e-5 parity bound.
+__device__ __forceinline__ float f_log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994531f; }
+__device__ __forceinline__ float f_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float f_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// softplus with beta = 1, threshold = 20 (torch.nn.Softplus defaults, posterior.py:23-27): log1p(e^x) as a 4-term series
+// below e^x = 2^-6 (truncation 1e-8 relative) and log(1 + e^x) above (1 + e^x is then exact to 6e-8 of a value >= 0.0155)
+__device__ __forceinline__ float softplus20(float x) {
+  const float e = f_exp(fminf(x, 20.f));
+  const float series = e * (1.0f - e * (0.5f - e * (0.33333334f - 0.25f * e)));
+  const float lg = f_log(1.0f + e);
+  return x > 20.f ? x : (e < 0.015625f ? series : lg);
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return f_rcp(1.0f + f_exp(-x)); }
+
 struct RowCfg {
   int vec;
   int L;
@@ -105,8 +122,7 @@ __device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsi
   const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1;
   c[0] = n0; c[1] = (unsigned)p1; c[2] = n2; c[3] = (unsigned)p0;
 }
-__device__ __forceinline__ void philox_normal4(const int64_t* __restrict__ rng, int64_t quad, float (&out)[4]) {
-  const unsigned long long seed = (unsigned long long)rng[0], off = (unsigned long long)rng[1];
+__device__ __forceinline__ void philox_normal4v(unsigned long long seed, unsigned long long off, int64_t quad, float (&out)[4]) {
   unsigned c[4] = {(unsigned)quad, (unsigned)((unsigned long long)quad >> 32), (unsigned)off, (unsigned)(off >> 32)};
   unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
 #pragma unroll
@@ -118,11 +134,14 @@ __device__ __forceinline__ void philox_normal4(const int64_t* __restrict__ rng, 
   for (int h = 0; h < 2; ++h) {
     const float u1 = ((float)c[2 * h] + 0.5f) * 2.3283064365386963e-10f;        // (0, 1]
     const float u2 = ((float)c[2 * h + 1] + 0.5f) * 2.3283064365386963e-10f;
-    const float r = sqrtf(-2.0f * logf(u1));
-    float sn, cs;
-    sincospif(2.0f * u2, &sn, &cs);
-    out[2 * h] = r * cs; out[2 * h + 1] = r * sn;
+    // Box-Muller on the hardware transcendentals: r = sqrt(-2 ln u1) from v_log_f32 (log2), v_sin / v_cos take the angle
+    // in revolutions
+    const float r = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+    out[2 * h] = r * __builtin_amdgcn_cosf(u2); out[2 * h + 1] = r * __builtin_amdgcn_sinf(u2);
   }
+}
+__device__ __forceinline__ void philox_normal4(const int64_t* __restrict__ rng, int64_t quad, float (&out)[4]) {
+  philox_normal4v((unsigned long long)rng[0], (unsigned long long)rng[1], quad, out);
 }
 // eps of the VEC elements starting at flat element index e0 (VEC = 1: any e0; VEC = 4, 8: e0 a multiple of 4)
 template <int VEC>
@@ -146,7 +165,7 @@ __device__ __forceinline__ void philox_eps(const int64_t* __restrict__ rng, int6
 __global__ void k_rng_take(int64_t* __restrict__ state, int64_t* __restrict__ used) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     const int64_t seed = state[0], off = state[1];
-    used[0] = seed; used[1] = off;
+    if (used) { used[0] = seed; used[1] = off; }
     state[1] = off + 1;
   }
 }
@@ -189,7 +208,7 @@ __global__ void k_reparam_fwd(const T* __restrict__ mu, const T* __restrict__ si
         float zz = (vm[i] + e * vs[i]) * m;
         float d = zz - vm[i];
         float sg = vs[i];
-        acc += -0.5f * (d * d * (1.0f / (sg * sg)) + 2.0f * logf(sg) + kLog2Pi);
+        acc += -0.5f * (d * d * f_rcp(sg * sg) + 2.0f * f_log(sg) + kLog2Pi);
         vz[i] = zz;
       }
       RowIO<T, VEC>::store(z + row * D + c, vz);
@@ -233,13 +252,150 @@ __global__ void k_reparam_bwd(const T* __restrict__ dz, const float* __restrict_
         float gi = dz ? g[i] : 0.f;
         float ei = (eps || rng) ? e[i] : 0.f;
         am[i] += gi;
-        as[i] += gi * ei - dq / vs[i];
+        as[i] += gi * ei - dq * f_rcp(vs[i]);
       }
     }
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { am[i] *= m; as[i] *= m; }
     RowIO<T, VEC>::store(dmu + prow * D + c, am);
     RowIO<T, VEC>::store(dsigma + prow * D + c, as);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a3 tail + a4 + a5 in ONE launch each way (launch-count pass over the latent path): the sigma head
+// Hardtanh(Softplus(pre), lo, hi) (posterior.py:23-27) is evaluated inside the sample / log q kernel (PRE = true: the
+// second operand is the head's pre-activation) and sigma is written out once for the callers that want it.  With
+// in-kernel noise the launch READS the generator state {seed, offset} and records it in rng_used; advancing the state
+// is left to a later single-thread step on the same stream -- mivae_rng_advance, or the ELBO tail kernel of the same
+// forward (mivae_latent_tail_fwd's rng_state argument), so that the training step pays no launch for it.  (A version in
+// which the last block to finish advanced the state through an atomic ticket was measured: thousands of blocks
+// serialise on the one ticket word, 53 us instead of 23 us at the C3 shape.)  sigma is rounded to the latent dtype
+// before use, exactly what the two-launch form (sigma head, then k_reparam_fwd) computes with.
+template <int VEC>
+__device__ __forceinline__ void philox_epsv(unsigned long long seed, unsigned long long off, int64_t e0, float (&ve)[VEC]) {
+  if constexpr (VEC == 1) {
+    float q[4];
+    philox_normal4v(seed, off, e0 >> 2, q);
+    ve[0] = q[e0 & 3];
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; i += 4) {
+      float q[4];
+      philox_normal4v(seed, off, (e0 + i) >> 2, q);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ve[i + j] = q[j];
+    }
+  }
+}
+template <typename T>
+__device__ __forceinline__ float round_to(float x) {
+  if constexpr (sizeof(T) == 2) return bf16_to_f32(f32_to_bf16(x));
+  else return x;
+}
+
+template <typename T, int VEC, bool PRE>
+__global__ void k_post_fwd(const T* __restrict__ mu, const T* __restrict__ sg_in, const T* __restrict__ eps,
+                           const int64_t* __restrict__ mask, T* __restrict__ z, T* __restrict__ sigma_out,
+                           float* __restrict__ tok_logq, int64_t rows, int n, int S, int D, int L, float lo, float hi,
+                           const int64_t* __restrict__ rng_state, int64_t* __restrict__ rng_used) {
+  unsigned long long seed = 0, off = 0;
+  if (rng_state) { seed = (unsigned long long)rng_state[0]; off = (unsigned long long)rng_state[1]; }
+  int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t row = tid / L;
+  int lig = (int)(tid % L);
+  float acc = 0.f;
+  if (row < rows) {
+    int64_t bn = row / S;
+    int s = (int)(row - bn * S);
+    int64_t b = bn / n;
+    int64_t prow = b * S + s;
+    const bool first = bn - b * n == 0;          // the sample that writes sigma (one copy per posterior row)
+    float m = mask ? (float)mask[prow] : 1.f;
+    for (int c = lig * VEC; c < D; c += L * VEC) {
+      float vm[VEC], vs[VEC], ve[VEC], vz[VEC];
+      RowIO<T, VEC>::load(mu + prow * D + c, vm);
+      RowIO<T, VEC>::load(sg_in + prow * D + c, vs);
+      if (PRE) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) vs[i] = round_to<T>(fminf(fmaxf(softplus20(vs[i]), lo), hi));
+        if (sigma_out && first) RowIO<T, VEC>::store(sigma_out + prow * D + c, vs);
+      }
+      if (eps) RowIO<T, VEC>::load(eps + row * D + c, ve);
+      else if (rng_state) philox_epsv<VEC>(seed, off, row * D + c, ve);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        float e = (eps || rng_state) ? ve[i] : 0.f;
+        float zz = (vm[i] + e * vs[i]) * m;
+        float d = zz - vm[i];
+        float sg = vs[i];
+        acc += -0.5f * (d * d * f_rcp(sg * sg) + 2.0f * f_log(sg) + kLog2Pi);
+        vz[i] = zz;
+      }
+      RowIO<T, VEC>::store(z + row * D + c, vz);
+    }
+    acc *= m;
+  }
+  acc = group_sum(acc, L);
+  if (row < rows && lig == 0) tok_logq[row] = acc;
+  if (rng_state && blockIdx.x == 0 && threadIdx.x == 0) {   // the draw this launch used, for the backward
+    rng_used[0] = (int64_t)seed; rng_used[1] = (int64_t)off;
+  }
+}
+
+// backward: rows over (b, s); dq_tok = 0: dlogq holds one cotangent per sentence (B n); 1: one per token ((B n) S).
+//   dmu = sum_j dz_j * m ; dsigma = sum_j (dz_j * eps_j - dlogq_j / sigma) * m ; PRE: d pre = dsigma * sigmoid(pre) inside
+//   the open interval (lo, hi), 0 elsewhere (k_sigma_head_bwd), dsigma rounded to the latent dtype first like the
+//   two-launch form
+template <typename T, int VEC, bool PRE>
+__global__ void k_post_bwd(const T* __restrict__ dz, const float* __restrict__ dlogq, int dq_tok,
+                           const T* __restrict__ sg_in, const T* __restrict__ eps, const int64_t* __restrict__ mask,
+                           T* __restrict__ dmu, T* __restrict__ dsg, int64_t prows, int n, int S, int D, int L,
+                           float lo, float hi, const int64_t* __restrict__ rng_used) {
+  int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t prow = tid / L;
+  int lig = (int)(tid % L);
+  if (prow >= prows) return;
+  unsigned long long seed = 0, off = 0;
+  if (rng_used) { seed = (unsigned long long)rng_used[0]; off = (unsigned long long)rng_used[1]; }
+  int64_t b = prow / S;
+  int s = (int)(prow - b * S);
+  float m = mask ? (float)mask[prow] : 1.f;
+  for (int c = lig * VEC; c < D; c += L * VEC) {
+    float vp[VEC], vs[VEC], am[VEC], as[VEC];
+    RowIO<T, VEC>::load(sg_in + prow * D + c, vp);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      vs[i] = PRE ? round_to<T>(fminf(fmaxf(softplus20(vp[i]), lo), hi)) : vp[i];
+      am[i] = 0.f; as[i] = 0.f;
+    }
+    for (int j = 0; j < n; ++j) {
+      int64_t bn = b * n + j;
+      int64_t row = bn * S + s;
+      float g[VEC], e[VEC];
+      if (dz) RowIO<T, VEC>::load(dz + row * D + c, g);
+      if (eps) RowIO<T, VEC>::load(eps + row * D + c, e);
+      else if (rng_used) philox_epsv<VEC>(seed, off, row * D + c, e);
+      float dq = dlogq ? dlogq[dq_tok ? row : bn] : 0.f;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        float gi = dz ? g[i] : 0.f;
+        float ei = (eps || rng_used) ? e[i] : 0.f;
+        am[i] += gi;
+        as[i] += gi * ei - dq * f_rcp(vs[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      am[i] *= m; as[i] *= m;
+      if (PRE) {
+        const float sp = softplus20(vp[i]);
+        const float d = vp[i] > 20.f ? 1.f : sigmoid_f(vp[i]);
+        as[i] = (sp > lo && sp < hi) ? round_to<T>(as[i]) * d : 0.f;
+      }
+    }
+    RowIO<T, VEC>::store(dmu + prow * D + c, am);
+    RowIO<T, VEC>::store(dsg + prow * D + c, as);
   }
 }
 
@@ -816,6 +972,118 @@ __global__ void k_elbo_bwd(const float* __restrict__ recon, const float* __restr
   }
 }
 
+
+// a5 / a15 reductions + a16 + a17 in ONE launch each way (launch-count pass): per-sentence sums of the
+// per-token log q and log p (the k_segment_sum order: lanes stride over s, shuffle tree), DefaultKLLoss
+// (kl_loss.py:38-49) and the ELBO tail (models/base/model.py:171-193, the k_elbo_fwd arithmetic on the first 256
+// threads) by one block of 1024 threads; kl of every sentence is staged in LDS (dynamic, (B n) floats).
+__global__ void __launch_bounds__(1024) k_tail_fwd(const float* __restrict__ tok_q, const float* __restrict__ tok_p,
+                                                  const float* __restrict__ recon, float* __restrict__ logq,
+                                                  float* __restrict__ logp, float* __restrict__ kl_out,
+                                                  float* __restrict__ out, int B, int n, int S, int use_fb, float fb,
+                                                  float wr, float wk, int iwae, const float* __restrict__ wdev,
+                                                  int64_t* __restrict__ rng_state) {
+  extern __shared__ float s_kl[];
+  __shared__ float red[8];
+  const int Bn = B * n;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  for (int bn = wave; bn < Bn; bn += nw) {
+    float aq = 0.f, ap = 0.f;
+    for (int s = lane; s < S; s += 64) {
+      aq += tok_q[(int64_t)bn * S + s];
+      ap += tok_p[(int64_t)bn * S + s];
+    }
+    aq = group_sum(aq, 64);
+    ap = group_sum(ap, 64);
+    if (lane == 0) {
+      float v = aq - ap;
+      if (use_fb) v = v < fb ? fb : v;
+      logq[bn] = aq; logp[bn] = ap; kl_out[bn] = v;
+      s_kl[bn] = v;
+    }
+  }
+  __syncthreads();
+  if (wdev) { wr = wdev[0]; wk = wdev[1]; }
+  float a_loss = 0.f, a_kl = 0.f, a_nll = 0.f;
+  if (threadIdx.x < 256) {
+    for (int b = threadIdx.x; b < B; b += 256) {
+      float mx = -INFINITY;
+      for (int j = 0; j < n; ++j) {
+        float r = recon[b * n + j], k = s_kl[b * n + j];
+        a_kl += k;
+        a_nll += r;
+        float l = wr * r + wk * k;
+        if (iwae) mx = fmaxf(mx, l);
+        else a_loss += l;
+      }
+      if (iwae) {
+        float den = 0.f, num = 0.f;
+        for (int j = 0; j < n; ++j) {
+          float l = wr * recon[b * n + j] + wk * s_kl[b * n + j];
+          float e = expf(l - mx);
+          den += e;
+          num += e * l;
+        }
+        a_loss += num / den;
+      }
+    }
+  }
+  // the three sums over the first four waves, in k_elbo_fwd's order
+  float sums[3] = {a_loss, a_kl, a_nll};
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    float v = group_sum(sums[q], 64);
+    __syncthreads();
+    if (lane == 0 && wave < 4) red[wave] = v;
+    __syncthreads();
+    sums[q] = ((red[0] + red[1]) + red[2]) + red[3];
+  }
+  if (threadIdx.x == 0) {
+    if (rng_state) rng_state[1] += 1;       // the posterior kernel of this forward drew from the state: one draw taken
+    out[0] = sums[0] / (iwae ? (float)B : (float)B * n);
+    out[1] = sums[1] / ((float)B * n);
+    out[2] = sums[2] / ((float)B * n);
+  }
+}
+
+// gout = {d batch-loss, d batch-kl, d batch-nll} -> d recon, d log q, d log p per sentence (k_elbo_bwd + k_kl_bwd)
+__global__ void k_tail_bwd(const float* __restrict__ recon, const float* __restrict__ logq, const float* __restrict__ logp,
+                           const float* __restrict__ gout, float* __restrict__ drecon, float* __restrict__ dq,
+                           float* __restrict__ dp, int B, int n, int use_fb, float fb, float wr, float wk, int iwae,
+                           const float* __restrict__ wdev) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  if (wdev) { wr = wdev[0]; wk = wdev[1]; }
+  float gl = gout[0], gk = gout[1] / ((float)B * n), gn = gout[2] / ((float)B * n);
+  auto kl_of = [&](int i) { float v = logq[i] - logp[i]; if (use_fb) v = v < fb ? fb : v; return v; };
+  auto put = [&](int i, float dr, float dk) {
+    const float v = logq[i] - logp[i];
+    const float g = (use_fb && !(v >= fb)) ? 0.f : dk;
+    drecon[i] = dr; dq[i] = g; dp[i] = -g;
+  };
+  if (!iwae) {
+    float c = gl / ((float)B * n);
+    for (int j = 0; j < n; ++j) put(b * n + j, wr * c + gn, wk * c + gk);
+    return;
+  }
+  float mx = -INFINITY;
+  for (int j = 0; j < n; ++j) mx = fmaxf(mx, wr * recon[b * n + j] + wk * kl_of(b * n + j));
+  float den = 0.f, num = 0.f;
+  for (int j = 0; j < n; ++j) {
+    float l = wr * recon[b * n + j] + wk * kl_of(b * n + j);
+    float e = expf(l - mx);
+    den += e;
+    num += e * l;
+  }
+  float mean = num / den;
+  for (int j = 0; j < n; ++j) {
+    float l = wr * recon[b * n + j] + wk * kl_of(b * n + j);
+    float w = expf(l - mx) / den;
+    float c = gl / (float)B * w * (1.f + l - mean);
+    put(b * n + j, wr * c + gn, wk * c + gk);
+  }
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -884,7 +1152,6 @@ extern "C" int mivae_attn_bias(const int64_t* mask, void* out, int64_t B, int64_
 // sigma head of the posterior: sigma = Hardtanh(Softplus(pre), lo, hi) (nonauto posterior.py:23-27: Softplus with
 // beta = 1, threshold = 20, then Hardtanh(1e-4, 5)) and its gradient d pre = d sigma * sigmoid(pre) inside the open
 // interval (lo, hi), 0 elsewhere -- one launch each instead of softplus / hardtanh / dtype-cast kernels.
-__device__ __forceinline__ float softplus20(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 template <typename T>
 __global__ void k_sigma_head_fwd(const T* __restrict__ pre, T* __restrict__ sigma, int64_t n, float lo, float hi) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -902,7 +1169,7 @@ __global__ void k_sigma_head_bwd(const T* __restrict__ pre, const T* __restrict_
     RowIO<T, 1>::load(pre + i, v);
     RowIO<T, 1>::load(dsigma + i, g);
     const float sp = softplus20(v[0]);
-    const float d = v[0] > 20.f ? 1.f : 1.f / (1.f + expf(-v[0]));
+    const float d = v[0] > 20.f ? 1.f : sigmoid_f(v[0]);
     g[0] = (sp > lo && sp < hi) ? g[0] * d : 0.f;
     RowIO<T, 1>::store(dpre + i, g);
   }
@@ -1167,6 +1434,123 @@ extern "C" int mivae_reparam_logq_bwd_rng(const void* dz, const float* dlogq, co
   MIVAE_REQUIRE(rng_used, "reparam_logq_bwd_rng: null generator state");
   return reparam_bwd_impl("reparam_logq_bwd_rng", dz, dlogq, sigma, nullptr, rng_used, mask, dmu, dsigma, B, n, S, D,
                           dtype, stream);
+}
+
+// ---- fused posterior sample (sigma head + sample + log q + generator bookkeeping): one launch each way --------------
+namespace {
+template <typename T, int VEC>
+void l_post_fwd(const void* mu, const void* sg, int pre, const void* eps, const int64_t* mask, void* z, void* sigma_out,
+                float* tok, int64_t rows, int n, int S, int D, float lo, float hi, const int64_t* rng_state, int64_t* rng_used,
+                RowCfg c, hipStream_t st) {
+  if (pre)
+    k_post_fwd<T, VEC, true><<<c.grid, kBlock, 0, st>>>((const T*)mu, (const T*)sg, (const T*)eps, mask, (T*)z,
+                                                       (T*)sigma_out, tok, rows, n, S, D, c.L, lo, hi, rng_state, rng_used);
+  else
+    k_post_fwd<T, VEC, false><<<c.grid, kBlock, 0, st>>>((const T*)mu, (const T*)sg, (const T*)eps, mask, (T*)z,
+                                                        (T*)sigma_out, tok, rows, n, S, D, c.L, lo, hi, rng_state, rng_used);
+}
+template <typename T, int VEC>
+void l_post_bwd(const void* dz, const float* dlogq, int dq_tok, const void* sg, int pre, const void* eps,
+                const int64_t* mask, void* dmu, void* dsg, int64_t prows, int n, int S, int D, float lo, float hi,
+                const int64_t* rng_used, RowCfg c, hipStream_t st) {
+  if (pre)
+    k_post_bwd<T, VEC, true><<<c.grid, kBlock, 0, st>>>((const T*)dz, dlogq, dq_tok, (const T*)sg, (const T*)eps, mask,
+                                                       (T*)dmu, (T*)dsg, prows, n, S, D, c.L, lo, hi, rng_used);
+  else
+    k_post_bwd<T, VEC, false><<<c.grid, kBlock, 0, st>>>((const T*)dz, dlogq, dq_tok, (const T*)sg, (const T*)eps, mask,
+                                                        (T*)dmu, (T*)dsg, prows, n, S, D, c.L, lo, hi, rng_used);
+}
+}  // namespace
+
+// Posterior sample + log q with the sigma head inside (a3 tail + a4 + a5, posterior.py:23-27, 86-172) in ONE launch.
+//   sigma_or_pre (B, S, D): sigma itself (sigma_is_pre = 0) or the sigma head's pre-activation (1: sigma =
+//   Hardtanh(Softplus(pre), lo, hi), written to sigma_out (B, S, D) when that is not NULL);
+//   noise: eps ((B n), S, D) injected, or drawn in-kernel when rng_state (device int64[2] {seed, offset}) is given -- the
+//   launch copies the state to rng_used (int64[2], kept for the backward) and does NOT advance it: follow up with
+//   mivae_rng_advance(rng_state) or hand rng_state to mivae_latent_tail_fwd of the same forward; both NULL: eps = 0.
+//   tok_logq ((B n) S) fp32 per-token log q; sum it per sentence with mivae_segment_sum or mivae_latent_tail_fwd.
+extern "C" int mivae_posterior_fwd(const void* mu, const void* sigma_or_pre, int sigma_is_pre, float lo, float hi,
+                                   const void* eps, const int64_t* rng_state, int64_t* rng_used, const int64_t* mask, void* z,
+                                   void* sigma_out, float* tok_logq, int64_t B, int64_t n, int64_t S, int64_t D,
+                                   int dtype, void* stream) {
+  int rc = check_latent("posterior_fwd", B * n, S, D, dtype);
+  if (rc) return rc;
+  MIVAE_REQUIRE(n >= 1 && lo <= hi, "posterior_fwd: bad arguments");
+  MIVAE_REQUIRE(!(eps && rng_state) && (!rng_state || rng_used), "posterior_fwd: eps and rng_state exclude each other; "
+                "rng_state needs rng_used");
+  if (B == 0) return MIVAE_OK;
+  MIVAE_REQUIRE(mu && sigma_or_pre && z && tok_logq, "posterior_fwd: null pointer");
+  int64_t rows = B * n * S;
+  bool al = aligned16(mu) && aligned16(sigma_or_pre) && aligned16(z) && (!eps || aligned16(eps)) &&
+            (!sigma_out || aligned16(sigma_out));
+  RowCfg c = row_cfg(rows, D, dtype, al);
+  DISPATCH(dtype, c.vec, l_post_fwd, mu, sigma_or_pre, sigma_is_pre, eps, mask, z, sigma_out, tok_logq, rows, (int)n,
+           (int)S, (int)D, lo, hi, rng_state, rng_used, c, S_(stream));
+  MIVAE_CHECK_LAUNCH("posterior_fwd");
+  return MIVAE_OK;
+}
+
+// Its backward: d mu and d sigma (or d pre when sigma_is_pre) (B, S, D).  dlogq: per sentence (B n) (dlogq_per_token =
+// 0) or per token ((B n) S) (1), or NULL; dz ((B n), S, D) or NULL; noise as in the forward (eps, or rng_used).
+extern "C" int mivae_posterior_bwd(const void* dz, const float* dlogq, int dlogq_per_token, const void* sigma_or_pre,
+                                   int sigma_is_pre, float lo, float hi, const void* eps, const int64_t* rng_used,
+                                   const int64_t* mask, void* dmu, void* dsigma, int64_t B, int64_t n, int64_t S,
+                                   int64_t D, int dtype, void* stream) {
+  int rc = check_latent("posterior_bwd", B * n, S, D, dtype);
+  if (rc) return rc;
+  MIVAE_REQUIRE(n >= 1 && lo <= hi && !(eps && rng_used), "posterior_bwd: bad arguments");
+  if (B == 0) return MIVAE_OK;
+  MIVAE_REQUIRE(sigma_or_pre && dmu && dsigma, "posterior_bwd: null pointer");
+  int64_t prows = B * S;
+  bool al = aligned16(sigma_or_pre) && aligned16(dmu) && aligned16(dsigma) && (!dz || aligned16(dz)) &&
+            (!eps || aligned16(eps));
+  RowCfg c = row_cfg(prows, D, dtype, al);
+  DISPATCH(dtype, c.vec, l_post_bwd, dz, dlogq, dlogq_per_token ? 1 : 0, sigma_or_pre, sigma_is_pre, eps, mask, dmu,
+           dsigma, prows, (int)n, (int)S, (int)D, lo, hi, rng_used, c, S_(stream));
+  MIVAE_CHECK_LAUNCH("posterior_bwd");
+  return MIVAE_OK;
+}
+
+// Per-sentence log q / log p (sums of the per-token values), DefaultKLLoss and the ELBO tail in ONE launch
+// (posterior.py:157-172 reduction, prior.py:148-158 reduction, nn/kl_loss.py:38-49, models/base/model.py:171-193).
+//   tok_logq, tok_logp ((B n), S) fp32; recon (B n); outputs logq, logp, kl (B n) and out3 = {batch-loss, batch-kl,
+//   batch-nll}.  weights_dev as mivae_elbo_fwd.  rng_state (or NULL): generator state whose offset this launch advances by
+//   one (the draw mivae_posterior_fwd of the same forward took).  Limits (one block): B n <= 16384, (B n) S <= 2^21.
+extern "C" int mivae_latent_tail_supported(int64_t B, int64_t n, int64_t S) {
+  return B > 0 && n > 0 && S > 0 && B * n <= 16384 && B * n * S <= (1ll << 21) ? 1 : 0;
+}
+extern "C" int mivae_latent_tail_fwd(const float* tok_logq, const float* tok_logp, const float* recon, float* logq,
+                                     float* logp, float* kl, float* out3, int64_t B, int64_t n, int64_t S, int use_fb,
+                                     float free_bits, float recon_weight, float kl_weight, int iwae,
+                                     const float* weights_dev, int64_t* rng_state, void* stream) {
+  MIVAE_REQUIRE(mivae_latent_tail_supported(B, n, S), "latent_tail_fwd: unsupported shape B=%ld n=%ld S=%ld", (long)B,
+                (long)n, (long)S);
+  MIVAE_REQUIRE(tok_logq && tok_logp && recon && logq && logp && kl && out3, "latent_tail_fwd: null pointer");
+  const size_t lds = (size_t)(B * n) * sizeof(float);
+  k_tail_fwd<<<1, 1024, lds, S_(stream)>>>(tok_logq, tok_logp, recon, logq, logp, kl, out3, (int)B, (int)n, (int)S,
+                                           use_fb, free_bits, recon_weight, kl_weight, iwae, weights_dev, rng_state);
+  MIVAE_CHECK_LAUNCH("latent_tail_fwd");
+  return MIVAE_OK;
+}
+extern "C" int mivae_latent_tail_bwd(const float* recon, const float* logq, const float* logp, const float* gout3,
+                                     float* drecon, float* dlogq, float* dlogp, int64_t B, int64_t n, int use_fb,
+                                     float free_bits, float recon_weight, float kl_weight, int iwae,
+                                     const float* weights_dev, void* stream) {
+  MIVAE_REQUIRE(B > 0 && n > 0 && B * n < (1ll << 30), "latent_tail_bwd: bad shape");
+  MIVAE_REQUIRE(recon && logq && logp && gout3 && drecon && dlogq && dlogp, "latent_tail_bwd: null pointer");
+  k_tail_bwd<<<(unsigned)((B + kBlock - 1) / kBlock), kBlock, 0, S_(stream)>>>(recon, logq, logp, gout3, drecon, dlogq,
+                                                                              dlogp, (int)B, (int)n, use_fb, free_bits,
+                                                                              recon_weight, kl_weight, iwae, weights_dev);
+  MIVAE_CHECK_LAUNCH("latent_tail_bwd");
+  return MIVAE_OK;
+}
+
+// state.offset += 1: one draw taken from the generator (stream ordered, one thread)
+extern "C" int mivae_rng_advance(int64_t* rng_state, void* stream) {
+  MIVAE_REQUIRE(rng_state, "rng_advance: null generator state");
+  k_rng_take<<<1, 64, 0, S_(stream)>>>(rng_state, nullptr);
+  MIVAE_CHECK_LAUNCH("rng_advance");
+  return MIVAE_OK;
 }
 
 // eps ((B n), S, D) fp32 of the draw recorded in rng_used: what the two kernels above used (tests, debugging)

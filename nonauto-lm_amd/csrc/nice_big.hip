@@ -359,7 +359,7 @@ struct BigArgs {
   float mu, inv2var, cst;
   // CHAIN
   const T* dz_out;      // (N, D) or null
-  const float* dlogp;   // (N) per-token cotangent of tok_val, or null
+  const float* dlogp;   // (Bn) cotangent of the per-sentence sum of tok_val (Bn = N / S; S = 1: per token), or null
   T* dz_in;             // (N, D): the x1 half is written by CHAIN, the x0 half by k_big_nets
   T* dSdT;              // (K, 2, N, h): d s_k, d t_k
 };
@@ -545,7 +545,7 @@ __global__ void __launch_bounds__(512) k_big_chain(BigArgs a) {
       const int64_t bn = tok / a.S;
       m = (float)a.mask[(bn / a.mask_div) * a.S + (tok - bn * a.S)];
     }
-    if (MODE == M_CHAIN && a.dlogp) dl = a.dlogp[tok] * m;
+    if (MODE == M_CHAIN && a.dlogp) dl = a.dlogp[tok / a.S] * m;   // one cotangent per sentence (S = 1: per token)
   }
   const bool live = (__any(m != 0.f) != 0) && !(a.dbg & 2);
   if (!block_live(a.mask, a.N, a.S, a.mask_div, lane)) {
@@ -874,7 +874,7 @@ struct NetsArgs {
   const char* stream;   // ST_NETS
   const float* bias;
   const T* dz_out;      // (N, D) or null
-  const float* dlogp;   // (N) or null
+  const float* dlogp;   // (Bn) or null
   const T* dSdT;        // (K, 2, N, h)
   T* dz_in;             // (N, D): x0 half written here
   T* hbuf;              // SAVE: (K, 2, N, Hp) hidden activations, token rows of Hp = 32 HC values
@@ -920,7 +920,7 @@ __global__ void __launch_bounds__(512) k_big_nets(NetsArgs a) {
       const int64_t bn = tok / a.S;
       m = (float)a.mask[(bn / a.mask_div) * a.S + (tok - bn * a.S)];
     }
-    if (a.dlogp) dl = a.dlogp[tok] * m;
+    if (a.dlogp) dl = a.dlogp[tok / a.S] * m;
   }
   const bool live = __any(m != 0.f) != 0;
   if (!block_live(a.mask, a.N, a.S, a.mask_div, lane)) {
@@ -1920,6 +1920,8 @@ extern "C" int64_t mivae_nice_big_hidden_elems(int64_t N, int64_t h, int64_t H, 
 }
 
 // Backward of mivae_nice_big_fwd (forward direction): dz_in (N, D) and the parameter gradients.
+//   dlogp (Bn): cotangent of every sentence's sum of tok_val (as mivae_nice_stack_bwd); per-token cotangents: call with
+//   Bn = N, S = 1 and the mask flattened;
 //   packed_chain / packed_nets / packed_bias: ST_CHAIN / ST_NETS / ST_BIAS images of the same weights;
 //   dSdT: scratch (K, 2, N, h) in the latent dtype; workspace: mivae_nice_big_dw_workspace_floats floats;
 //   hidden: scratch of mivae_nice_big_hidden_elems elements (latent dtype, 16-byte aligned) or NULL.  With it the nets

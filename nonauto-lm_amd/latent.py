@@ -91,6 +91,11 @@ class DefaultPrior(Prior):
     def masked_log_prob(self, latent, mask, size_average: bool = False):
         return ops.gauss_logprob(latent, mask, float(self.mu), float(self.std))
 
+    def token_log_prob(self, posterior_sample: LatentSample, mask: Optional[torch.Tensor] = None):
+        """log_probability() before its per-sentence reduction: ((B n), S) fp32, or None when this prior has no
+        per-token form (the ELBO tail kernel takes the per-token values and reduces them itself)."""
+        return ops.gauss_logprob_tok(posterior_sample.z, mask, float(self.mu), float(self.std))
+
 
 @Prior.register("flow")
 class FlowPrior(DefaultPrior):
@@ -115,6 +120,15 @@ class FlowPrior(DefaultPrior):
 
     def log_probability(self, posterior_sample: LatentSample, mask: Optional[torch.Tensor] = None):
         return self.forward_pass(posterior_sample.z, mask)[1]
+
+    def token_log_prob(self, posterior_sample: LatentSample, mask: Optional[torch.Tensor] = None):
+        z0 = posterior_sample.z
+        spec = fused_stack_spec(self._flows, z0) if self.allow_fused else None
+        if spec is None or not (mask is not None or z0.dim() == 2):
+            return None                     # flow lists the fused stack does not take: per-sentence path
+        params, H, act = spec
+        return ops.nice_stack_tok(z0, mask, params, H, act, inverse=False, base=True, mu=float(self.mu),
+                                  std=float(self.std))[1]
 
     def forward_pass(self, z0, mask=None):
         spec = fused_stack_spec(self._flows, z0) if self.allow_fused else None
@@ -172,6 +186,7 @@ class Posterior(torch.nn.Module, Registrable):
             torch.nn.Hardtanh(min_val=1e-4, max_val=5.0))
         self._mu = None
         self._sigma = None
+        self.rng_pending = False     # an in-kernel draw whose generator step was left to the caller (sample_tokens)
 
     @property
     def base_dist(self):
@@ -186,23 +201,34 @@ class Posterior(torch.nn.Module, Registrable):
         lead = (mu.size(0), self.samples) + tuple(mu.shape[1:])
         return torch.randn(lead, device=mu.device, dtype=mu.dtype)
 
-    def sample_and_log_prob(self, encoded, mask, random=True, eps=None):
+    def sample_tokens(self, encoded, mask, random=True, eps=None, defer_rng: bool = False):
+        """(z ((B n), ...), repeated mask, per-token log q ((B n), S)): a3 + a4 + a5 as two launches -- the grouped
+        mu | sigma heads, then ONE kernel for the sigma head's Hardtanh(Softplus(.)), the reparameterised sample, the
+        mask multiply and the per-token log q (posterior.py:19-27, 86-172); the noise is injected (`eps`), drawn inside
+        that kernel (Philox) or absent (`random=False`).  defer_rng: with in-kernel noise, leave the generator's step to the
+        caller (`self.rng_pending` says whether one is due: ops.latent_tail(..., rng_advance=True) or ops.rng_advance)."""
         # a3: the two heads share `encoded` -> one grouped launch forward, one for the input gradient
         mu, pre = linear_group(encoded, [self._mu_net, self._sigma_net[0]])
         self._mu = mu
         sp, ht = self._sigma_net[1], self._sigma_net[2]
-        if (pre.is_cuda and pre.dtype in (torch.float32, torch.bfloat16) and isinstance(sp, torch.nn.Softplus)
-                and sp.beta == 1 and sp.threshold == 20 and isinstance(ht, torch.nn.Hardtanh)):
-            self._sigma = ops.sigma_head(pre, ht.min_val, ht.max_val)      # one launch; sigma in the latent dtype
+        fused_head = (pre.is_cuda and pre.dtype in (torch.float32, torch.bfloat16) and isinstance(sp, torch.nn.Softplus)
+                      and sp.beta == 1 and sp.threshold == 20 and isinstance(ht, torch.nn.Hardtanh))
+        if random and eps is None and not ops.PHILOX:
+            eps = self._draw(mu, random, None)
+        rng = bool(random and eps is None)
+        self.rng_pending = rng and defer_rng
+        if fused_head:
+            z, self._sigma, tok = ops.posterior_tok(mu, pre, eps, mask, self.samples, True, ht.min_val, ht.max_val, rng,
+                                                    advance=not defer_rng)
         else:
-            self._sigma = ht(sp(pre))
-        if random and eps is None and ops.PHILOX:        # eps drawn inside the kernel (Philox): no randn launch
-            z, log_prob = ops.reparam_logq_rng(self._mu, self._sigma, mask, self.samples)
-        else:                                            # injected eps (parity runs) / random=False
-            noise = self._draw(self._mu, random, eps)
-            z, log_prob = ops.reparam_logq(self._mu, self._sigma, noise, mask, self.samples)
+            z, self._sigma, tok = ops.posterior_tok(mu, ht(sp(pre)), eps, mask, self.samples, False, rng=rng,
+                                                    advance=not defer_rng)
         rep_mask = mask if mask is None or self.samples == 1 else mask.repeat_interleave(self.samples, dim=0)
-        return z, rep_mask, log_prob
+        return z, rep_mask, tok
+
+    def sample_and_log_prob(self, encoded, mask, random=True, eps=None):
+        z, rep_mask, tok = self.sample_tokens(encoded, mask, random, eps)
+        return z, rep_mask, ops._SegmentSum.apply(tok, tok.size(0), tok.size(1))
 
     def calc_mutual_info(self, z, log_prob, mask=None):
         """I(x, z) estimator (posterior.py:174-222).  On the GPU the (B n)^2 pairwise log-densities come from one tiled

@@ -11,7 +11,7 @@ from typing import Dict, Iterable, List, Optional
 import torch
 
 from . import ops
-from .latent import KLLoss, LatentSample, Posterior, PosteriorSample, Prior, PriorSample
+from .latent import DefaultKLLoss, KLLoss, LatentSample, Posterior, PosteriorSample, Prior, PriorSample
 from .nn_bracket import Decoder, Embedder, Encoder, EncoderOutput, LabelSmoothingNLL
 from .registrable import Registrable
 
@@ -103,7 +103,22 @@ class VAELmModel(torch.nn.Module, Registrable):
         batch = src_tokens.size(0)
         n = self.nsamples_posterior
         encoded = self.encode(src_tokens)
-        latent, posterior_log_prob = self.sample_from_posterior(encoded, random=random, eps=eps)
+        # Launch-count pass over the latent path: with the default KL the per-sentence reductions of log q / log p, the
+        # KL and the ELBO tail are ONE kernel each way (ops.latent_tail) fed by the per-token values of the posterior
+        # and prior kernels; any other combination takes the module-by-module route below.  Same arithmetic, same order.
+        tok_logq = None
+        if (tgt_tokens is not None and type(self._kl_loss) is DefaultKLLoss and src_tokens.is_cuda
+                and hasattr(self._posterior, "sample_tokens")):
+            x_post, m_post = self._posterior_inputs(encoded)
+            tail_ok = ops.latent_tail_supported(batch, n, x_post.size(1) if x_post.dim() == 3 else 1)
+            # the generator's step after an in-kernel draw rides in the ELBO tail kernel (no launch of its own)
+            z, _, tok_logq = self._posterior.sample_tokens(x_post, m_post, random=random, eps=eps, defer_rng=tail_ok)
+            latent, posterior_log_prob = LatentSample(z, self._posterior._mu, self._posterior._sigma), None
+            if not tail_ok:
+                posterior_log_prob = ops._SegmentSum.apply(tok_logq, tok_logq.size(0), tok_logq.size(1))
+                tok_logq = None
+        else:
+            latent, posterior_log_prob = self.sample_from_posterior(encoded, random=random, eps=eps)
         tgt_mask = None
         if tgt_tokens is not None:
             # the usual call reconstructs the source: one mask kernel, and no repeat copies for a single sample
@@ -113,18 +128,32 @@ class VAELmModel(torch.nn.Module, Registrable):
                 tgt_tokens = tgt_tokens.repeat_interleave(n, dim=0)
         decoded = {k: v.view(batch, n, *v.shape[1:])
                    for k, v in self.decode(latent.z, tgt_mask, target=tgt_tokens).items()}
-        prior_log_prob = self._get_prior_log_prob(latent, tgt_mask)
+        tok_logp = None
+        if tok_logq is not None:
+            tok_logp = self._prior_token_log_prob(latent, tgt_mask)
+            if tok_logp is None:            # a prior without a per-token form: reduce log q now, go module by module
+                posterior_log_prob = ops._SegmentSum.apply(tok_logq, tok_logq.size(0), tok_logq.size(1))
+                if self._posterior.rng_pending:
+                    ops.rng_advance(tok_logq.device)
+        if tok_logp is None:
+            prior_log_prob = self._get_prior_log_prob(latent, tgt_mask)
         if tgt_tokens is None:
             return {"source": src_tokens, "latent": latent.z, **decoded}
         recon_error = decoded.pop("loss")                                  # (B, n)
-        kl_out = {f"batch-{k}": v.view(batch, n)
-                  for k, v in self._kl_loss(posterior_log_prob, prior_log_prob, latent=latent.z).items()}
-        kl_loss = kl_out.pop("batch-loss")
         w_r, w_kl = self._recon_scheduler.weight, self._kl_scheduler.weight
         # device_weights (set by step.TrainStep): the two weights live in device memory, written by the host before
         # every step, so that a HIP-graph replay of this forward does not freeze them at their capture-time values
-        batch_loss, batch_kl, batch_nll = ops.elbo_tail(recon_error, kl_loss, batch, n, w_r, w_kl, self._iwae,
-                                                        weights_dev=self.device_weights)
+        if tok_logp is not None:
+            kl_out = {}
+            (batch_loss, batch_kl, batch_nll), _ = ops.latent_tail(
+                tok_logq, tok_logp, recon_error, batch, n, self._kl_loss._free_bits_alpha, w_r, w_kl, self._iwae,
+                weights_dev=self.device_weights, rng_advance=self._posterior.rng_pending)
+        else:
+            kl_out = {f"batch-{k}": v.view(batch, n)
+                      for k, v in self._kl_loss(posterior_log_prob, prior_log_prob, latent=latent.z).items()}
+            kl_loss = kl_out.pop("batch-loss")
+            batch_loss, batch_kl, batch_nll = ops.elbo_tail(recon_error, kl_loss, batch, n, w_r, w_kl, self._iwae,
+                                                            weights_dev=self.device_weights)
         if not manual_kl_step and self.training:
             self.kl_scheduler_step()
         if self.training:
@@ -220,6 +249,13 @@ class NonAutoModel(VAELmModel):
 
     def _get_prior_log_prob(self, z: LatentSample, mask=None):
         return self._prior.log_probability(z, mask)
+
+    def _posterior_inputs(self, encoded: EncoderOutput):
+        return encoded.output, encoded.mask
+
+    def _prior_token_log_prob(self, z: LatentSample, mask=None):
+        fn = getattr(self._prior, "token_log_prob", None)
+        return None if fn is None else fn(z, mask)
 
     def calc_mutual_info(self, src_tokens, random: bool = True):
         encoded = self.encode(src_tokens)

@@ -333,6 +333,14 @@ def philox_state(device) -> torch.Tensor:
     return ent["state"]
 
 
+def _philox_peek(device) -> torch.Tensor:
+    """the device generator state without the host-side bookkeeping of philox_state() (same tensor)"""
+    device = torch.device(device)
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    ent = _PHILOX_STATE.get(key)
+    return ent["state"] if ent is not None else philox_state(device)
+
+
 class _ReparamLogQRng(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mu, sigma, mask, n):
@@ -360,6 +368,82 @@ class _ReparamLogQRng(torch.autograd.Function):
         L.call("mivae_reparam_logq_bwd_rng", L.ptr(dz), L.ptr(dlogq), L.ptr(sg), L.ptr(used), L.ptr(mask),
                L.ptr(dmu), L.ptr(dsg), B, n, S, D, L.dtype_code(sg.dtype), L.stream())
         return dmu, dsg.to(ctx.sigma_dtype), None, None
+
+
+def _tok_cotangent(dtok, Bn: int, S: int):
+    """(tensor, per_token flag) for the kernels from the cotangent of a (Bn, S) per-token output.  The ELBO tail's
+    backward hands back ONE value per sentence as an expanded (stride-0) view; the kernels index it per sentence, so no
+    (Bn, S) copy is made.  Anything else is a genuine per-token cotangent."""
+    if dtok is None:
+        return None, False
+    if (dtok.dim() == 2 and dtok.shape == (Bn, S) and dtok.dtype == torch.float32
+            and (S == 1 or dtok.stride(1) == 0) and (Bn == 1 or dtok.stride(0) == 1)):
+        return dtok[:, 0], False
+    return dtok.contiguous().float().reshape(-1), True
+
+
+class _PosteriorTok(torch.autograd.Function):
+    """mivae_posterior_fwd / _bwd: (mu, sigma or the sigma head's pre-activation) -> (z, sigma, per-token log q (Bn, S)),
+    noise injected (eps), drawn in-kernel (rng) or absent; ONE launch each way."""
+
+    @staticmethod
+    def forward(ctx, mu, sg, eps, mask, n, is_pre, lo, hi, rng, advance):
+        B, S, D = _shape3(mu)
+        mu_c, sg_c = mu.contiguous(), sg.contiguous().to(mu.dtype)
+        eps_c = None if eps is None else eps.contiguous().to(mu.dtype)
+        ctx.sg_dtype = sg.dtype
+        z = torch.empty((B * n, *mu.shape[1:]), dtype=mu.dtype, device=mu.device)
+        sigma = torch.empty_like(mu_c) if is_pre else sg_c
+        tok = torch.empty(B * n, S, dtype=torch.float32, device=mu.device)
+        used = state = None
+        if rng and eps_c is None:
+            used = torch.empty(2, dtype=torch.int64, device=mu.device)
+            state = philox_state(mu.device)
+        L.call("mivae_posterior_fwd", L.ptr(mu_c), L.ptr(sg_c), int(is_pre), lo, hi, L.ptr(eps_c), L.ptr(state), L.ptr(used),
+               L.ptr(mask), L.ptr(z), L.ptr(sigma) if is_pre else None, L.ptr(tok), B, n, S, D, L.dtype_code(mu.dtype),
+               L.stream())
+        if state is not None and advance:   # the draw is taken now; advance = False: the ELBO tail of this forward does it
+            L.call("mivae_rng_advance", L.ptr(state), L.stream())
+        ctx.save_for_backward(sg_c, eps_c, used, mask)
+        ctx.meta = (B, n, S, D, int(is_pre), lo, hi)
+        return z, sigma, tok
+
+    @staticmethod
+    def backward(ctx, dz, dsigma_up, dtok):
+        sg, eps, used, mask = ctx.saved_tensors
+        B, n, S, D, is_pre, lo, hi = ctx.meta
+        dz = None if dz is None else dz.contiguous().to(sg.dtype)
+        dq, per_tok = _tok_cotangent(dtok, B * n, S)
+        dmu = torch.empty_like(sg)
+        dsg = torch.empty_like(sg)
+        L.call("mivae_posterior_bwd", L.ptr(dz), L.ptr(dq), int(per_tok), L.ptr(sg), is_pre, lo, hi, L.ptr(eps), L.ptr(used),
+               L.ptr(mask), L.ptr(dmu), L.ptr(dsg), B, n, S, D, L.dtype_code(sg.dtype), L.stream())
+        if dsigma_up is not None:           # someone differentiates through the returned sigma itself (not the ELBO path)
+            if is_pre:
+                extra = torch.empty_like(sg)
+                L.call("mivae_sigma_head_bwd", L.ptr(sg), L.ptr(dsigma_up.contiguous().to(sg.dtype)), L.ptr(extra),
+                       sg.numel(), lo, hi, L.dtype_code(sg.dtype), L.stream())
+                dsg = dsg + extra
+            else:
+                dsg = dsg + dsigma_up.to(sg.dtype)
+        return dmu, dsg.to(ctx.sg_dtype), None, None, None, None, None, None, None, None
+
+
+def posterior_tok(mu, sigma_or_pre, eps, mask, samples: int, is_pre: bool = False, lo: float = 1e-4, hi: float = 5.0,
+                  rng: bool = False, advance: bool = True):
+    """a3 tail + a4 + a5 (posterior.py:23-27, 86-172) in one launch: returns (z ((B n), ...), sigma (B, ...), per-token
+    log q ((B n), S)).  `sigma_or_pre` is sigma, or (is_pre) the sigma head's pre-activation; noise = `eps` if given, else
+    drawn inside the kernel when `rng`, else zero.  With `rng` the generator state moves on by one draw right after the
+    kernel (one single-thread launch); `advance=False` leaves that to the caller -- latent_tail(..., rng_advance=True)
+    of the same forward does it inside the ELBO tail kernel, rng_advance() by itself."""
+    L.require_gpu(mu, sigma_or_pre, eps, mask)
+    return _PosteriorTok.apply(mu, sigma_or_pre, eps, _mask_i64(mask), int(samples), bool(is_pre), float(lo), float(hi),
+                               bool(rng), bool(advance))
+
+
+def rng_advance(device) -> None:
+    """one draw taken from the in-kernel noise generator of `device` (see posterior_tok(advance=False))"""
+    L.call("mivae_rng_advance", L.ptr(_philox_peek(device)), L.stream())
 
 
 class _SigmaHead(torch.autograd.Function):
@@ -412,31 +496,46 @@ def reparam_logq(mu, sigma, eps, mask, samples: int):
 
 # ----------------------------------------------------------------------------------- base log-prob
 class _GaussLogProb(torch.autograd.Function):
+    """per-token base log-prob (Bn, S); the cotangent comes back per sentence (expanded view) or per token"""
+
     @staticmethod
     def forward(ctx, z, mask, mask_div, mu, std):
         Bn, S, D = _shape3(z)
         z = z.contiguous()
-        tok = torch.empty(Bn * S, dtype=torch.float32, device=z.device)
+        tok = torch.empty(Bn, S, dtype=torch.float32, device=z.device)
         L.call("mivae_gauss_logprob_fwd", L.ptr(z), L.ptr(mask), L.ptr(tok), Bn, mask_div, S, D,
                float(mu), float(std), L.dtype_code(z.dtype), L.stream())
         ctx.save_for_backward(z, mask)
         ctx.meta = (Bn, S, D, mask_div, float(mu), float(std))
-        return segment_sum(tok, Bn, S)
+        return tok
 
     @staticmethod
-    def backward(ctx, dlogp):
+    def backward(ctx, dtok):
         z, mask = ctx.saved_tensors
         Bn, S, D, mask_div, mu, std = ctx.meta
         dz = torch.empty_like(z)
-        L.call("mivae_gauss_logprob_bwd", L.ptr(z), L.ptr(mask), L.ptr(dlogp.contiguous().float()),
-               L.ptr(dz), Bn, mask_div, S, D, mu, std, L.dtype_code(z.dtype), L.stream())
+        dl, per_tok = _tok_cotangent(dtok, Bn, S)
+        if per_tok:       # one "sentence" per token: the mask is indexed per token (un-repeated masks are expanded first)
+            if mask is not None and mask_div != 1:
+                mask = mask.repeat_interleave(mask_div, dim=0).contiguous()
+            L.call("mivae_gauss_logprob_bwd", L.ptr(z), L.ptr(mask), L.ptr(dl), L.ptr(dz), Bn * S, 1, 1, D, mu, std,
+                   L.dtype_code(z.dtype), L.stream())
+        else:
+            L.call("mivae_gauss_logprob_bwd", L.ptr(z), L.ptr(mask), L.ptr(dl.contiguous()), L.ptr(dz), Bn, mask_div, S, D,
+                   mu, std, L.dtype_code(z.dtype), L.stream())
         return dz, None, None, None, None
+
+
+def gauss_logprob_tok(z, mask, mu: float, std: float, mask_div: int = 1):
+    """a15 per token: Normal(mu, std).log_prob(z) summed over the features, times the mask -> (Bn, S) fp32."""
+    L.require_gpu(z, mask)
+    return _GaussLogProb.apply(z, _mask_i64(mask), mask_div, mu, std)
 
 
 def gauss_logprob(z, mask, mu: float, std: float, mask_div: int = 1):
     """a15: sum over all but batch of Normal(mu, std).log_prob(z) * mask  (priors/prior.py:148-158)."""
-    L.require_gpu(z, mask)
-    return _GaussLogProb.apply(z, _mask_i64(mask), mask_div, mu, std)
+    Bn, S, _ = _shape3(z)
+    return _SegmentSum.apply(gauss_logprob_tok(z, mask, mu, std, mask_div), Bn, S)
 
 
 # ----------------------------------------------------------------------------------- NICE affine tail
@@ -638,13 +737,14 @@ def maf_sequential(z, packed, mask, activation: str, parity: bool, params=None):
 class _SegmentSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tok, nseg, S):
-        ctx.meta = (nseg, S)
+        ctx.meta = (nseg, S, tok.dim())
         return segment_sum(tok.contiguous(), nseg, S)
 
     @staticmethod
     def backward(ctx, g):
-        nseg, S = ctx.meta
-        return g.reshape(nseg, 1).expand(nseg, S).reshape(-1), None, None
+        nseg, S, dim = ctx.meta
+        ge = g.contiguous().reshape(nseg, 1).expand(nseg, S)   # stride-0 view: the producing kernel indexes it per sentence
+        return (ge if dim == 2 else ge.reshape(-1)), None, None
 
 
 # ----------------------------------------------------------------------------------- ActNorm
@@ -1541,6 +1641,63 @@ def elbo_tail(recon, kl, batch: int, samples: int, recon_weight: float, kl_weigh
     return out[0], out[1], out[2]
 
 
+class _LatentTail(torch.autograd.Function):
+    """mivae_latent_tail_fwd / _bwd: per-token log q, log p + per-sentence reconstruction error -> {batch-loss, batch-kl,
+    batch-nll} and (non-differentiable) per-sentence log q, log p, kl."""
+
+    @staticmethod
+    def forward(ctx, tok_q, tok_p, recon, B, n, fb, wr, wk, iwae, wdev, rng_state):
+        Bn, S = tok_q.shape
+        tq, tp, r = tok_q.contiguous(), tok_p.contiguous(), recon.contiguous().float()
+        dev = tq.device
+        out = torch.empty(3, dtype=torch.float32, device=dev)
+        stats = torch.empty(3, Bn, dtype=torch.float32, device=dev)      # log q, log p, kl
+        use = fb is not None
+        L.call("mivae_latent_tail_fwd", L.ptr(tq), L.ptr(tp), L.ptr(r), L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(stats[2]),
+               L.ptr(out), B, n, S, int(use), float(fb) if use else 0.0, float(wr), float(wk), int(iwae), L.ptr(wdev),
+               L.ptr(rng_state), L.stream())
+        ctx.save_for_backward(r, stats)
+        ctx.wdev = wdev
+        ctx.meta = (B, n, S, fb, float(wr), float(wk), int(iwae))
+        ctx.mark_non_differentiable(stats)
+        return out, stats
+
+    @staticmethod
+    def backward(ctx, g, _gstats):
+        r, stats = ctx.saved_tensors
+        B, n, S, fb, wr, wk, iwae = ctx.meta
+        Bn = B * n
+        d = torch.empty(3, Bn, dtype=torch.float32, device=r.device)     # d recon, d log q, d log p
+        use = fb is not None
+        L.call("mivae_latent_tail_bwd", L.ptr(r), L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(g.contiguous().float()),
+               L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]), B, n, int(use), float(fb) if use else 0.0, wr, wk, iwae,
+               L.ptr(ctx.wdev), L.stream())
+        # per-sentence cotangents of the per-token inputs as expanded views: the producers' kernels index them per sentence
+        return (d[1].view(Bn, 1).expand(Bn, S), d[2].view(Bn, 1).expand(Bn, S), d[0], None, None, None, None, None,
+                None, None, None)
+
+
+def latent_tail_supported(batch: int, samples: int, S: int) -> bool:
+    return bool(L.query("mivae_latent_tail_supported", int(batch), int(samples), int(S)))
+
+
+def latent_tail(tok_logq, tok_logp, recon, batch: int, samples: int, free_bits: Optional[float], recon_weight: float,
+                kl_weight: float, iwae: bool, weights_dev: Optional[torch.Tensor] = None, rng_advance: bool = False):
+    """The reductions of a5 / a15, a16 and a17 in one launch each way: per-token log q and log p ((B n), S) + the
+    reconstruction error (B n) -> ((batch-loss, batch-kl, batch-nll), (log q, log p, kl) per sentence).
+    posterior.py:157-172, priors/prior.py:148-158, nn/kl_loss.py:38-49, models/base/model.py:171-193.
+    rng_advance: also take the draw a posterior_tok(..., rng=True, advance=False) of this forward left pending."""
+    L.require_gpu(tok_logq, tok_logp, recon)
+    if tok_logq.shape != tok_logp.shape or tok_logq.dim() != 2 or tok_logq.size(0) != batch * samples:
+        raise ValueError("latent_tail: per-token log q / log p must both be ((B n), S)")
+    if tok_logq.dtype != torch.float32 or tok_logp.dtype != torch.float32:
+        raise TypeError("latent_tail: per-token values are fp32")
+    state = _philox_peek(tok_logq.device) if rng_advance else None     # the posterior's deferred generator step
+    out, stats = _LatentTail.apply(tok_logq, tok_logp, recon.reshape(-1), int(batch), int(samples), free_bits,
+                                   recon_weight, kl_weight, iwae, weights_dev, state)
+    return (out[0], out[1], out[2]), (stats[0], stats[1], stats[2])
+
+
 # ----------------------------------------------------------------------------------- reconstruction NLL
 class _NLL(torch.autograd.Function):
     @staticmethod
@@ -1741,7 +1898,7 @@ class _NiceStack(torch.autograd.Function):
         N = Bn * S
         z_out = torch.empty_like(z)
         hist = torch.empty(K, N, h, dtype=z.dtype, device=z.device) if need_grad else None
-        tok = torch.empty(N, dtype=torch.float32, device=z.device)
+        tok = torch.empty(Bn, S, dtype=torch.float32, device=z.device)
         with _timed("nice_stack_inv" if inverse else "nice_stack_fwd"):
             L.call("mivae_nice_stack_fwd", L.ptr(z), L.ptr(z_out), L.ptr(hist), L.ptr(mask), L.ptr(packed),
                    L.ptr(tok), Bn, 1, S, D, H, K, act, int(inverse), int(base), float(mu), float(std), code,
@@ -1766,13 +1923,14 @@ class _NiceStack(torch.autograd.Function):
         dSt = torch.empty(K, 2, hp, npad, dtype=dt, device=z.device)
         x0t = torch.empty(hp, npad, dtype=dt, device=z.device)
         dz_in = torch.empty_like(z)
-        # The kernel takes the per-token cotangent through `dlogp` with S = 1 segments: the
-        # per-sentence broadcast has already been applied by _SegmentSum.backward.
-        dlog = None if dtok is None else dtok.contiguous().float()
+        # `dlogp` is one cotangent per sentence (the expanded view _SegmentSum / the ELBO tail hand back), or -- a genuine
+        # per-token cotangent -- one per token with S = 1 segments
+        dlog, per_tok = _tok_cotangent(dtok, Bn, S)
+        seg = (N, 1, 1) if per_tok else (Bn, 1, S)
         dzo = None if dz_out is None else dz_out.contiguous()
         with _timed("nice_stack_bwd"):
             L.call("mivae_nice_stack_bwd", L.ptr(z), L.ptr(z_out), L.ptr(hist), L.ptr(mask), L.ptr(packed),
-                   L.ptr(dzo), L.ptr(dlog), L.ptr(dz_in), L.ptr(Gt), L.ptr(Ht), L.ptr(dSt), L.ptr(x0t), N, 1, 1,
+                   L.ptr(dzo), L.ptr(dlog), L.ptr(dz_in), L.ptr(Gt), L.ptr(Ht), L.ptr(dSt), L.ptr(x0t), *seg,
                    D, H, K, act, base, mu, std, code, L.stream())
         # Weight gradients: split-K NT MFMA products over the token axis on the emitted
         # [feature][token] tensors, reduced in fixed order (k_dw_partial / k_dw_reduce).
@@ -1861,7 +2019,7 @@ class _NiceStackBig(torch.autograd.Function):
         pk, pb = packed[kinds[0]], packed["bias"]
         z_out = torch.empty_like(z)
         hist = torch.empty(K, N, h, dtype=z.dtype, device=z.device) if need_grad else None
-        tok = torch.empty(N, dtype=torch.float32, device=z.device)
+        tok = torch.empty(Bn, S, dtype=torch.float32, device=z.device)
         with _timed("nice_stack_inv" if inverse else "nice_stack_fwd"):
             L.call("mivae_nice_big_fwd", L.ptr(z), L.ptr(z_out), L.ptr(hist), L.ptr(mask), L.ptr(pk), L.ptr(pb),
                    L.ptr(tok), Bn, 1, S, D, H, K, act, int(inverse), int(base), float(mu), float(std), L.stream())
@@ -1884,7 +2042,8 @@ class _NiceStackBig(torch.autograd.Function):
         # hidden activations + d pre of every (step, net, token), saved by the nets launch for the weight gradients
         hid = torch.empty(L.query("mivae_nice_big_hidden_elems", N, h, H, K), dtype=z.dtype, device=dev) \
             if _nice_big_save_hidden(h) else None
-        dlog = None if dtok is None else dtok.contiguous().float()
+        dlog, per_tok = _tok_cotangent(dtok, Bn, S)
+        seg = (N, 1, 1) if per_tok else (Bn, 1, S)       # per-token cotangents: one "sentence" per token
         dzo = None if dz_out is None else dz_out.contiguous()
         sink = grad_sink_ok(*params) and all(ctx.needs_input_grad[8:])
         if sink:
@@ -1900,7 +2059,7 @@ class _NiceStackBig(torch.autograd.Function):
             L.call("mivae_nice_big_bwd", L.ptr(z), L.ptr(z_out), L.ptr(hist), L.ptr(mask), L.ptr(_ptr_table(params, dev)),
                    L.ptr(pc), L.ptr(pn), L.ptr(pb),
                    L.ptr(dzo), L.ptr(dlog), L.ptr(dz_in), L.ptr(dsdt), L.ptr(hid), L.ptr(ws), L.ptr(dW1), L.ptr(db1), L.ptr(dW2),
-                   L.ptr(db2), L.ptr(table), Bn, 1, S, D, H, K, act, base, mu, std, L.stream())
+                   L.ptr(db2), L.ptr(table), *seg, D, H, K, act, base, mu, std, L.stream())
         if sink:
             sink_arrived(*[p.grad for p in params])
             return (dz_in, None, None, None, None, None, None, None, *([None] * len(params)))
@@ -1919,14 +2078,21 @@ def nice_stack(z, mask, params: Sequence[torch.Tensor], H: int, activation: str,
     L.require_gpu(z, mask, *params)
     mask = _mask_i64(mask)
     Bn, S, D = _shape3(z)
-    fn = _NiceStackBig if nice_big_supported(z, H) else _NiceStack
-    z_out, tok = fn.apply(z, mask, int(H), ACT_IDS[activation], bool(inverse), bool(base), float(mu), float(std),
-                          *params)
+    z_out, tok = nice_stack_tok(z, mask, params, H, activation, inverse, base, mu, std)
     if z.dim() == 2:
-        return z_out, tok
+        return z_out, tok.view(Bn)
     if mask is None and not base:
-        return z_out, tok.view(Bn, S)
+        return z_out, tok
     return z_out, _SegmentSum.apply(tok, Bn, S)
+
+
+def nice_stack_tok(z, mask, params: Sequence[torch.Tensor], H: int, activation: str, inverse: bool = False,
+                   base: bool = False, mu: float = 0.0, std: float = 1.0):
+    """nice_stack without the per-sentence reduction: (z_K, per-token value (Bn, S) fp32)."""
+    L.require_gpu(z, mask, *params)
+    mask = _mask_i64(mask)
+    fn = _NiceStackBig if nice_big_supported(z, H) else _NiceStack
+    return fn.apply(z, mask, int(H), ACT_IDS[activation], bool(inverse), bool(base), float(mu), float(std), *params)
 
 
 # ----------------------------------------------------------------------------------- mixed flow stack (no grad)
