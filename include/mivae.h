@@ -346,7 +346,8 @@ int mivae_elbo_bwd(const float* recon, const float* kl, const float* gout3, floa
 /* The per-sentence reductions of log q / log p (posterior.py:157-172, priors/prior.py:148-158: sums of the per-token
  * values), DefaultKLLoss (nn/kl_loss.py:38-49) and the ELBO tail (models/base/model.py:171-193) in ONE launch each way:
  * tok_logq, tok_logp ((B n), S) fp32, recon (B n) -> logq, logp, kl (B n) and out3 = {batch-loss, batch-kl, batch-nll};
- * the backward turns gout3 into d recon, d log q, d log p per sentence.  rng_state (or NULL): a generator state whose
+ * the backward turns the cotangents of the three scalars (one device float each, NULL = zero) into d recon, d log q,
+ * d log p per sentence.  rng_state (or NULL): a generator state whose
  * offset the forward advances by one (see mivae_posterior_fwd).  One block: B n <= 16384, (B n) S <= 2^21
  * (mivae_latent_tail_supported); larger shapes use mivae_segment_sum + mivae_kl_* + mivae_elbo_*. */
 int mivae_latent_tail_supported(int64_t B, int64_t n, int64_t S);
@@ -354,9 +355,10 @@ int mivae_latent_tail_fwd(const float* tok_logq, const float* tok_logp, const fl
                           float* kl, float* out3, int64_t B, int64_t n, int64_t S, int use_free_bits, float free_bits,
                           float recon_weight, float kl_weight, int iwae, const float* weights_dev, int64_t* rng_state,
                           void* stream);
-int mivae_latent_tail_bwd(const float* recon, const float* logq, const float* logp, const float* gout3, float* drecon,
-                          float* dlogq, float* dlogp, int64_t B, int64_t n, int use_free_bits, float free_bits,
-                          float recon_weight, float kl_weight, int iwae, const float* weights_dev, void* stream);
+int mivae_latent_tail_bwd(const float* recon, const float* logq, const float* logp, const float* g_loss, const float* g_kl,
+                          const float* g_nll, float* drecon, float* dlogq, float* dlogp, int64_t B, int64_t n,
+                          int use_free_bits, float free_bits, float recon_weight, float kl_weight, int iwae,
+                          const float* weights_dev, void* stream);
 
 /* ---- reconstruction term: label-smoothing NLL over the vocabulary ------------------------------ */
 /* per_seq[b] = sum_s w[b,s] * nll[b,s] / clamp(sum_s w[b,s], 1e-13) with
@@ -526,6 +528,9 @@ int mivae_adam_clip_step(float* p, void* p_bf16, float* g, float* m, float* v, c
                          double beta2, float eps, float weight_decay, float max_norm, float max_value,
                          float grad_scale, void* stream);
 int mivae_scalar_add(float* x, float delta, void* stream);
+/* *dst[i] += (src[i] ? *src[i] : inc[i]) for n <= 4 device scalars in one launch (host arrays of device pointers): the
+ * running metric sums of models/base/model.py:200-210 and the optimizer's step counter inside a replayed graph. */
+int mivae_accumulate_scalars(float* const* dst, const float* const* src, const float* inc, int64_t n, void* stream);
 /* Measurement aid, no counterpart in the reference: dst[0:bytes] = src[0:bytes] as a plain streaming copy (16 bytes per
  * lane).  bench.py times it on 256 MiB to report the HBM bandwidth this box reaches beside the datasheet peak
  * (both denominators).  bytes % 16 == 0, 16-byte aligned buffers.  mode bit 0: non-temporal loads / stores;

@@ -60,7 +60,7 @@ SIGNATURES = {
     "mivae_latent_tail_supported": [I64, I64, I64],
     "mivae_latent_tail_fwd": [P, P, P, P, P, P, P, I64, I64, I64, I32, F32, F32, F32, I32, P, P, P],
     "mivae_rng_advance": [P, P],
-    "mivae_latent_tail_bwd": [P, P, P, P, P, P, P, I64, I64, I32, F32, F32, F32, I32, P, P],
+    "mivae_latent_tail_bwd": [P, P, P, P, P, P, P, P, P, I64, I64, I32, F32, F32, F32, I32, P, P],
     "mivae_maf_sequential_bwd": [P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I32, I32, I32, P],
     "mivae_maf_sequential_bwd_supported": [I64, I64],
     "mivae_maf_sequential_bwd_blocks": [I64],
@@ -116,6 +116,7 @@ SIGNATURES = {
     "mivae_sumsq_partial": [P, P, I64, P],
     "mivae_adam_clip_step": [P, P, P, P, P, P, I64, P, P, I64, F64, F64, F64, F32, F32, F32, F32, F32, P],
     "mivae_scalar_add": [P, F32, P],
+    "mivae_accumulate_scalars": [P, P, P, I64, P],
     "mivae_hbm_copy": [P, P, I64, I32, P],
     "mivae_nice_pack_bytes": [I64, I64, I32],
     "mivae_nice_pack": [P, P, I64, I64, I64, I32, I32, P],

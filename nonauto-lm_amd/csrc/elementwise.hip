@@ -987,19 +987,60 @@ __global__ void __launch_bounds__(1024) k_tail_fwd(const float* __restrict__ tok
   __shared__ float red[8];
   const int Bn = B * n;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-  for (int bn = wave; bn < Bn; bn += nw) {
-    float aq = 0.f, ap = 0.f;
-    for (int s = lane; s < S; s += 64) {
-      aq += tok_q[(int64_t)bn * S + s];
-      ap += tok_p[(int64_t)bn * S + s];
+  // four sentences of a wave in flight at a time (eight independent load streams): the single block is latency bound
+  for (int bn0 = 4 * wave; bn0 < Bn; bn0 += 4 * nw) {
+    float aq[4] = {0.f, 0.f, 0.f, 0.f}, ap[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < S; s0 += 64) {
+      // unconditional loads from clamped addresses (all eight in flight), the out-of-range ones masked afterwards: a
+      // load under a branch is followed by its own wait, and eight serialised round trips per iteration made this
+      // single-block kernel take 13 us
+      const int s = s0 + lane, sc = s < S ? s : S - 1;
+      float vq[4], vp[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t row = bn0 + u < Bn ? bn0 + u : Bn - 1;
+        vq[u] = tok_q[row * S + sc];
+        vp[u] = tok_p[row * S + sc];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        aq[u] += s < S ? vq[u] : 0.f;
+        ap[u] += s < S ? vp[u] : 0.f;
+      }
     }
-    aq = group_sum(aq, 64);
-    ap = group_sum(ap, 64);
-    if (lane == 0) {
-      float v = aq - ap;
-      if (use_fb) v = v < fb ? fb : v;
-      logq[bn] = aq; logp[bn] = ap; kl_out[bn] = v;
-      s_kl[bn] = v;
+    // The eight wave sums (q and p of four sentences) as ONE transposing butterfly: at offsets 32, 16, 8 a lane keeps half
+    // of its values and hands the other half to its partner, then three plain steps -- 10 shuffles instead of 48, every
+    // addition pairing exactly the lanes group_sum() pairs (32, 16, ..., 1), so the sums are bit-identical to
+    // k_segment_sum's.  (Eight separate reductions with a store branch between them ran as serial dependent chains: the
+    // single block took 13 us.)  Value j = 2 u + {0: q, 1: p} ends up in the lanes with bits (5, 4, 3) = (j & 1, j >> 1 & 1, j >> 2).
+    float v8[8] = {aq[0], ap[0], aq[1], ap[1], aq[2], ap[2], aq[3], ap[3]};
+    float v4[4], v2[2];
+    const bool h32 = (lane & 32) != 0, h16 = (lane & 16) != 0, h8 = (lane & 8) != 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float got = __shfl_xor(h32 ? v8[2 * i] : v8[2 * i + 1], 32, 64);
+      v4[i] = (h32 ? v8[2 * i + 1] : v8[2 * i]) + got;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float got = __shfl_xor(h16 ? v4[2 * i] : v4[2 * i + 1], 16, 64);
+      v2[i] = (h16 ? v4[2 * i + 1] : v4[2 * i]) + got;
+    }
+    float y = (h8 ? v2[1] : v2[0]) + __shfl_xor(h8 ? v2[0] : v2[1], 8, 64);
+    y += __shfl_xor(y, 4, 64);
+    y += __shfl_xor(y, 2, 64);
+    y += __shfl_xor(y, 1, 64);
+    const float other = __shfl_xor(y, 32, 64);            // the p sum sits opposite the q sum of the same sentence
+    const int u = (h16 ? 1 : 0) + (h8 ? 2 : 0);
+    if ((lane & 7) == 0 && bn0 + u < Bn) {
+      if (!h32) {
+        float v = y - other;
+        if (use_fb) v = v < fb ? fb : v;
+        logq[bn0 + u] = y; kl_out[bn0 + u] = v;
+        s_kl[bn0 + u] = v;
+      } else {
+        logp[bn0 + u] = y;
+      }
     }
   }
   __syncthreads();
@@ -1046,15 +1087,18 @@ __global__ void __launch_bounds__(1024) k_tail_fwd(const float* __restrict__ tok
   }
 }
 
-// gout = {d batch-loss, d batch-kl, d batch-nll} -> d recon, d log q, d log p per sentence (k_elbo_bwd + k_kl_bwd)
+// cotangents of batch-loss, batch-kl, batch-nll (one device scalar each, NULL = zero) -> d recon, d log q, d log p per
+// sentence (k_elbo_bwd + k_kl_bwd)
 __global__ void k_tail_bwd(const float* __restrict__ recon, const float* __restrict__ logq, const float* __restrict__ logp,
-                           const float* __restrict__ gout, float* __restrict__ drecon, float* __restrict__ dq,
+                           const float* __restrict__ g_loss, const float* __restrict__ g_kl,
+                           const float* __restrict__ g_nll, float* __restrict__ drecon, float* __restrict__ dq,
                            float* __restrict__ dp, int B, int n, int use_fb, float fb, float wr, float wk, int iwae,
                            const float* __restrict__ wdev) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   if (wdev) { wr = wdev[0]; wk = wdev[1]; }
-  float gl = gout[0], gk = gout[1] / ((float)B * n), gn = gout[2] / ((float)B * n);
+  float gl = g_loss ? g_loss[0] : 0.f, gk = (g_kl ? g_kl[0] : 0.f) / ((float)B * n),
+        gn = (g_nll ? g_nll[0] : 0.f) / ((float)B * n);
   auto kl_of = [&](int i) { float v = logq[i] - logp[i]; if (use_fb) v = v < fb ? fb : v; return v; };
   auto put = [&](int i, float dr, float dk) {
     const float v = logq[i] - logp[i];
@@ -1532,13 +1576,13 @@ extern "C" int mivae_latent_tail_fwd(const float* tok_logq, const float* tok_log
   MIVAE_CHECK_LAUNCH("latent_tail_fwd");
   return MIVAE_OK;
 }
-extern "C" int mivae_latent_tail_bwd(const float* recon, const float* logq, const float* logp, const float* gout3,
-                                     float* drecon, float* dlogq, float* dlogp, int64_t B, int64_t n, int use_fb,
-                                     float free_bits, float recon_weight, float kl_weight, int iwae,
-                                     const float* weights_dev, void* stream) {
+extern "C" int mivae_latent_tail_bwd(const float* recon, const float* logq, const float* logp, const float* g_loss,
+                                     const float* g_kl, const float* g_nll, float* drecon, float* dlogq, float* dlogp,
+                                     int64_t B, int64_t n, int use_fb, float free_bits, float recon_weight,
+                                     float kl_weight, int iwae, const float* weights_dev, void* stream) {
   MIVAE_REQUIRE(B > 0 && n > 0 && B * n < (1ll << 30), "latent_tail_bwd: bad shape");
-  MIVAE_REQUIRE(recon && logq && logp && gout3 && drecon && dlogq && dlogp, "latent_tail_bwd: null pointer");
-  k_tail_bwd<<<(unsigned)((B + kBlock - 1) / kBlock), kBlock, 0, S_(stream)>>>(recon, logq, logp, gout3, drecon, dlogq,
+  MIVAE_REQUIRE(recon && logq && logp && drecon && dlogq && dlogp, "latent_tail_bwd: null pointer");
+  k_tail_bwd<<<(unsigned)((B + kBlock - 1) / kBlock), kBlock, 0, S_(stream)>>>(recon, logq, logp, g_loss, g_kl, g_nll, drecon, dlogq,
                                                                               dlogp, (int)B, (int)n, use_fb, free_bits,
                                                                               recon_weight, kl_weight, iwae, weights_dev);
   MIVAE_CHECK_LAUNCH("latent_tail_bwd");

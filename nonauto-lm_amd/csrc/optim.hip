@@ -166,6 +166,24 @@ extern "C" int mivae_scalar_add(float* x, float delta, void* stream) {
   return MIVAE_OK;
 }
 
+// dst[i] += (src[i] ? *src[i] : inc[i]) for up to four device scalars in one launch: the running metric sums of the step
+// (models/base/model.py:200-210) and the optimizer's step counter, which a replayed graph advances together.
+struct Acc4 { float* dst[4]; const float* src[4]; float inc[4]; int n; };
+__global__ void k_accumulate4(Acc4 a) {
+  const int i = threadIdx.x;
+  if (i < a.n && a.dst[i]) *a.dst[i] += a.src[i] ? *a.src[i] : a.inc[i];
+}
+extern "C" int mivae_accumulate_scalars(float* const* dst, const float* const* src, const float* inc, int64_t n, void* stream) {
+  MIVAE_REQUIRE(dst && src && inc && n >= 0 && n <= 4, "accumulate_scalars: up to four scalars");
+  if (n == 0) return MIVAE_OK;
+  Acc4 a = {};
+  a.n = (int)n;
+  for (int i = 0; i < (int)n; ++i) { a.dst[i] = dst[i]; a.src[i] = src[i]; a.inc[i] = inc[i]; }
+  k_accumulate4<<<1, 64, 0, S_(stream)>>>(a);
+  MIVAE_CHECK_LAUNCH("accumulate_scalars");
+  return MIVAE_OK;
+}
+
 // ---- measurement aid: a plain streaming copy (16 bytes per lane, 4 loads in flight per lane) ----------------------
 // bench.py times it on a 256 MiB buffer to report the copy bandwidth THIS box reaches next to the 8 TB/s datasheet
 // figure (SURVEY 8d asks for both denominators).  Not part of the product path.  A block walks a contiguous segment,

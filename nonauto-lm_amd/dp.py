@@ -302,6 +302,7 @@ class PackedScalars:
         self.buf = torch.zeros(len(self.names) + 1, dtype=torch.float32, device=device)
         self._tmpl = torch.zeros_like(self.buf)
         self._tmpl_host: Optional[tuple] = None
+        self._buf_is_tmpl = False                # buf's host slots currently equal the template's (single rank only)
         self._idx_cache: Dict[tuple, torch.Tensor] = {}
 
     def reduce(self, values: Dict[str, torch.Tensor], count: float = 1.0, async_op: bool = False):
@@ -316,16 +317,33 @@ class PackedScalars:
                 host.append(float(v))
         host.append(float(count))
         host = tuple(host)
-        if host != self._tmpl_host:
+        fresh = host != self._tmpl_host
+        if fresh:
             self._tmpl.copy_(torch.tensor(host, dtype=torch.float32))
             self._tmpl_host = host
-        self.buf.copy_(self._tmpl)
-        if tens_i:
-            key = tuple(tens_i)
-            idx = self._idx_cache.get(key)
-            if idx is None:
-                idx = self._idx_cache[key] = torch.tensor(tens_i, dtype=torch.int64, device=self.buf.device)
-            self.buf.index_copy_(0, idx, torch.stack(tens_v).to(self.buf.device))
+        multi = world_size(self.group) > 1
+        # device scalars that sit side by side in one buffer (TrainStep's {batch-loss, batch-kl, batch-nll}) and fill the
+        # leading slots travel as ONE strided copy; on a single rank the host slots are rewritten only when they change
+        # (no all-reduce touches the buffer), so a steady-state step issues one launch here
+        k = len(tens_v)
+        packed = (k > 0 and tens_i == list(range(k)) and all(t.dim() == 0 and t.dtype == torch.float32 for t in tens_v)
+                  and tens_v[0].device == self.buf.device
+                  and all(t.untyped_storage().data_ptr() == tens_v[0].untyped_storage().data_ptr()
+                          and t.storage_offset() == tens_v[0].storage_offset() + i for i, t in enumerate(tens_v)))
+        if packed:
+            if multi or fresh or not self._buf_is_tmpl:
+                self.buf.copy_(self._tmpl)
+            self.buf[:k].copy_(torch.as_strided(tens_v[0], (k,), (1,)))
+            self._buf_is_tmpl = not multi
+        else:
+            self.buf.copy_(self._tmpl)
+            self._buf_is_tmpl = False
+            if tens_i:
+                key = tuple(tens_i)
+                idx = self._idx_cache.get(key)
+                if idx is None:
+                    idx = self._idx_cache[key] = torch.tensor(tens_i, dtype=torch.int64, device=self.buf.device)
+                self.buf.index_copy_(0, idx, torch.stack(tens_v).to(self.buf.device))
         if world_size(self.group) > 1:
             return dist.all_reduce(self.buf, group=self.group, async_op=async_op)
         return None

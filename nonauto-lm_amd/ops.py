@@ -406,6 +406,7 @@ class _PosteriorTok(torch.autograd.Function):
             L.call("mivae_rng_advance", L.ptr(state), L.stream())
         ctx.save_for_backward(sg_c, eps_c, used, mask)
         ctx.meta = (B, n, S, D, int(is_pre), lo, hi)
+        ctx.set_materialize_grads(False)     # unused outputs (sigma, usually) come back as None, not as zero tensors
         return z, sigma, tok
 
     @staticmethod
@@ -513,6 +514,8 @@ class _GaussLogProb(torch.autograd.Function):
     def backward(ctx, dtok):
         z, mask = ctx.saved_tensors
         Bn, S, D, mask_div, mu, std = ctx.meta
+        if dtok is None:
+            return None, None, None, None, None
         dz = torch.empty_like(z)
         dl, per_tok = _tok_cotangent(dtok, Bn, S)
         if per_tok:       # one "sentence" per token: the mask is indexed per token (un-repeated masks are expanded first)
@@ -1642,8 +1645,10 @@ def elbo_tail(recon, kl, batch: int, samples: int, recon_weight: float, kl_weigh
 
 
 class _LatentTail(torch.autograd.Function):
-    """mivae_latent_tail_fwd / _bwd: per-token log q, log p + per-sentence reconstruction error -> {batch-loss, batch-kl,
-    batch-nll} and (non-differentiable) per-sentence log q, log p, kl."""
+    """mivae_latent_tail_fwd / _bwd: per-token log q, log p + per-sentence reconstruction error -> batch-loss, batch-kl,
+    batch-nll (three device scalars, views of one 3-vector) and (non-differentiable) per-sentence log q, log p, kl.
+    The scalars are separate outputs so that the backward receives their cotangents as they are (None when unused):
+    indexing one 3-vector output instead costs a zeros + copy launch per step in autograd's select backward."""
 
     @staticmethod
     def forward(ctx, tok_q, tok_p, recon, B, n, fb, wr, wk, iwae, wdev, rng_state):
@@ -1660,16 +1665,18 @@ class _LatentTail(torch.autograd.Function):
         ctx.wdev = wdev
         ctx.meta = (B, n, S, fb, float(wr), float(wk), int(iwae))
         ctx.mark_non_differentiable(stats)
-        return out, stats
+        ctx.set_materialize_grads(False)
+        return out[0], out[1], out[2], stats
 
     @staticmethod
-    def backward(ctx, g, _gstats):
+    def backward(ctx, g_loss, g_kl, g_nll, _gstats):
         r, stats = ctx.saved_tensors
         B, n, S, fb, wr, wk, iwae = ctx.meta
         Bn = B * n
         d = torch.empty(3, Bn, dtype=torch.float32, device=r.device)     # d recon, d log q, d log p
         use = fb is not None
-        L.call("mivae_latent_tail_bwd", L.ptr(r), L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(g.contiguous().float()),
+        gs = [None if g is None else g.contiguous().float() for g in (g_loss, g_kl, g_nll)]
+        L.call("mivae_latent_tail_bwd", L.ptr(r), L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(gs[0]), L.ptr(gs[1]), L.ptr(gs[2]),
                L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]), B, n, int(use), float(fb) if use else 0.0, wr, wk, iwae,
                L.ptr(ctx.wdev), L.stream())
         # per-sentence cotangents of the per-token inputs as expanded views: the producers' kernels index them per sentence
@@ -1693,9 +1700,9 @@ def latent_tail(tok_logq, tok_logp, recon, batch: int, samples: int, free_bits: 
     if tok_logq.dtype != torch.float32 or tok_logp.dtype != torch.float32:
         raise TypeError("latent_tail: per-token values are fp32")
     state = _philox_peek(tok_logq.device) if rng_advance else None     # the posterior's deferred generator step
-    out, stats = _LatentTail.apply(tok_logq, tok_logp, recon.reshape(-1), int(batch), int(samples), free_bits,
-                                   recon_weight, kl_weight, iwae, weights_dev, state)
-    return (out[0], out[1], out[2]), (stats[0], stats[1], stats[2])
+    o0, o1, o2, stats = _LatentTail.apply(tok_logq, tok_logp, recon.reshape(-1), int(batch), int(samples), free_bits,
+                                          recon_weight, kl_weight, iwae, weights_dev, state)
+    return (o0, o1, o2), (stats[0], stats[1], stats[2])
 
 
 # ----------------------------------------------------------------------------------- reconstruction NLL
@@ -1906,6 +1913,7 @@ class _NiceStack(torch.autograd.Function):
         ctx.meta = (Bn, S, D, H, K, act, int(base), float(mu), float(std), code)
         ctx.shapes = [tuple(p.shape) for p in params]
         ctx.params = params
+        ctx.set_materialize_grads(False)     # an unused z_K (the ELBO only takes the per-token values) comes back as None
         if need_grad:
             ctx.save_for_backward(z, z_out, hist, mask, packed)
         return z_out, tok
@@ -2025,6 +2033,7 @@ class _NiceStackBig(torch.autograd.Function):
                    L.ptr(tok), Bn, 1, S, D, H, K, act, int(inverse), int(base), float(mu), float(std), L.stream())
         ctx.meta = (Bn, S, D, H, K, act, int(base), float(mu), float(std))
         ctx.params = params
+        ctx.set_materialize_grads(False)
         if need_grad:
             ctx.save_for_backward(z, z_out, hist, mask, pb, packed["chain"], packed["nets"])
         return z_out, tok

@@ -59,6 +59,7 @@ class TrainStep:
         self._pinned = None
         # scheduler weights on the device (read by mivae_elbo_fwd / _bwd)
         self._w_dev = torch.zeros(2, dtype=torch.float32, device=tokens.device)
+        self._w_host = (0.0, 0.0)                 # what _w_dev holds (uploads happen only when a weight changes)
         if isinstance(optimizer, dp.FusedAdam):   # averaging folded into the update kernel
             reducer.fold_average = True
         if graph:
@@ -109,8 +110,14 @@ class TrainStep:
         # by-value fills: a pinned staging buffer reused every step would be overwritten by the host while the
         # asynchronous copy of an earlier step is still queued behind the GPU's backlog
         m = self.model
-        self._w_dev[0:1].fill_(float(m._recon_scheduler.weight))
-        self._w_dev[1:2].fill_(float(m._kl_scheduler.weight))
+        w = (float(m._recon_scheduler.weight), float(m._kl_scheduler.weight))
+        if w == self._w_host:                     # constant schedulers: nothing to upload, no launch
+            return
+        if w[0] != self._w_host[0]:
+            self._w_dev[0:1].fill_(w[0])
+        if w[1] != self._w_host[1]:
+            self._w_dev[1:2].fill_(w[1])
+        self._w_host = w
 
     # ---- snapshot of everything a warm-up / capture iteration touches ---------------------------
     def _snapshot(self):
@@ -236,12 +243,15 @@ class TrainStep:
                 track = self._want_track and self._acc is not None
                 fold = track and isinstance(self.opt, dp.FusedAdam)     # the optimizer's step counter rides along
                 self._update(bump=not fold)
-                if track:
-                    if self._seed is None:
-                        self._seed = torch.ones((), dtype=torch.float32, device=self._acc.device)
-                    dst = list(self._acc_views) + ([self.opt.step_count] if fold else [])
-                    src = [self.info["batch-nll"].detach().float(), self.info["batch-kl"].detach().float()]
-                    torch._foreach_add_(dst, src + ([self._seed.float()] if fold else []))
+                if track:     # running sums += batch-nll, batch-kl; step counter += 1: ONE single-thread launch
+                    import ctypes
+                    from . import _lib as L
+                    self._acc_src = [self.info["batch-nll"].detach().float(), self.info["batch-kl"].detach().float()]
+                    dst = [v.data_ptr() for v in self._acc_views] + ([self.opt.step_count.data_ptr()] if fold else [])
+                    src = [t.data_ptr() for t in self._acc_src] + ([None] if fold else [])
+                    inc = [0.0, 0.0] + ([1.0] if fold else [])
+                    L.call("mivae_accumulate_scalars", (ctypes.c_void_p * len(dst))(*dst),
+                           (ctypes.c_void_p * len(src))(*src), (ctypes.c_float * len(inc))(*inc), len(dst), L.stream())
             self.graph_a, self.graph_b, self.comm_in_graph = graph_a, graph_b, comm
             return True
         except RuntimeError as err:
