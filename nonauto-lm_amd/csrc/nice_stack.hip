@@ -729,18 +729,41 @@ __global__ void __launch_bounds__(256) k_dw_partial(DwArgs a) {
   if constexpr (P::KS == 16) {
     const u16x8 ones_raw = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
     const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_raw);
-    for (int64_t k0 = t0; k0 < t1; k0 += 16) {
-      const int64_t blk = (k0 >> 3) + hh;
-      const bf16x8 af = *reinterpret_cast<const bf16x8*>(A + blk * sA);
-      bf16x8 bf[HT];
+    // Batches of UB k-steps, the next batch's fragments requested before the current batch's MFMAs: the loop was a chain
+    // of (global load -> wait -> MFMA) round trips, ~0.5 us per 16 tokens at C2 (slabs are multiples of 64 tokens).
+    constexpr int UB = HT <= 2 ? 4 : 2;
+    bf16x8 afc[UB], bfc[UB][HT];
+    auto loadb = [&](int64_t k0, bf16x8 (&af)[UB], bf16x8 (&bf)[UB][HT]) {
 #pragma unroll
-      for (int t = 0; t < HT; ++t) bf[t] = *reinterpret_cast<const bf16x8*>(B + blk * sB + 32 * t * TB);
+      for (int u = 0; u < UB; ++u) {
+        const int64_t blk = ((k0 + 16 * u) >> 3) + hh;
+        af[u] = *reinterpret_cast<const bf16x8*>(A + blk * sA);
 #pragma unroll
-      for (int t = 0; t < HT; ++t) acc[t] = P::mma(af, bf[t], acc[t]);
-      if (type == 0) accb[0] = P::mma(af, ones, accb[0]);
-      if (want_b2) {
+        for (int t = 0; t < HT; ++t) bf[u][t] = *reinterpret_cast<const bf16x8*>(B + blk * sB + 32 * t * TB);
+      }
+    };
+    if (t0 < t1) loadb(t0, afc, bfc);
+    for (int64_t k0 = t0; k0 < t1; k0 += 16 * UB) {
+      bf16x8 afn[UB], bfn[UB][HT];
+      const bool more = k0 + 16 * UB < t1;           // wave-uniform
+      if (more) loadb(k0 + 16 * UB, afn, bfn);
 #pragma unroll
-        for (int t = 0; t < HT; ++t) accb[t] = P::mma(ones, bf[t], accb[t]);
+      for (int u = 0; u < UB; ++u) {
+#pragma unroll
+        for (int t = 0; t < HT; ++t) acc[t] = P::mma(afc[u], bfc[u][t], acc[t]);
+        if (type == 0) accb[0] = P::mma(afc[u], ones, accb[0]);
+        if (want_b2) {
+#pragma unroll
+          for (int t = 0; t < HT; ++t) accb[t] = P::mma(ones, bfc[u][t], accb[t]);
+        }
+      }
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          afc[u] = afn[u];
+#pragma unroll
+          for (int t = 0; t < HT; ++t) bfc[u][t] = bfn[u][t];
+        }
       }
     }
   } else {
@@ -801,8 +824,15 @@ __global__ void __launch_bounds__(256) k_dw_reduce(DwArgs a) {
     const float* p = a.part + (item0 * a.HT + t) * 1024 + e;
     const int64_t stride = (int64_t)a.HT * 1024;
     float s = 0.f;
-#pragma unroll 4
-    for (int sl = grp; sl < a.nslab; sl += 4) s += p[sl * stride];
+    int sl = grp;
+    for (; sl + 28 < a.nslab; sl += 32) {      // eight loads in flight, summed in slab order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(sl + 4 * u) * stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; sl < a.nslab; sl += 4) s += p[sl * stride];
     red[grp][lane] = s;
     __syncthreads();
     if (grp != 0) return;
