@@ -126,6 +126,20 @@ static inline int lanes_per_row(int64_t D, int vec) {
   return l;
 }
 
+// ---- transposing LDS read (gfx950 ds_read_b64_tr_b16) ------------------------------------------
+// MFMA fragment whose 8 elements per lane run along the SLOW index of a row-major bf16 LDS tile: f[j] =
+// tile[k0 + 8 hh + j][fbase + r32] (A or B operand of v_mfma_f32_32x32x16_bf16 contracting over tile rows).  Per
+// 16-lane group the instruction delivers a 4-row x 16-column block column-major.  EXEC must be all ones.
+typedef __bf16 bf16x4_tr __attribute__((__vector_size__(4 * sizeof(__bf16))));
+__device__ __forceinline__ bf16x8 lds_tr_frag(const unsigned short* tile, int stride, int fbase, int k0, int lane) {
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+  const unsigned short* a0 = tile + (k0 + 8 * (g >> 1) + q) * stride + fbase + 16 * (g & 1) + 4 * p;
+  typedef __attribute__((address_space(3))) bf16x4_tr* lds_ptr;
+  const bf16x4_tr v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(a0));
+  const bf16x4_tr v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(a0 + 4 * stride));
+  return __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace mivae

@@ -570,40 +570,12 @@ __global__ void k_nice_affine_bwd(const T* __restrict__ dout, const float* __res
 
 // ------------------------------------------------------------------------------------------------
 // a12/a13 ActNorm (actnorm.py:31-33 forward, :45-48 inverse).  Parameters are fp32.
-template <typename T, int VEC>
-__global__ void k_actnorm_fwd(const T* __restrict__ z, const float* __restrict__ log_scale,
-                              const float* __restrict__ bias, const int64_t* __restrict__ mask,
-                              T* __restrict__ out, int64_t rows, int mask_div, int S, int D, int L,
-                              int inverse) {
-  int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int64_t row = tid / L;
-  int lig = (int)(tid % L);
-  if (row >= rows) return;
-  float m = 1.f;
-  if (mask) {
-    int64_t bn = row / S;
-    m = (float)mask[(bn / mask_div) * S + (row - bn * S)];
-  }
-  for (int c = lig * VEC; c < D; c += L * VEC) {
-    float v[VEC], o[VEC];
-    RowIO<T, VEC>::load(z + row * D + c, v);
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-      float e = expf(log_scale[c + i]);
-      if (!inverse) o[i] = (v[i] * e + bias[c + i]) * m;
-      else o[i] = ((v[i] - bias[c + i]) * m) / (e + 1e-13f);
-    }
-    RowIO<T, VEC>::store(out + row * D + c, o);
-  }
-}
-
-// log_det[bn] = sign * (sum_d log_scale[d]) * count[bn]   (count = integer token count, or 1 when
-// there is no mask / 2-D input, in which case the caller passes nseg = 1).  One wave per output.
-__global__ void k_actnorm_logdet(const float* __restrict__ log_scale, const int64_t* __restrict__ mask,
-                                 float* __restrict__ out, int64_t nseg, int mask_div, int S, int D,
-                                 float sign) {
-  int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  int lane = threadIdx.x & 63;
+// log_det[bn] = sign * (sum_d log_scale[d]) * count[bn]   (count = integer token count, or 1 when there is no mask /
+// 2-D input, in which case the caller passes nseg = 1).  One wave per output.
+__device__ __forceinline__ void actnorm_logdet_wave(const float* __restrict__ log_scale, const int64_t* __restrict__ mask,
+                                                    float* __restrict__ out, int64_t wave, int64_t nseg, int mask_div,
+                                                    int S, int D, float sign) {
+  const int lane = threadIdx.x & 63;
   float acc = 0.f;
   for (int d = lane; d < D; d += 64) acc += log_scale[d];
   acc = group_sum(acc, 64);
@@ -613,6 +585,67 @@ __global__ void k_actnorm_logdet(const float* __restrict__ log_scale, const int6
   for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
   if (wave < nseg && lane == 0) out[wave] = sign * acc * (mask ? (float)cnt : 1.f);
 }
+__global__ void k_actnorm_logdet(const float* __restrict__ log_scale, const int64_t* __restrict__ mask,
+                                 float* __restrict__ out, int64_t nseg, int mask_div, int S, int D,
+                                 float sign) {
+  actnorm_logdet_wave(log_scale, mask, out, ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nseg, mask_div, S, D, sign);
+}
+
+// A thread owns one VEC-wide column chunk of kActRows rows (the block's row groups interleaved): exp(log_scale) and the
+// bias are formed once per thread instead of once per element (the IEEE expf per element made the kernel VALU-bound at
+// 4x its HBM time: 36.6 us for 32 MiB at the C3 shape), and the kActRows independent 16-byte loads are in flight
+// together.  The first waves of the grid also write the log-determinants (was a launch of its own, 4 us).
+constexpr int kActRows = 4;
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) k_actnorm_fwd(const T* __restrict__ z, const float* __restrict__ log_scale,
+                                                     const float* __restrict__ bias, const int64_t* __restrict__ mask,
+                                                     T* __restrict__ out, int64_t rows, int mask_div, int S, int D, int L,
+                                                     int inverse, float* __restrict__ logdet, int64_t n_logdet,
+                                                     const int64_t* __restrict__ ld_mask) {
+  const int rif = blockDim.x / L, rg = threadIdx.x / L, lig = threadIdx.x % L;
+  const int64_t row0 = (int64_t)blockIdx.x * (rif * kActRows) + rg;
+  float m[kActRows];
+#pragma unroll
+  for (int k = 0; k < kActRows; ++k) {
+    const int64_t row = row0 + (int64_t)k * rif;
+    m[k] = 1.f;
+    if (mask && row < rows) {
+      const int64_t bn = row / S;
+      m[k] = (float)mask[(bn / mask_div) * S + (row - bn * S)];
+    }
+  }
+  if (row0 < rows)
+    for (int c = lig * VEC; c < D; c += L * VEC) {
+      float sc[VEC], bi[VEC], v[kActRows][VEC];
+#pragma unroll
+      for (int k = 0; k < kActRows; ++k) {
+        const int64_t row = row0 + (int64_t)k * rif;
+        if (row < rows) RowIO<T, VEC>::load(z + row * D + c, v[k]);
+      }
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const float e = expf(log_scale[c + i]);
+        sc[i] = inverse ? e + 1e-13f : e;
+        bi[i] = bias[c + i];
+      }
+#pragma unroll
+      for (int k = 0; k < kActRows; ++k) {
+        const int64_t row = row0 + (int64_t)k * rif;
+        if (row >= rows) continue;
+        float o[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          if (!inverse) o[i] = (v[k][i] * sc[i] + bi[i]) * m[k];
+          else o[i] = ((v[k][i] - bi[i]) * m[k]) / sc[i];
+        }
+        RowIO<T, VEC>::store(out + row * D + c, o);
+      }
+    }
+  if (logdet) {
+    const int64_t w = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (w < n_logdet) actnorm_logdet_wave(log_scale, ld_mask, logdet, w, n_logdet, mask_div, S, D, inverse ? -1.f : 1.f);
+  }
+}
 
 // Column reductions over token rows (two stage, fixed order).  Each block owns a contiguous chunk
 // of rows; lanes own VEC columns; partial[block][NV][D] then k_col_finish sums blocks in order.
@@ -620,7 +653,7 @@ __global__ void k_actnorm_logdet(const float* __restrict__ log_scale, const int6
 //   MODE 1: v0 = (x - aux[c])^2          (variance pass)
 //   MODE 2: ActNorm backward: g = dout*m ; dz = g*exp(ls) ; v0 = g*x*exp(ls) ; v1 = g
 template <typename T, int VEC, int MODE>
-__global__ void k_col_partial(const T* __restrict__ x, const T* __restrict__ dout,
+__global__ void __launch_bounds__(256) k_col_partial(const T* __restrict__ x, const T* __restrict__ dout,
                               const float* __restrict__ aux, const int64_t* __restrict__ mask,
                               T* __restrict__ dz, float* __restrict__ partial, int64_t rows,
                               int rows_per_block, int mask_div, int S, int D, int L) {
@@ -643,7 +676,38 @@ __global__ void k_col_partial(const T* __restrict__ x, const T* __restrict__ dou
 #pragma unroll
         for (int i = 0; i < VEC; ++i) ax[i] = MODE == 2 ? expf(aux[c + i]) : aux[c + i];
       }
-      for (int64_t row = r0 + rg; row < r1; row += rif) {
+      int64_t row = r0 + rg;
+      if (MODE == 2) {
+        // four rows per trip: eight independent 16-byte loads in flight, accumulated in the same row order as the
+        // one-row loop below (which takes the remainder)
+        for (; row + 3 * (int64_t)rif < r1; row += 4 * (int64_t)rif) {
+          float v[4][VEC], g[4][VEC], m[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int64_t rk = row + (int64_t)k * rif;
+            RowIO<T, VEC>::load(x + rk * D + c, v[k]);
+            RowIO<T, VEC>::load(dout + rk * D + c, g[k]);
+            m[k] = 1.f;
+            if (mask) {
+              const int64_t bn = rk / S;
+              m[k] = (float)mask[(bn / mask_div) * S + (rk - bn * S)];
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            float o[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+              const float gi = g[k][i] * m[k];
+              o[i] = gi * ax[i];
+              a0[i] += gi * v[k][i] * ax[i];
+              a1[i] += gi;
+            }
+            RowIO<T, VEC>::store(dz + (row + (int64_t)k * rif) * D + c, o);
+          }
+        }
+      }
+      for (; row < r1; row += rif) {
         float v[VEC];
         RowIO<T, VEC>::load(x + row * D + c, v);
         if (MODE == 0) {
@@ -1363,9 +1427,13 @@ void l_affine_bwd(const void* dout, const float* dld, const void* z, const void*
 }
 template <typename T, int VEC>
 void l_actnorm_fwd(const void* z, const float* ls, const float* bias, const int64_t* mask, void* out,
-                   int64_t rows, int mask_div, int S, int D, int inverse, RowCfg c, hipStream_t st) {
-  k_actnorm_fwd<T, VEC><<<c.grid, kBlock, 0, st>>>((const T*)z, ls, bias, mask, (T*)out, rows,
-                                                  mask_div, S, D, c.L, inverse);
+                   int64_t rows, int mask_div, int S, int D, int inverse, RowCfg c, hipStream_t st, float* logdet,
+                   int64_t n_logdet, const int64_t* ld_mask) {
+  const int rows_per_block = (kBlock / c.L) * kActRows;
+  int64_t grid = (rows + rows_per_block - 1) / rows_per_block;
+  if (logdet && (n_logdet + 3) / 4 > grid) grid = (n_logdet + 3) / 4;
+  k_actnorm_fwd<T, VEC><<<(unsigned)grid, kBlock, 0, st>>>((const T*)z, ls, bias, mask, (T*)out, rows, mask_div, S, D,
+                                                          c.L, inverse, logdet, n_logdet, ld_mask);
 }
 template <int MODE>
 struct ColPartial {
@@ -1707,17 +1775,17 @@ extern "C" int mivae_actnorm_fwd(const void* z, const float* log_scale, const fl
   if (rc) return rc;
   MIVAE_REQUIRE(mask_div >= 1, "actnorm_fwd: mask_div >= 1");
   MIVAE_REQUIRE(log_scale && bias, "actnorm_fwd: null parameter pointer");
+  const bool want_ld = logdet && n_logdet > 0;
+  // n_logdet = Bn and count_weighted = 1 for 3-D input with a mask, else 1 / 0 (actnorm.py:35-38)
+  MIVAE_REQUIRE(!want_ld || !count_weighted || mask, "actnorm_fwd: count_weighted needs a mask");
   if (Bn > 0) {
     MIVAE_REQUIRE(z && out, "actnorm_fwd: null pointer");
     int64_t rows = Bn * S;
     RowCfg c = row_cfg(rows, D, dtype, aligned16(z) && aligned16(out));
     DISPATCH(dtype, c.vec, l_actnorm_fwd, z, log_scale, bias, mask, out, rows, (int)mask_div, (int)S,
-             (int)D, inverse, c, S_(stream));
+             (int)D, inverse, c, S_(stream), want_ld ? logdet : nullptr, n_logdet, count_weighted ? mask : nullptr);
     MIVAE_CHECK_LAUNCH("actnorm_fwd");
-  }
-  if (logdet && n_logdet > 0) {
-    // n_logdet = Bn and count_weighted = 1 for 3-D input with a mask, else 1 / 0 (actnorm.py:35-38)
-    MIVAE_REQUIRE(!count_weighted || mask, "actnorm_fwd: count_weighted needs a mask");
+  } else if (want_ld) {
     unsigned grid = (unsigned)((n_logdet + 3) / 4);
     k_actnorm_logdet<<<grid, kBlock, 0, S_(stream)>>>(log_scale, count_weighted ? mask : nullptr,
                                                     logdet, n_logdet, (int)mask_div, (int)S, (int)D,

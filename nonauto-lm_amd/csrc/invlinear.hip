@@ -7,14 +7,18 @@
 // No mask multiply (the reference does not mask here); the log-det (slogdet(W) x token count x heads) is scalar work
 // and stays with the caller.
 //
-//   k_rowgemm<Mma>   one wave per 32 rows: A fragments straight from X (each row is read once per 32 output columns,
-//                    L1/L2 resident), B fragments straight from M (hs^2 elements, L2 resident), MFMA 32x32 tiles
-//                    (bf16: v_mfma_f32_32x32x16_bf16; fp32: v_mfma_f32_32x32x2_f32, bit-identical to an fmaf chain).
-//                    HBM-bound: reads X, writes Y once.
-//   k_rowgemm_wgrad  d M[o][i] = sum_r dY[r][o] X[r][i]: the contraction runs over ROWS, which both operands hold as
-//                    their slow index; the f32 MFMA's k = 2 fragments (lane = column, k = row) read them coalesced
-//                    without any transpose.  A wave owns a 32 x 32 tile of d M and a slab of rows; slabs are summed in
-//                    fixed order by mivae_colsum (run-to-run reproducible, no atomics).
+//   k_rowgemm_bf16<NKS>   production path (bf16, hs a multiple of 8): a block of 4 waves owns 128 rows; every wave keeps
+//                    its 32 rows of X in registers as MFMA B fragments (ONE read of X) and walks the output features
+//                    in tiles of 32 whose rows of M the block streams through a double-buffered LDS ring (M is read
+//                    from L2 once per 128 rows, not once per 32); v_mfma_f32_32x32x16_bf16 with the output features
+//                    on the accumulator rows, so each lane stores 4 consecutive bf16 (8 bytes) per quad.
+//   k_rowgemm_wgrad_bf16<WT>  d M[o][i] = sum_r dY[r][o] X[r][i] contracts over ROWS: a block stages a slab of rows of
+//                    both operands row-major in LDS (16-byte copies) and reads the k = row fragments with the
+//                    transposing LDS read (ds_read_b64_tr_b16); 4 waves in a 2 x 2 arrangement own a (64 WT)^2 tile
+//                    of d M; row slabs are summed in fixed order by mivae_colsum (reproducible, no atomics).
+//   k_rowgemm<Mma>, k_rowgemm_wgrad  fp32 latents (the checking mode: v_mfma_f32_32x32x2_f32 is bit-identical to an
+//                    fmaf chain) and bf16 widths that are not a multiple of 8: one wave per 32 rows, fragments straight
+//                    from global memory.
 #include "nice_common.hpp"
 
 namespace {
@@ -134,14 +138,177 @@ __global__ void __launch_bounds__(64) k_rowgemm_wgrad(WgradArgs a) {
   }
 }
 
+// ---- bf16 production kernels ------------------------------------------------------------------------------------
+// hs <= 16 NKS; LDS ring: 2 x [32 output features][16 NKS + 8] bf16 (row stride padded by 16 bytes: the 32 rows a
+// fragment read touches fall on different bank groups)
+template <int NKS>
+__global__ void __launch_bounds__(256) k_rowgemm_bf16(RowGemmArgs a) {
+  constexpr int SM = 16 * NKS + 8;               // LDS row stride (elements)
+  constexpr int CPR = 2 * NKS;                   // 16-byte chunks per staged row
+  constexpr int STG = (32 * CPR) / 256;          // chunks per thread and tile (NKS >= 4)
+  extern __shared__ __attribute__((aligned(16))) unsigned short ring[];   // [2][32][SM]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r32 = lane & 31, hh = lane >> 5;
+  const int hs = a.hs;
+  const int ntiles = (hs + 31) >> 5;
+  const int per = (ntiles + (int)gridDim.y - 1) / (int)gridDim.y;     // blockIdx.y takes a contiguous share of the output tiles
+  const int t0 = blockIdx.y * per, t1 = min(t0 + per, ntiles);
+  const unsigned short* X = static_cast<const unsigned short*>(a.x);
+  const unsigned short* M = static_cast<const unsigned short*>(a.m);
+  unsigned short* Y = static_cast<unsigned short*>(a.y);
+  const int64_t tok = ((int64_t)blockIdx.x * 4 + wave) * 32 + r32;
+  const bool valid = tok < a.R;
+  // the wave's 32 rows as B fragments: xf[ks][j] = X[tok][16 ks + 8 hh + j], zero past hs
+  bf16x8 xf[NKS];
+  {
+    const unsigned short* xr = X + (valid ? tok : 0) * hs + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (valid && 16 * ks + 8 * hh < hs) v = *reinterpret_cast<const u16x8*>(xr + 16 * ks);
+      xf[ks] = __builtin_bit_cast(bf16x8, v);
+    }
+  }
+  u16x8 stg[STG];
+  auto fetch = [&](int t) {                       // rows 32 t .. 32 t + 31 of M -> registers (zero past hs either way)
+#pragma unroll
+    for (int j = 0; j < STG; ++j) {
+      const int c = threadIdx.x + 256 * j, row = c / CPR, c8 = (c - row * CPR) * 8;
+      u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (32 * t + row < hs && c8 < hs) v = *reinterpret_cast<const u16x8*>(M + (int64_t)(32 * t + row) * hs + c8);
+      stg[j] = v;
+    }
+  };
+  auto park = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < STG; ++j) {
+      const int c = threadIdx.x + 256 * j, row = c / CPR, c8 = (c - row * CPR) * 8;
+      *reinterpret_cast<u16x8*>(ring + (buf * 32 + row) * SM + c8) = stg[j];
+    }
+  };
+  if (t0 >= t1) return;                           // block-uniform, before the first barrier
+  fetch(t0);
+  park(t0 & 1);
+  __syncthreads();
+  for (int t = t0; t < t1; ++t) {
+    if (t + 1 < t1) fetch(t + 1);                 // global loads in flight under this tile's MFMAs
+    const unsigned short* mrow = ring + ((t & 1) * 32 + r32) * SM + 8 * hh;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // all NKS k-steps, no bound check: the ring and xf are zero past hs, and a branch-free chain lets the LDS reads
+    // be issued many MFMAs ahead (one wave per SIMD: nothing else hides their latency)
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(mrow + 16 * ks), xf[ks], acc, 0, 0, 0);
+    // accumulator rows = output features 32 t + 8 q + 4 hh + i, column = token
+    if (valid) {
+      unsigned short* yr = Y + tok * hs + 32 * t + 4 * hh;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (32 * t + 8 * q + 4 * hh < hs) {       // hs is a multiple of 8: a quad is inside or outside as a whole
+          const u16x4 o = {f32_to_bf16(acc[4 * q]), f32_to_bf16(acc[4 * q + 1]), f32_to_bf16(acc[4 * q + 2]),
+                           f32_to_bf16(acc[4 * q + 3])};
+          *reinterpret_cast<u16x4*>(yr + 8 * q) = o;
+        }
+    }
+    if (t + 1 < t1) park((t + 1) & 1);            // the other buffer: its last readers passed the barrier of tile t - 1
+    __syncthreads();
+  }
+}
+
+// d M partial of one row slab and one (64 WT)^2 output tile.  LDS: dY and X slabs [KR rows][64 WT + 32] bf16.
+template <int WT>
+__global__ void __launch_bounds__(256) k_rowgemm_wgrad_bf16(WgradArgs a) {
+  constexpr int TW = 64 * WT;                    // block tile edge
+  constexpr int TS = TW + 32;                    // LDS row stride (elements): 16 banks (mod 64) per row
+  constexpr int KR = WT == 1 ? 128 : 64;         // rows staged per pass
+  constexpr int CPR = TW / 8;                    // 16-byte chunks per staged row and operand
+  __shared__ __attribute__((aligned(16))) unsigned short gt[KR * TS];
+  __shared__ __attribute__((aligned(16))) unsigned short xt[KR * TS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r32 = lane & 31, hh = lane >> 5;
+  const int wo = wave >> 1, wi = wave & 1;       // the wave's (32 WT)^2 corner of the block tile
+  const int hs = a.hs;
+  const int o0 = blockIdx.y * TW, i0 = blockIdx.z * TW;
+  const unsigned short* X = static_cast<const unsigned short*>(a.x);
+  const unsigned short* G = static_cast<const unsigned short*>(a.dy);
+  const int64_t lo = (int64_t)blockIdx.x * a.slab_rows;
+  int64_t hi = lo + a.slab_rows;
+  if (hi > a.R) hi = a.R;
+  f32x16 acc[WT][WT];
+#pragma unroll
+  for (int m = 0; m < WT; ++m)
+#pragma unroll
+    for (int n = 0; n < WT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+  constexpr int STG = KR * CPR / 256;            // 16-byte chunks per thread, pass and operand
+  u16x8 sg[STG], sx[STG];
+  auto fetch = [&](int64_t rb) {
+#pragma unroll
+    for (int j = 0; j < STG; ++j) {
+      const int c = threadIdx.x + 256 * j, row = c / CPR, c8 = (c - row * CPR) * 8;
+      u16x8 vg = {0, 0, 0, 0, 0, 0, 0, 0}, vx = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (rb + row < hi) {
+        if (o0 + c8 < hs) vg = *reinterpret_cast<const u16x8*>(G + (rb + row) * hs + o0 + c8);
+        if (i0 + c8 < hs) vx = *reinterpret_cast<const u16x8*>(X + (rb + row) * hs + i0 + c8);
+      }
+      sg[j] = vg;
+      sx[j] = vx;
+    }
+  };
+  if (lo < hi) fetch(lo);
+  for (int64_t rb = lo; rb < hi; rb += KR) {
+    if (rb != lo) __syncthreads();               // the previous pass has been consumed
+#pragma unroll
+    for (int j = 0; j < STG; ++j) {
+      const int c = threadIdx.x + 256 * j, row = c / CPR, c8 = (c - row * CPR) * 8;
+      *reinterpret_cast<u16x8*>(gt + row * TS + c8) = sg[j];
+      *reinterpret_cast<u16x8*>(xt + row * TS + c8) = sx[j];
+    }
+    __syncthreads();
+    if (rb + KR < hi) fetch(rb + KR);            // the next pass's global loads fly under this pass's MFMAs
+#pragma unroll
+    for (int s = 0; s < KR / 16; ++s) {
+      bf16x8 af[WT], bfr[WT];
+#pragma unroll
+      for (int m = 0; m < WT; ++m) af[m] = lds_tr_frag(gt, TS, 32 * (WT * wo + m), 16 * s, lane);
+#pragma unroll
+      for (int n = 0; n < WT; ++n) bfr[n] = lds_tr_frag(xt, TS, 32 * (WT * wi + n), 16 * s, lane);
+#pragma unroll
+      for (int m = 0; m < WT; ++m)
+#pragma unroll
+        for (int n = 0; n < WT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
+    }
+  }
+  float* P = a.part + (int64_t)blockIdx.x * hs * hs;
+#pragma unroll
+  for (int m = 0; m < WT; ++m)
+#pragma unroll
+    for (int n = 0; n < WT; ++n) {
+      const int i = i0 + 32 * (WT * wi + n) + r32;
+      if (i < hs) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = o0 + 32 * (WT * wo + m) + acc_row(r, hh);
+          if (o < hs) P[(int64_t)o * hs + i] = acc[m][n][r];
+        }
+      }
+    }
+}
+
+// row slabs of the weight gradient (both dtypes): ~256-512 blocks of (64 WT)^2 output tiles, >= 256 rows per slab, whole
+// staging passes per slab
 static void wgrad_geom(int64_t R, int hs, int& nslab, int& slab_rows) {
-  const int tiles = ((hs + 31) / 32) * ((hs + 31) / 32);
-  int64_t want = (2048 + tiles - 1) / tiles;            // ~8 waves per CU in total
-  const int64_t maxs = (R + 63) / 64;                   // at least 64 rows per slab
+  const int wt = hs > 256 ? 2 : 1;
+  const int tb = (hs + 64 * wt - 1) / (64 * wt);
+  int64_t want = ((wt == 2 ? 256 : 512) + tb * tb - 1) / (tb * tb);
+  const int64_t maxs = (R + 255) / 256;
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
   int64_t sr = (R + want - 1) / want;
-  sr = (sr + 1) / 2 * 2;                                // whole MFMA k-steps
+  sr = (sr + 127) / 128 * 128;
   slab_rows = (int)sr;
   nslab = (int)((R + sr - 1) / sr);
 }
@@ -163,8 +330,33 @@ extern "C" int mivae_rowgemm(const void* x, const void* m, void* y, int64_t R, i
                 "rowgemm: bf16 operands must be 16-byte aligned");
   RowGemmArgs a = {x, m, y, R, (int)hs};
   const unsigned grid = (unsigned)((R + 127) / 128);
-  if (dtype == MIVAE_F32) k_rowgemm<MmaF32, float><<<grid, 256, 0, (hipStream_t)stream>>>(a);
-  else k_rowgemm<MmaBF16, unsigned short><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MIVAE_F32) {
+    k_rowgemm<MmaF32, float><<<grid, 256, 0, st>>>(a);
+  } else if ((hs & 7) == 0 && aligned16(y)) {
+    const int nks = hs <= 64 ? 4 : hs <= 128 ? 8 : hs <= 256 ? 16 : 32;
+    const size_t lds = (size_t)2 * 32 * (16 * nks + 8) * sizeof(unsigned short);
+    // two resident blocks per CU hide each other's barriers: split the output tiles over blockIdx.y while the row blocks
+    // alone would leave CUs with a single block (X is then read once per split, the second time from L2 / MALL)
+    const int ntiles = (int)((hs + 31) / 32);
+    int splits = (int)((512 + grid - 1) / grid);
+    if (splits > ntiles) splits = ntiles;
+    if (splits > 4) splits = 4;
+    const dim3 g2(grid, (unsigned)splits);
+    switch (nks) {
+      case 4: k_rowgemm_bf16<4><<<g2, 256, lds, st>>>(a); break;
+      case 8: k_rowgemm_bf16<8><<<g2, 256, lds, st>>>(a); break;
+      case 16: k_rowgemm_bf16<16><<<g2, 256, lds, st>>>(a); break;
+      default: {
+        static const hipError_t once = hipFuncSetAttribute((const void*)k_rowgemm_bf16<32>,
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)once;
+        k_rowgemm_bf16<32><<<g2, 256, lds, st>>>(a);
+      }
+    }
+  } else {
+    k_rowgemm<MmaBF16, unsigned short><<<grid, 256, 0, st>>>(a);
+  }
   MIVAE_CHECK_LAUNCH("rowgemm");
   return MIVAE_OK;
 }
@@ -192,10 +384,19 @@ extern "C" int mivae_rowgemm_wgrad(const void* x, const void* dy, float* part, i
   WgradArgs a = {x, dy, part, R, (int)hs, 0};
   int nslab;
   wgrad_geom(R, (int)hs, nslab, a.slab_rows);
-  const unsigned t = (unsigned)((hs + 31) / 32);
-  dim3 grid((unsigned)nslab, t, t);
-  if (dtype == MIVAE_F32) k_rowgemm_wgrad<float><<<grid, 64, 0, (hipStream_t)stream>>>(a);
-  else k_rowgemm_wgrad<unsigned short><<<grid, 64, 0, (hipStream_t)stream>>>(a);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MIVAE_BF16 && (hs & 7) == 0 && aligned16(x) && aligned16(dy)) {
+    const int wt = hs > 256 ? 2 : 1;
+    const unsigned tb = (unsigned)((hs + 64 * wt - 1) / (64 * wt));
+    dim3 grid((unsigned)nslab, tb, tb);
+    if (wt == 2) k_rowgemm_wgrad_bf16<2><<<grid, 256, 0, st>>>(a);
+    else k_rowgemm_wgrad_bf16<1><<<grid, 256, 0, st>>>(a);
+  } else {
+    const unsigned t = (unsigned)((hs + 31) / 32);
+    dim3 grid((unsigned)nslab, t, t);
+    if (dtype == MIVAE_F32) k_rowgemm_wgrad<float><<<grid, 64, 0, st>>>(a);
+    else k_rowgemm_wgrad<unsigned short><<<grid, 64, 0, st>>>(a);
+  }
   MIVAE_CHECK_LAUNCH("rowgemm_wgrad");
   return MIVAE_OK;
 }

@@ -142,16 +142,10 @@ struct WgArgs {
 // 16-lane group a 4-row x 16-column block delivered column-major).  The 4 waves split the OUTPUT tiles of
 // dW (Fo x Fi) instead of the tokens, so every wave owns its accumulators outright and writes its part of the
 // block's partial row directly.  Row strides are padded to 16 (mod 64) banks: the transposed reads are conflict free.
-typedef __bf16 lin_bf16x4 __attribute__((__vector_size__(4 * sizeof(__bf16))));
-#define LIN_LDS __attribute__((address_space(3)))
 
 // fragment f[j] = tile[tok0 + 8 hh + j][fbase + r32]   (A or B operand of v_mfma_f32_32x32x16_bf16, k = tokens)
 __device__ __forceinline__ lin_bf16x8 lin_tr_frag(const unsigned short* tile, int stride, int fbase, int tok0, int lane) {
-  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-  const unsigned short* a0 = tile + (tok0 + 8 * (g >> 1) + q) * stride + fbase + 16 * (g & 1) + 4 * p;
-  const lin_bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LIN_LDS lin_bf16x4*)(a0));
-  const lin_bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LIN_LDS lin_bf16x4*)(a0 + 4 * stride));
-  return __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+  return lds_tr_frag(tile, stride, fbase, tok0, lane);
 }
 
 constexpr int kSlab = 128;    // tokens staged per block and pass

@@ -2,9 +2,9 @@
 C5 D=512 K=32 ragged) against the fp32 CPU oracle (oracle/latent_path.py, pinned to the reference's goldens).
 
 bf16 latents: the oracle is evaluated in fp32 on the same bf16-rounded inputs and weights.  Tolerances (tensor-level
-max-norm relative error, conftest.rel_err): z_K <= 2e-2, log p <= 1e-2 (the bounds north_star's "stated looser tolerance
-in bf16" is given as in test_hip_parity.py), gradients <= 3e-2 (d s / d t and the hidden-layer cotangents are rounded to
-bf16 once before the weight-gradient products).  fp32 latents of the same widths run the composed path (library MLP +
+max-norm relative error, conftest.rel_err) are per shape, 2x the error measured on MI355X and recorded next to each bound
+(BIG_BOUNDS): z_K 2-3e-3 (one bf16 rounding per coupling), log p 2-7e-5 (fp32 accumulation), gradients 2-8e-3 (d s / d t
+and the hidden-layer cotangents are rounded to bf16 once before the weight-gradient products).  fp32 latents of the same widths run the composed path (library MLP +
 HIP affine / log-det tail) and keep the fp32 bound 1e-5 (gradients 5e-5)."""
 import pytest
 import torch
@@ -73,6 +73,21 @@ BIG_SHAPES = [
 ]
 
 
+# per-shape bounds = 2x the error measured on MI355X (recorded in the comment of each row), not a blanket 2e-2 / 3e-2
+BIG_BOUNDS = {
+    # measured:        z 2.2e-3, log p 6.9e-5, dz 3.3e-3, d params 7.5e-3, inverse 3.7e-3
+    (256, 256, 16): dict(z=5e-3, logp=1.5e-4, dz=7e-3, dparams=1.5e-2, inverse=8e-3),
+    # measured:        z 2.2e-3, log p 2.6e-5, dz 3.9e-3, d params 6.0e-3, inverse 2.4e-3
+    (208, 200, 3): dict(z=5e-3, logp=6e-5, dz=8e-3, dparams=1.2e-2, inverse=5e-3),
+    # measured:        z 2.0e-3, log p 1.8e-5, dz 2.2e-3, d params 4.7e-3, inverse 2.6e-3
+    (256, 96, 2): dict(z=4e-3, logp=4e-5, dz=5e-3, dparams=1e-2, inverse=6e-3),
+    # measured:        z 2.4e-3, log p 1.8e-5, dz 3.2e-3, d params 7.0e-3, inverse 1.5e-2 (32 inverse couplings in bf16)
+    (512, 512, 32): dict(z=5e-3, logp=4e-5, dz=7e-3, dparams=1.5e-2, inverse=3e-2),
+    # measured:        z 3.0e-3, log p 1.8e-5, dz 3.3e-3, d params 4.6e-3, inverse 2.7e-3
+    (400, 320, 4): dict(z=6e-3, logp=4e-5, dz=7e-3, dparams=1e-2, inverse=6e-3),
+}
+
+
 @pytest.mark.parametrize("B,S,D,H,K,act,ragged", BIG_SHAPES)
 def test_nice_big_bf16_vs_fp32_oracle(M, B, S, D, H, K, act, ragged):
     ps, flat, z0, mask, cz, cl = make_case(B, S, D, H, K, act, 100 + D + K, ragged, True)
@@ -82,20 +97,22 @@ def test_nice_big_bf16_vs_fp32_oracle(M, B, S, D, H, K, act, ragged):
     zg = z0.to(DEV).bfloat16().requires_grad_(True)
     zK, lp = M.ops.nice_stack(zg, mask.to(DEV), gp, H, act, inverse=False, base=True, mu=0.0, std=1.0)
     assert zK.dtype == torch.bfloat16 and lp.dtype == torch.float32
-    assert rel_err(zK.float(), zK_r) < 2e-2, rel_err(zK.float(), zK_r)
-    assert rel_err(lp, lp_r) < 1e-2, rel_err(lp, lp_r)
+    errs = {"z": rel_err(zK.float(), zK_r), "logp": rel_err(lp, lp_r)}
     # padding positions are exact zeros (couplings.py:159-161)
     assert float((zK.float().cpu() * (1 - mask).unsqueeze(-1)).abs().max()) == 0.0
     ((zK.float() * cz.to(DEV)).sum() + (lp * cl.to(DEV)).sum()).backward()
-    assert rel_err(zg.grad.float(), dz_r) < 3e-2, rel_err(zg.grad.float(), dz_r)
+    errs["dz"] = rel_err(zg.grad.float(), dz_r)
     assert float((zg.grad.float().cpu() * (1 - mask).unsqueeze(-1)).abs().max()) == 0.0
-    worst = max(rel_err(a.grad, b) for a, b in zip(gp, g_r))
-    assert worst < 3e-2, worst
+    errs["dparams"] = max(rel_err(a.grad, b) for a, b in zip(gp, g_r))
     with torch.no_grad():
-        zi_r, _ = O.flow_prior_inverse(zK_r, O.nice_steps(ps), mask.float())
         zi, _ = M.ops.nice_stack(zK_r.to(DEV).bfloat16(), mask.to(DEV), [t.detach() for t in gp], H, act, inverse=True)
         zi_r2, _ = O.flow_prior_inverse(zK_r.to(torch.bfloat16).float(), O.nice_steps(ps), mask.float())
-        assert rel_err(zi.float(), zi_r2) < 3e-2, rel_err(zi.float(), zi_r2)
+        errs["inverse"] = rel_err(zi.float(), zi_r2)
+    bound = BIG_BOUNDS[(D, H, K)]
+    print(f"nice_big bf16 vs fp32 oracle D={D} H={H} K={K} {act}: measured", {k: f"{v:.2e}" for k, v in errs.items()},
+          "bounds", bound)
+    for k, v in errs.items():
+        assert v < bound[k], (k, v, bound[k])
 
 
 def test_nice_big_grad_sink_matches_returned_grads(M):
