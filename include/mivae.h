@@ -217,6 +217,13 @@ int mivae_nice_dw_sink(const void* Gt, const void* Ht, const void* dSt, const vo
                        const int64_t* grad_ptrs, int64_t N, int64_t h, int64_t H, int64_t K, int dtype,
                        void* stream);
 
+/* As mivae_nice_dw for K coupling steps that are not consecutive in their flow list (ActNorm / linear steps between
+ * them change x0, flow_prior.py:37-52): x0t holds one (hp, Npad) section per step.  Weight gradients of the coupling
+ * nets of a mixed list (couplings.py:141-162 under autograd) after mivae_mixed_stack_bwd. */
+int mivae_nice_dw_steps(const void* Gt, const void* Ht, const void* dSt, const void* x0t, float* workspace,
+                        float* dW1, float* db1, float* dW2, float* db2, int64_t N, int64_t h, int64_t H,
+                        int64_t K, int dtype, void* stream);
+
 /* ---- ActNorm ------------------------------------------------------------------------------------- */
 /* out = (z exp(log_scale) + bias) * mask  (inverse: ((z - bias) * mask) / (exp(log_scale) + 1e-13));
  * logdet[i] = +-sum(log_scale) * (count_weighted ? token count of row i : 1), i < n_logdet.
@@ -312,6 +319,13 @@ int mivae_rowgemm(const void* x, const void* m, void* y, int64_t R, int64_t hs, 
 int64_t mivae_rowgemm_wgrad_slabs(int64_t R, int64_t hs);
 int mivae_rowgemm_wgrad(const void* x, const void* dy, float* part, int64_t R, int64_t hs, int dtype, void* stream);
 
+/* log |det M_i| of `count` <= 24 small square fp32 matrices (n_i <= 128) and, where inv_t[i] != NULL, M_i^-T = its
+ * gradient, in one launch: torch.slogdet(self._weight)[1] of invertible_flows.py:30-33 / :64-66 and what autograd
+ * derives from it.  mats / n / inv_t are HOST arrays (device pointers, sizes), read during the call; logdet (count) is
+ * a device array.  Gauss-Jordan with partial pivoting in LDS, fp32; a singular matrix gives -inf. */
+int mivae_slogdet_inv(const void* const* mats, const int64_t* n, int64_t count, float* logdet, void* const* inv_t,
+                      void* stream);
+
 /* Mixed flow stack, one launch, no gradients (evaluation / sampling): K steps executed in the order given, each a
  * NICE feed-forward coupling (couplings.py:141-183 + :50-51), an ActNorm (actnorm.py:30-54) or an invertible linear
  * map with one matrix per head (invertible_flows.py:26-44, :58-83), the loop of FlowPrior.forward_pass /
@@ -325,6 +339,29 @@ int mivae_mixed_stack_supported(int64_t D, int64_t Hmax);
 int mivae_mixed_stack(const void* z_in, void* z_out, const int64_t* mask, float* tok_val, const int64_t* steps,
                       int64_t K, int64_t Bn, int64_t S, int64_t mask_div, int64_t D, int inverse, int dtype,
                       void* stream);
+
+/* Training path of the same lists (density direction): what autograd runs through the per-flow modules of
+ * FlowPrior.forward_pass (flow_prior.py:37-52; actnorm.py:30-39, invertible_flows.py:26-33 / :58-66,
+ * couplings.py:141-162), in one launch each way.
+ *   mivae_mixed_stack_train_fwd = mivae_mixed_stack(inverse = 0) that also writes the input of every step to
+ *     hist (K, Bn S, D) fp32.
+ *   mivae_mixed_stack_bwd: steps K-1 .. 0 with the cotangent tile resident in LDS.  dz_out (Bn S, D) latent dtype or
+ *     NULL; dval = cotangent of tok_val, one per sentence (Bn) or, dval_per_token = 1, one per token, or NULL.
+ *     Outputs: dz_in; gcot (nL, Bn S, D) fp32 = cotangent at every linear step's output, row-major (d M = gcot^T hist[k]
+ *     through mivae_rowgemm_wgrad); an_part (blocks, nA, 2, D) fp32, blocks = mivae_mixed_stack_bwd_blocks: its sum over
+ *     the block axis (mivae_colsum) is [d log_scale | d bias] of every ActNorm step (z path; the log-det terms of the
+ *     parameters are the caller's, like the forward's); Gt, Ht (nN, 2, Hp, Npad), dSt (nN, 2, hp, Npad), x0t (nN, hp,
+ *     Npad) fp32, Npad = mivae_nice_stack_npad(Bn S): operands of mivae_nice_dw_steps (dtype MIVAE_F32).
+ *     nN / nA / nL = number of coupling / ActNorm / linear steps, ordinals in list order.  All coupling steps must share
+ *     one hidden width (MIVAE_EUNSUPPORTED otherwise; mivae_mixed_stack_bwd_blocks returns 0 for such lists). */
+int mivae_mixed_stack_train_fwd(const void* z_in, void* z_out, const int64_t* mask, float* tok_val, float* hist,
+                                const int64_t* steps, int64_t K, int64_t Bn, int64_t S, int64_t mask_div, int64_t D,
+                                int dtype, void* stream);
+int64_t mivae_mixed_stack_bwd_blocks(int64_t N, int64_t D, int64_t Hmax, int64_t Hmin, int any_linear);
+int mivae_mixed_stack_bwd(const float* hist, const void* dz_out, const float* dval, int dval_per_token,
+                          const int64_t* mask, const int64_t* steps, int64_t K, void* dz_in, float* gcot, float* an_part,
+                          float* Gt, float* Ht, float* dSt, float* x0t, int64_t Bn, int64_t S, int64_t mask_div,
+                          int64_t D, int dtype, void* stream);
 
 /* ---- KL / ELBO tail -------------------------------------------------------------------------------- */
 /* kl = clamp(logq - logp, min = free_bits) (clamp only if use_fb).  Replaces DefaultKLLoss.forward

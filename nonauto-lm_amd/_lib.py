@@ -70,8 +70,13 @@ SIGNATURES = {
     "mivae_rowgemm": [P, P, P, I64, I64, I32, P],
     "mivae_rowgemm_wgrad": [P, P, P, I64, I64, I32, P],
     "mivae_rowgemm_wgrad_slabs": [I64, I64],
+    "mivae_slogdet_inv": [P, P, I64, P, P, P],
     "mivae_mixed_stack_supported": [I64, I64],
     "mivae_mixed_stack": [P, P, P, P, P, I64, I64, I64, I64, I64, I32, I32, P],
+    "mivae_mixed_stack_train_fwd": [P, P, P, P, P, P, I64, I64, I64, I64, I64, I32, P],
+    "mivae_mixed_stack_bwd_blocks": [I64, I64, I64, I64, I32],
+    "mivae_mixed_stack_bwd": [P, P, P, I32, P, P, I64, P, P, P, P, P, P, P, I64, I64, I64, I64, I32, P],
+    "mivae_nice_dw_steps": [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I32, P],
     "mivae_elbo_fwd": [P, P, P, I64, I64, F32, F32, I32, P, P],
     "mivae_elbo_bwd": [P, P, P, P, P, I64, I64, F32, F32, I32, P, P],
     "mivae_nll_fwd": [P, P, P, P, P, P, P, I64, I64, I64, F32, I32, P],
@@ -154,6 +159,7 @@ _RET = {
     "mivae_layernorm_workspace_floats": I64,
     "mivae_nice_stack_npad": I64,
     "mivae_nice_dw_workspace_floats": I64,
+    "mivae_mixed_stack_bwd_blocks": I64,
     "mivae_nice_big_pack_bytes": I64,
     "mivae_nice_big_dw_workspace_floats": I64,
     "mivae_nice_big_hidden_elems": I64,

@@ -298,6 +298,83 @@ __global__ void __launch_bounds__(256) k_rowgemm_wgrad_bf16(WgradArgs a) {
     }
 }
 
+// fp32 operands (the checking mode, and the fp32 history / cotangents of the mixed-stack training path): the same slab
+// scheme on v_mfma_f32_32x32x2_f32.  Rows are staged row-major with an odd pitch, so the k = row fragments
+// (lane = column) are plain conflict-free LDS reads; 64 x 64 output tile per block, 32 x 32 per wave.
+__global__ void __launch_bounds__(256) k_rowgemm_wgrad_f32(WgradArgs a) {
+  constexpr int KR = 64, TS = 65, CPR = 16;      // rows per pass, LDS pitch (floats), 16-byte chunks per staged row
+  __shared__ float gt[KR * TS];
+  __shared__ float xt[KR * TS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r32 = lane & 31, hh = lane >> 5;
+  const int wo = wave >> 1, wi = wave & 1;
+  const int hs = a.hs;
+  const int o0 = blockIdx.y * 64, i0 = blockIdx.z * 64;
+  const float* X = static_cast<const float*>(a.x);
+  const float* G = static_cast<const float*>(a.dy);
+  const int64_t lo = (int64_t)blockIdx.x * a.slab_rows;
+  int64_t hi = lo + a.slab_rows;
+  if (hi > a.R) hi = a.R;
+  const bool vec = (hs & 3) == 0;                // 16-byte global loads need hs % 4 == 0 (the bases are 16-byte aligned)
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  constexpr int STG = KR * CPR / 256;
+  f32x4 sg[STG], sx[STG];
+  auto fetch = [&](int64_t rb) {
+#pragma unroll
+    for (int j = 0; j < STG; ++j) {
+      const int c = threadIdx.x + 256 * j, row = c / CPR, c4 = (c - row * CPR) * 4;
+      f32x4 vg = {0.f, 0.f, 0.f, 0.f}, vx = {0.f, 0.f, 0.f, 0.f};
+      if (rb + row < hi) {
+        const float* gp = G + (rb + row) * hs + o0 + c4;
+        const float* xp = X + (rb + row) * hs + i0 + c4;
+        if (vec) {
+          if (o0 + c4 < hs) vg = *reinterpret_cast<const f32x4*>(gp);
+          if (i0 + c4 < hs) vx = *reinterpret_cast<const f32x4*>(xp);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (o0 + c4 + e < hs) vg[e] = gp[e];
+            if (i0 + c4 + e < hs) vx[e] = xp[e];
+          }
+        }
+      }
+      sg[j] = vg;
+      sx[j] = vx;
+    }
+  };
+  if (lo < hi) fetch(lo);
+  for (int64_t rb = lo; rb < hi; rb += KR) {
+    if (rb != lo) __syncthreads();
+#pragma unroll
+    for (int j = 0; j < STG; ++j) {
+      const int c = threadIdx.x + 256 * j, row = c / CPR, c4 = (c - row * CPR) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        gt[row * TS + c4 + e] = sg[j][e];
+        xt[row * TS + c4 + e] = sx[j][e];
+      }
+    }
+    __syncthreads();
+    if (rb + KR < hi) fetch(rb + KR);
+#pragma unroll 8
+    for (int ks = 0; ks < KR / 2; ++ks) {
+      const int k = 2 * ks + hh;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(gt[k * TS + 32 * wo + r32], xt[k * TS + 32 * wi + r32], acc, 0, 0, 0);
+    }
+  }
+  float* P = a.part + (int64_t)blockIdx.x * hs * hs;
+  const int i = i0 + 32 * wi + r32;
+  if (i < hs) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = o0 + 32 * wo + acc_row(r, hh);
+      if (o < hs) P[(int64_t)o * hs + i] = acc[r];
+    }
+  }
+}
+
 // row slabs of the weight gradient (both dtypes): ~256-512 blocks of (64 WT)^2 output tiles, >= 256 rows per slab, whole
 // staging passes per slab
 static void wgrad_geom(int64_t R, int hs, int& nslab, int& slab_rows) {
@@ -311,6 +388,113 @@ static void wgrad_geom(int64_t R, int hs, int& nslab, int& slab_rows) {
   sr = (sr + 127) / 128 * 128;
   slab_rows = (int)sr;
   nslab = (int)((R + sr - 1) / sr);
+}
+
+
+// ---- log |det M| and M^-T of the flows' small square matrices -------------------------------------------------------
+// torch.slogdet(self._weight)[1] of invertible_flows.py:30-33 / :64-66 and its gradient d log|det M| / d M = M^-T, for up
+// to kSlogMats matrices in ONE launch (one block per matrix; n <= 128).  The library route is an LU factorisation per
+// matrix forward (getf2 panel kernel 70-130 us + ~15 pivot / index launches) and two triangular solves backward: at the
+// sizes of a flow list that is more GPU time and ten times more launches than the flows themselves.  Here: Gauss-Jordan
+// with partial (row) pivoting on the augmented image [M | I] in LDS, fp32; pivot rows are neither swapped nor scaled
+// in place (a used-row flag and the pivot values are kept instead), so a step is: column scan + arg-max (first wave) ->
+// barrier -> rank-1 update of every other row -> barrier.
+constexpr int kSlogMats = 24;
+constexpr int kSlogMaxN = 128;
+struct SlogArgs {
+  const float* m[kSlogMats];
+  float* invT[kSlogMats];       // may hold nulls (log-determinant only)
+  int n[kSlogMats];
+  float* logdet;                // [count]
+};
+
+__global__ void __launch_bounds__(1024) k_slogdet_inv(SlogArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float A[];     // [n][2 n + 1]
+  __shared__ float fac[kSlogMaxN], pivs[kSlogMaxN];
+  __shared__ int used[kSlogMaxN], perm[kSlogMaxN];
+  __shared__ int s_p;
+  const int n = a.n[blockIdx.x], LD = 2 * n + 1;
+  const float* __restrict__ M = a.m[blockIdx.x];
+  for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
+    const int i = idx / n, j = idx - i * n;
+    A[i * LD + j] = M[idx];
+    A[i * LD + n + j] = i == j ? 1.f : 0.f;
+  }
+  for (int i = threadIdx.x; i < n; i += blockDim.x) used[i] = 0;
+  float logdet = 0.f;                                            // thread 0's copy is the result
+  bool singular = false;
+  const int nw = blockDim.x >> 6;                                // waves: 4 (n <= 64) or 16
+  __syncthreads();
+  for (int k = 0; k < n; ++k) {
+    if (threadIdx.x < 64) {                                      // first wave: column k of the unused rows, arg-max |.|
+      const int lane = threadIdx.x;
+      float best = -1.f;
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int rep = 0; rep < 2; ++rep) {
+        const int t = lane + 64 * rep;
+        if (t < n) {
+          const float v = A[t * LD + k];
+          fac[t] = v;
+          const float av = used[t] ? -1.f : (fabsf(v) >= 0.f ? fabsf(v) : 3.0e38f);   // a NaN is taken (and propagates)
+          if (av > best) { best = av; bi = t; }                  // strict: the lower row wins ties
+        }
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+      }
+      if (lane == 0) {
+        s_p = bi;
+        used[bi] = 1;
+        perm[k] = bi;
+        pivs[k] = fac[bi];
+        logdet += logf(best);
+        singular = singular || best == 0.f;
+      }
+    }
+    __syncthreads();
+    const int p = s_p;
+    const float inv = 1.0f / pivs[k];
+    // every other row i: A[i][j] -= (A[i][k] / piv) A[p][j] over the n columns that can be non-zero and are still read:
+    // the left block's j > k and, in the right block, the identity columns of the rows used so far (B = the product of
+    // the row operations: a row that was never a pivot row still holds only its own 1).  Lanes own columns, waves rows.
+    {
+      const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nleft = n - k - 1;
+      for (int c0 = 0; c0 < n; c0 += 64) {
+        const int slot = c0 + lane;
+        if (slot < n) {
+          const int j = slot < nleft ? k + 1 + slot : n + perm[slot - nleft];
+          const float pr = A[p * LD + j] * inv;
+          for (int i0 = w; i0 < n; i0 += 8 * nw) {               // eight rows per trip: the LDS reads are in flight together
+            float v[8], f[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int i = i0 + u * nw;
+              if (i < n) { v[u] = A[i * LD + j]; f[u] = fac[i]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int i = i0 + u * nw;
+              if (i < n && i != p) A[i * LD + j] = v[u] - f[u] * pr;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) a.logdet[blockIdx.x] = singular ? -INFINITY : logdet;   // torch.slogdet: -inf
+  float* __restrict__ out = a.invT[blockIdx.x];
+  if (out) {
+    // [M | I] -> [P | B] with P[perm[c]][c] = piv_c: M^-1[c][:] = B[perm[c]][:] / piv_c, so M^-T[r][c] = B[perm[c]][r] / piv_c
+    for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
+      const int r = idx / n, c = idx - r * n;
+      out[idx] = A[perm[c] * LD + n + r] / pivs[c];
+    }
+  }
 }
 
 }  // namespace
@@ -391,6 +575,10 @@ extern "C" int mivae_rowgemm_wgrad(const void* x, const void* dy, float* part, i
     dim3 grid((unsigned)nslab, tb, tb);
     if (wt == 2) k_rowgemm_wgrad_bf16<2><<<grid, 256, 0, st>>>(a);
     else k_rowgemm_wgrad_bf16<1><<<grid, 256, 0, st>>>(a);
+  } else if (dtype == MIVAE_F32 && aligned16(x) && aligned16(dy)) {
+    const unsigned tb = (unsigned)((hs + 63) / 64);
+    dim3 grid((unsigned)nslab, tb, tb);
+    k_rowgemm_wgrad_f32<<<grid, 256, 0, st>>>(a);
   } else {
     const unsigned t = (unsigned)((hs + 31) / 32);
     dim3 grid((unsigned)nslab, t, t);
@@ -398,5 +586,38 @@ extern "C" int mivae_rowgemm_wgrad(const void* x, const void* dy, float* part, i
     else k_rowgemm_wgrad<unsigned short><<<grid, 64, 0, st>>>(a);
   }
   MIVAE_CHECK_LAUNCH("rowgemm_wgrad");
+  return MIVAE_OK;
+}
+
+// logdet[i] = log |det M_i| and, where inv_t[i] is not NULL, inv_t[i] = M_i^-T (the gradient of logdet[i] with respect to
+// M_i), for `count` <= 24 contiguous fp32 square matrices of n_i <= 128 rows, one launch.  mats / inv_t / n are HOST
+// arrays (device pointers / sizes), read during the call.  A singular matrix gives -inf like torch.slogdet.
+extern "C" int mivae_slogdet_inv(const void* const* mats, const int64_t* n, int64_t count, float* logdet,
+                                 void* const* inv_t, void* stream) {
+  MIVAE_REQUIRE(count >= 0 && count <= kSlogMats, "slogdet_inv: 0..%d matrices, got %lld", kSlogMats, (long long)count);
+  if (count == 0) return MIVAE_OK;
+  MIVAE_REQUIRE(mats && n && logdet, "slogdet_inv: null pointer");
+  SlogArgs a = {};
+  int nmax = 0;
+  for (int i = 0; i < count; ++i) {
+    if (n[i] < 1 || n[i] > kSlogMaxN) {
+      mivae_set_error("slogdet_inv: matrix %d has %lld rows (1..%d)", i, (long long)n[i], kSlogMaxN);
+      return MIVAE_EUNSUPPORTED;
+    }
+    MIVAE_REQUIRE(mats[i], "slogdet_inv: null matrix %d", i);
+    a.m[i] = static_cast<const float*>(mats[i]);
+    a.invT[i] = inv_t ? static_cast<float*>(inv_t[i]) : nullptr;
+    a.n[i] = (int)n[i];
+    if (a.n[i] > nmax) nmax = a.n[i];
+  }
+  a.logdet = logdet;
+  const size_t lds = (size_t)nmax * (2 * nmax + 1) * sizeof(float);
+  if (lds > 48 * 1024) {
+    static const hipError_t once = hipFuncSetAttribute((const void*)k_slogdet_inv, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       (int)((size_t)kSlogMaxN * (2 * kSlogMaxN + 1) * sizeof(float)));
+    (void)once;
+  }
+  k_slogdet_inv<<<(unsigned)count, nmax <= 64 ? 256 : 1024, lds, (hipStream_t)stream>>>(a);
+  MIVAE_CHECK_LAUNCH("slogdet_inv");
   return MIVAE_OK;
 }

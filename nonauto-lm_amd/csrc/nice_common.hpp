@@ -270,4 +270,22 @@ __device__ __forceinline__ void store_acc(T* __restrict__ row, bool valid, int h
     }
 }
 
+// Side outputs of the backward (consumed by the weight-gradient kernel) are stored "token-blocked":
+// element (feature row f, token tau) of a section with F rows lives at ((tau / TB) * F + f) * TB + tau % TB,
+// TB = 16 bytes worth of tokens (8 bf16 / 4 fp32).  The reader's MFMA fragment (row on the lane, TB
+// consecutive tokens per lane) is then ONE fully coalesced 16-byte-per-lane load per operand.
+// Store of one accumulator tile (rows row0 + acc_row(r, hh), token on the lane): `base`, `row0` are
+// wave-uniform, `loff` = (tau / TB) * F * TB + tau % TB + 4 * hh * TB is the per-lane part (computed
+// once per kernel): no per-store 64-bit VALU address arithmetic.
+template <typename T>
+__device__ __forceinline__ void store_tile_t(T* __restrict__ base, int row0, unsigned loff, const f32x16& x) {
+  constexpr int TB = 16 / sizeof(T);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    T* rowp = base + (row0 + (r & 3) + 8 * (r >> 2)) * TB;
+    float t1[1] = {x[r]};
+    RowIO<T, 1>::store(rowp + loff, t1);
+  }
+}
+
 }  // namespace mivae

@@ -36,24 +36,6 @@ using namespace mivae;
 namespace {
 
 
-// Side outputs of the backward (consumed by the weight-gradient kernel) are stored "token-blocked":
-// element (feature row f, token tau) of a section with F rows lives at ((tau / TB) * F + f) * TB + tau % TB,
-// TB = 16 bytes worth of tokens (8 bf16 / 4 fp32).  The reader's MFMA fragment (row on the lane, TB
-// consecutive tokens per lane) is then ONE fully coalesced 16-byte-per-lane load per operand.
-// Store of one accumulator tile (rows row0 + acc_row(r, hh), token on the lane): `base`, `row0` are
-// wave-uniform, `loff` = (tau / TB) * F * TB + tau % TB + 4 * hh * TB is the per-lane part (computed
-// once per kernel): no per-store 64-bit VALU address arithmetic.
-template <typename T>
-__device__ __forceinline__ void store_tile_t(T* __restrict__ base, int row0, unsigned loff, const f32x16& x) {
-  constexpr int TB = 16 / sizeof(T);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    T* rowp = base + (row0 + (r & 3) + 8 * (r >> 2)) * TB;
-    float t1[1] = {x[r]};
-    RowIO<T, 1>::store(rowp + loff, t1);
-  }
-}
-
 // ---- packed weight streams -------------------------------------------------------------------------
 // The packed image is two linear streams of equally sized "task" regions laid out in exactly the
 // order the kernels consume them, so staging is a pure sequential copy:
@@ -697,6 +679,7 @@ struct DwArgs {
   const int64_t* sink;   // optional device table [K*2][4] of fp32 gradient addresses {W1, b1, W2, b2}: accumulate there
   int64_t Npad;
   int K, h, H, hp, Hp, HT, HC, nslab, slab_len;
+  int x0_per_step;   // 0: one x0t section shared by all steps (a coupling-only stack never changes x0); 1: one per step
   int64_t nitems;
 };
 
@@ -715,7 +698,7 @@ __global__ void __launch_bounds__(256) k_dw_partial(DwArgs a) {
   constexpr int TB = 16 / sizeof(T);
   const int64_t sA = (int64_t)a.Hp * TB, sB = (int64_t)a.hp * TB;   // elements per token block
   const T* A = reinterpret_cast<const T*>(type == 0 ? a.Gt : a.Ht) + (int64_t)kn * a.Hp * ldn + (32 * mt + r32) * TB;
-  const T* B = (type == 0 ? reinterpret_cast<const T*>(a.x0t)
+  const T* B = (type == 0 ? reinterpret_cast<const T*>(a.x0t) + (a.x0_per_step ? (int64_t)(kn >> 1) * a.hp * ldn : 0)
                           : reinterpret_cast<const T*>(a.dSt) + (int64_t)kn * a.hp * ldn) + r32 * TB;
   const int64_t t0 = (int64_t)slab * a.slab_len;
   int64_t t1 = t0 + a.slab_len;
@@ -1059,7 +1042,7 @@ extern "C" int64_t mivae_nice_dw_workspace_floats(int64_t N, int64_t h, int64_t 
 
 static int nice_dw_impl(const void* Gt, const void* Ht, const void* dSt, const void* x0t,
                         float* workspace, float* dW1, float* db1, float* dW2, float* db2, const int64_t* sink,
-                        int64_t N, int64_t h, int64_t H, int64_t K, int dtype, void* stream) {
+                        int64_t N, int64_t h, int64_t H, int64_t K, int dtype, void* stream, int x0_per_step = 0) {
   MIVAE_REQUIRE(Gt && Ht && dSt && x0t && workspace && (sink || (dW1 && db1 && dW2 && db2)), "nice_dw: null pointer");
   MIVAE_REQUIRE(N >= 1 && h >= 1 && H >= 1 && K >= 1 && K <= 4096, "nice_dw: bad shape");
   MIVAE_REQUIRE(dtype == MIVAE_F32 || dtype == MIVAE_BF16, "nice_dw: bad dtype %d", dtype);
@@ -1076,6 +1059,7 @@ static int nice_dw_impl(const void* Gt, const void* Ht, const void* dSt, const v
   a.partb1 = workspace + a.nitems * (int64_t)g.HT * 1024;
   a.partb2 = a.partb1 + a.nitems * 32;
   a.dW1 = dW1; a.db1 = db1; a.dW2 = dW2; a.db2 = db2; a.sink = sink;
+  a.x0_per_step = x0_per_step;
   int rc = dtype == MIVAE_BF16 ? launch_dw<MmaBF16, unsigned short>(g.HT, a, (hipStream_t)stream)
                                : launch_dw<MmaF32, float>(g.HT, a, (hipStream_t)stream);
   MIVAE_REQUIRE(rc == 0, "nice_dw: no kernel instance");
@@ -1099,4 +1083,12 @@ extern "C" int mivae_nice_dw_sink(const void* Gt, const void* Ht, const void* dS
                                   int64_t K, int dtype, void* stream) {
   MIVAE_REQUIRE(grad_ptrs, "nice_dw_sink: null pointer table");
   return nice_dw_impl(Gt, Ht, dSt, x0t, workspace, nullptr, nullptr, nullptr, nullptr, grad_ptrs, N, h, H, K, dtype, stream);
+}
+
+// mivae_nice_dw for K coupling steps that are NOT consecutive (other flows sit between them and change x0): x0t holds
+// one (hp, Npad) section per step.  Used by the mixed-stack training path (csrc/mixed_stack.hip); same outputs.
+extern "C" int mivae_nice_dw_steps(const void* Gt, const void* Ht, const void* dSt, const void* x0t,
+                                   float* workspace, float* dW1, float* db1, float* dW2, float* db2,
+                                   int64_t N, int64_t h, int64_t H, int64_t K, int dtype, void* stream) {
+  return nice_dw_impl(Gt, Ht, dSt, x0t, workspace, dW1, db1, dW2, db2, nullptr, N, h, H, K, dtype, stream, 1);
 }

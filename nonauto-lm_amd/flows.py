@@ -384,7 +384,7 @@ class _InvLinearBase(Flow):
             out = ops.rowgemm(z.reshape(*lead, heads, hs), w).reshape(*lead, z.size(-1))
         else:       # matrices wider than the MFMA kernel's 512 / other latent dtypes: the library product
             out = torch.matmul(z.reshape(*lead, heads, hs), w.to(z.dtype).t()).reshape(*lead, z.size(-1))
-        logdet = torch.linalg.slogdet(w)[1]
+        logdet = ops.slogdet(w)                       # invertible_flows.py:30-33: torch.slogdet(w)[1]
         if z.dim() > 2:
             cnt = ops.mask_count(mask, z.size(0))        # integer token count (HIP), bit exact
             logdet = logdet * (cnt * heads)
@@ -531,4 +531,60 @@ def mixed_stack_run(flows, z, mask, inverse: bool):
     if const is not None:
         # (sum log_scale) x tokens, slogdet x tokens x heads; a 2-D input counts once
         val = val + (const * ops.mask_count(mask, z.size(0)) if z.dim() == 3 else const)
+    return out, val
+
+
+def mixed_stack_train_run(flows, z, mask):
+    """The density direction of a mixed NICE-FF / ActNorm / invertible-linear list WITH gradients (training): one launch
+    forward, one launch for the z-gradient chain (csrc/mixed_stack.hip), parameter gradients as a fixed handful of
+    reductions (ops._MixedStackTrain).  The parameter-only log-determinants (sum log_scale, slogdet W x heads) x token
+    count are formed here from the live parameters, so autograd differentiates them.  Returns (z', log_det) like the
+    per-flow loop of flow_prior.py:37-52, or None when the list does not qualify (then that loop runs)."""
+    flows = list(flows)
+    if not flows or not z.is_cuda or z.dtype not in (torch.float32, torch.bfloat16) or z.dim() not in (2, 3):
+        return None
+    if (z.dim() == 3 and mask is None) or z.size(-1) % 2 or not torch.is_grad_enabled():
+        return None
+    if all(isinstance(f, NICECoupling) for f in flows) or len(flows) > 24:
+        return None
+    D, three = z.size(-1), z.dim() == 3
+    steps, hidden, scales, mats, heads_of = [], [], [], [], []
+    for flow in flows:
+        if isinstance(flow, NICECoupling):
+            spec = flow.fused_spec(z)
+            if spec is None or D > ops.FUSED_MAX_D:
+                return None
+            params, H, act = spec
+            hidden.append(H)
+            steps.append((ops.MIXED_NICE, H, act, params))
+        elif isinstance(flow, ActNorm):
+            if not flow._is_initted or flow._log_scale.dtype != torch.float32 or flow._input_size != D:
+                return None
+            steps.append((ops.MIXED_ACTNORM, flow._log_scale, flow._bias))
+            scales.append(flow._log_scale)
+        elif isinstance(flow, _InvLinearBase):
+            heads = getattr(flow, "_num_heads", 1)
+            w = flow._weight
+            if w.dtype != torch.float32 or w.size(0) * heads != D:
+                return None
+            steps.append((ops.MIXED_LINEAR, w))
+            mats.append(w)
+            heads_of.append(float(heads) if three else 1.0)       # 2-D inputs: no head factor, like the per-flow modules
+        else:
+            return None
+    if not ops.mixed_stack_train_supported(D, hidden, bool(mats)):
+        return None
+    out, val = ops.mixed_stack_train(z, mask, steps)
+    # parameter-only log-determinants per token: sum log_scale (actnorm.py:35-38), slogdet W x heads
+    # (invertible_flows.py:30-33, :64-66) -- every slogdet of the list in one launch, the scales in one reduction
+    const = None
+    if scales:
+        const = (scales[0] if len(scales) == 1 else torch.cat(scales)).sum()
+    if mats:
+        ld = ops.slogdet_batch(mats)
+        if any(hf != 1.0 for hf in heads_of):
+            ld = ld * torch.tensor(heads_of, dtype=torch.float32).to(ld.device, non_blocking=True)
+        const = ld.sum() if const is None else const + ld.sum()
+    if const is not None:
+        val = val + (const * ops.mask_count(mask, z.size(0)) if three else const)
     return out, val

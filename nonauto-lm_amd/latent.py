@@ -11,7 +11,7 @@ import torch
 import torch.distributions as D
 
 from . import ops
-from .flows import Flow, fused_stack_spec, mixed_stack_run
+from .flows import Flow, fused_stack_spec, mixed_stack_run, mixed_stack_train_run
 from .nn_bracket import Linear, linear_group
 from .registrable import Registrable
 
@@ -137,7 +137,9 @@ class FlowPrior(DefaultPrior):
             return ops.nice_stack(z0, mask, params, H, act, inverse=False, base=True,
                                   mu=float(self.mu), std=float(self.std))
         mixed = mixed_stack_run(self._flows, z0, mask, False) if self.allow_fused else None
-        if mixed is not None:       # no-grad evaluation of a mixed list: one launch
+        if mixed is None and self.allow_fused:       # training: one launch each way + the parameter reductions
+            mixed = mixed_stack_train_run(self._flows, z0, mask)
+        if mixed is not None:       # a mixed list in one launch (no-grad evaluation, or the training path)
             z, total = mixed
             return z, self.masked_log_prob(z, mask, size_average=True) + total
         z = z0

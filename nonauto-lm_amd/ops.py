@@ -1579,6 +1579,56 @@ def rowgemm(x, m):
     return _RowGemm.apply(x2, m).view(x.shape)
 
 
+# ----------------------------------------------------------------------------------- log |det| of the flow matrices
+SLOGDET_MAX = 128
+
+
+class _SlogdetInv(torch.autograd.Function):
+    """log |det M_i| of a list of small square fp32 matrices in ONE launch (mivae_slogdet_inv); the same launch leaves
+    M_i^-T, which IS the gradient, so the backward is one scaling per matrix (the library route: an LU factorisation +
+    ~15 index launches per matrix forward, two triangular solves backward)."""
+
+    @staticmethod
+    def forward(ctx, *mats):
+        import ctypes
+        ms = [m.detach().contiguous() for m in mats]
+        dev = ms[0].device
+        out = torch.empty(len(ms), dtype=torch.float32, device=dev)
+        need = [ctx.needs_input_grad[i] for i in range(len(ms))]
+        inv = [torch.empty_like(m) if g else None for m, g in zip(ms, need)]
+        sizes = (ctypes.c_int64 * len(ms))(*[m.size(0) for m in ms])
+        L.call("mivae_slogdet_inv", _ptr_array(ms), sizes, len(ms), L.ptr(out), _ptr_array(inv), L.stream())
+        ctx.inv = inv
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(None if t is None else g[i] * t for i, t in enumerate(ctx.inv))
+
+
+def slogdet_supported(m) -> bool:
+    return bool(m.is_cuda and m.dtype == torch.float32 and m.dim() == 2 and m.size(0) == m.size(1)
+                and 1 <= m.size(0) <= SLOGDET_MAX)
+
+
+def slogdet_batch(mats: Sequence[torch.Tensor]) -> torch.Tensor:
+    """(len(mats),) fp32: log |det M_i| with gradients (torch.slogdet(M)[1], invertible_flows.py:30-33), up to 24
+    matrices of <= 128 rows per launch."""
+    mats = list(mats)
+    L.require_gpu(*mats)
+    if not all(slogdet_supported(m) for m in mats):
+        raise ValueError("slogdet_batch: square fp32 CUDA matrices of 1..128 rows")
+    outs = [_SlogdetInv.apply(*mats[i:i + 24]) for i in range(0, len(mats), 24)]
+    return outs[0] if len(outs) == 1 else torch.cat(outs)
+
+
+def slogdet(m: torch.Tensor) -> torch.Tensor:
+    """log |det m| (0-d) with gradient: the HIP kernel for fp32 CUDA matrices of <= 128 rows, else torch.linalg.slogdet."""
+    if slogdet_supported(m):
+        return slogdet_batch([m])[0]
+    return torch.linalg.slogdet(m)[1]
+
+
 # ----------------------------------------------------------------------------------- KL / ELBO
 class _KL(torch.autograd.Function):
     @staticmethod
@@ -2168,3 +2218,121 @@ def mixed_stack(z, mask, steps, inverse: bool = False):
     if mask is None:
         return z_out, tok.view(Bn, S)
     return z_out, segment_sum(tok, Bn, S)
+
+
+# ----------------------------------------------------------------------------------- mixed flow stack, training path
+class _MixedStackTrain(torch.autograd.Function):
+    """A mixed NICE-FF / ActNorm / invertible-linear list in the density direction under autograd: ONE launch forward
+    (mivae_mixed_stack_train_fwd, which keeps the input of every step) and ONE launch for the whole z-gradient chain
+    (mivae_mixed_stack_bwd); the parameter gradients are reductions over all tokens and follow as a fixed handful of
+    launches whatever the number of steps: one fold for every ActNorm step together, the split-K pair of
+    csrc/nice_stack.hip for every coupling step together, and one row-slab product + fold per linear step.
+    `meta` = [(kind, H, activation name, head size, number of parameters)] in list order, `params` flat."""
+
+    @staticmethod
+    def forward(ctx, z, mask, meta, *params):
+        Bn, S, D = _shape3(z)
+        N = Bn * S
+        z = z.contiguous()
+        steps, at = [], 0
+        for kind, H, act, hs, cnt in meta:
+            ps = list(params[at:at + cnt])
+            at += cnt
+            steps.append((kind, H, act, ps) if kind == MIXED_NICE else (kind, *ps))
+        plan = MixedPlan(steps)
+        z_out = torch.empty_like(z)
+        tok = torch.empty(Bn, S, dtype=torch.float32, device=z.device)
+        hist = torch.empty(plan.K, N, D, dtype=torch.float32, device=z.device)
+        L.call("mivae_mixed_stack_train_fwd", L.ptr(z), L.ptr(z_out), L.ptr(mask), L.ptr(tok), L.ptr(hist), plan.addr,
+               plan.K, Bn, S, 1, D, L.dtype_code(z.dtype), L.stream())
+        ctx.plan, ctx.meta, ctx.shape = plan, meta, (Bn, S, D, z.dtype)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(hist, mask)
+        return z_out, tok
+
+    @staticmethod
+    def backward(ctx, dz_out, dtok):
+        hist, mask = ctx.saved_tensors
+        plan, meta = ctx.plan, ctx.meta
+        Bn, S, D, dtype = ctx.shape
+        N, h, dev = Bn * S, D // 2, hist.device
+        nice = [i for i, m in enumerate(meta) if m[0] == MIXED_NICE]
+        acts = [i for i, m in enumerate(meta) if m[0] == MIXED_ACTNORM]
+        lins = [i for i, m in enumerate(meta) if m[0] == MIXED_LINEAR]
+        H = meta[nice[0]][1] if nice else 0
+        hp, Hp = (h + 31) // 32 * 32, (H + 31) // 32 * 32
+        npad = L.query("mivae_nice_stack_npad", N)
+        blocks = L.query("mivae_mixed_stack_bwd_blocks", N, D, H, H, int(bool(lins)))
+        f32 = dict(dtype=torch.float32, device=dev)
+        an_part = torch.empty(blocks, len(acts) * 2 * D, **f32) if acts else None
+        gcot = torch.empty(len(lins), N, D, **f32) if lins else None
+        Gt = torch.empty(len(nice), 2, Hp, npad, **f32) if nice else None
+        Ht = torch.empty(len(nice), 2, Hp, npad, **f32) if nice else None
+        dSt = torch.empty(len(nice), 2, hp, npad, **f32) if nice else None
+        x0t = torch.empty(len(nice), hp, npad, **f32) if nice else None
+        dz_in = torch.empty(Bn, S, D, dtype=dtype, device=dev)
+        dlog, per_tok = (None, False) if dtok is None else _tok_cotangent(dtok, Bn, S)
+        dzo = None if dz_out is None else dz_out.contiguous()
+        L.call("mivae_mixed_stack_bwd", L.ptr(hist), L.ptr(dzo), L.ptr(dlog), int(per_tok), L.ptr(mask), plan.addr, plan.K,
+               L.ptr(dz_in), L.ptr(gcot), L.ptr(an_part), L.ptr(Gt), L.ptr(Ht), L.ptr(dSt), L.ptr(x0t), Bn, S, 1, D,
+               L.dtype_code(dtype), L.stream())
+        grads = [None] * sum(m[4] for m in meta)
+        first = [0]
+        for m in meta:
+            first.append(first[-1] + m[4])
+        if acts:
+            folded = colsum(an_part).view(len(acts), 2, D)
+            for j, i in enumerate(acts):
+                grads[first[i]], grads[first[i] + 1] = folded[j, 0], folded[j, 1]
+        for j, i in enumerate(lins):
+            hs = meta[i][3]
+            R = N * (D // hs)
+            nslab = L.query("mivae_rowgemm_wgrad_slabs", R, hs)
+            part = torch.empty(nslab, hs * hs, **f32)
+            L.call("mivae_rowgemm_wgrad", L.ptr(hist[i]), L.ptr(gcot[j]), L.ptr(part), R, hs, L.dtype_code(torch.float32),
+                   L.stream())
+            grads[first[i]] = colsum(part).view(hs, hs)
+        if nice:
+            K = len(nice)
+            ws = torch.empty(L.query("mivae_nice_dw_workspace_floats", N, h, H, K), **f32)
+            dW1, db1 = torch.empty(K, 2, H, h, **f32), torch.empty(K, 2, H, **f32)
+            dW2, db2 = torch.empty(K, 2, h, H, **f32), torch.empty(K, 2, h, **f32)
+            L.call("mivae_nice_dw_steps", L.ptr(Gt), L.ptr(Ht), L.ptr(dSt), L.ptr(x0t), L.ptr(ws), L.ptr(dW1), L.ptr(db1),
+                   L.ptr(dW2), L.ptr(db2), N, h, H, K, L.dtype_code(torch.float32), L.stream())
+            for j, i in enumerate(nice):
+                for net in range(2):
+                    grads[first[i] + 4 * net: first[i] + 4 * net + 4] = [dW1[j, net], db1[j, net], dW2[j, net], db2[j, net]]
+        return (dz_in if ctx.needs_input_grad[0] else None, None, None, *grads)
+
+
+def mixed_stack_train_supported(D: int, hidden: Sequence[int], any_linear: bool) -> bool:
+    """True when the list fits mivae_mixed_stack_bwd: D even <= 128, one coupling hidden width <= 128."""
+    hmax, hmin = (max(hidden), min(hidden)) if hidden else (0, 0)
+    return mixed_stack_supported(D, hmax) and L.query("mivae_mixed_stack_bwd_blocks", 1, int(D), hmax, hmin,
+                                                      int(any_linear)) > 0
+
+
+def mixed_stack_train(z, mask, steps):
+    """mixed_stack() in the density direction WITH gradients for z and every step parameter (steps as for mixed_stack,
+    holding the live fp32 parameters).  Returns (z_out, val) reduced like mixed_stack."""
+    L.require_gpu(z, mask)
+    mask = _mask_i64(mask)
+    Bn, S, D = _shape3(z)
+    meta, flat = [], []
+    for st in steps:
+        if st[0] == MIXED_NICE:
+            meta.append((MIXED_NICE, int(st[1]), st[2], 0, 8))
+            flat += list(st[3])
+        elif st[0] == MIXED_ACTNORM:
+            meta.append((MIXED_ACTNORM, 0, None, 0, 2))
+            flat += [st[1], st[2]]
+        else:
+            meta.append((MIXED_LINEAR, 0, None, int(st[1].size(-1)), 1))
+            flat.append(st[1])
+    z3 = z if z.dim() == 3 else z.unsqueeze(1)
+    z_out, tok = _MixedStackTrain.apply(z3, mask, tuple(meta), *flat)
+    if z.dim() == 2:
+        return z_out.view(Bn, D), tok.view(Bn)
+    if mask is None:
+        return z_out, tok
+    return z_out, _SegmentSum.apply(tok, Bn, S)

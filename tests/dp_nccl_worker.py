@@ -80,10 +80,14 @@ def main():
         reducer.finish()
     torch.cuda.synchronize()
     worst = 0.0
+    # tensor-level max-norm error; the scale of a tensor is floored at 1e-3 of the largest gradient of the model: the
+    # attention key biases have a mathematically ZERO gradient (softmax is shift invariant), what they hold is rounding
+    # noise (~1e-9 of the largest gradient) that changes with the summation order of anything upstream
+    gmax = max(float(g.abs().max()) for g in gref.values())
     for n, p in model.named_parameters():
         if n in gref:
             g = p.grad / world                      # fold_average: the buckets hold the rank SUM
-            den = float(gref[n].abs().max()) + 1e-12
+            den = max(float(gref[n].abs().max()), 1e-3 * gmax)
             worst = max(worst, float((g - gref[n]).abs().max()) / den)
     res["grad_rel_err_vs_full_batch"] = worst
     reducer.zero_grad()

@@ -6,6 +6,8 @@ on flow outputs, log-dets and ELBO; gradients <= 5e-5 (they are sums of O(N) fp3
 in a different but fixed order); integer work bit-exact; bf16 <= 2e-2 on z and <= 1e-2 on
 log-det / log-prob against the fp32 oracle fed the same bf16-rounded inputs.
 """
+import math
+
 import pytest
 import torch
 
@@ -355,6 +357,23 @@ def test_mixed_stack_golden(M):
     with torch.no_grad():
         zi, lpi = prior.backward_pass(zK.detach(), mask)
         assert rel_err(zi, g["inv.zK"]) < TOL and rel_err(lpi, g["inv.logp"]) < TOL
+    # the same gradients through the training path of the one-launch mixed stack (the ActNorm layers are initialised
+    # now, the parameters unchanged): mivae_mixed_stack_train_fwd / _bwd + the parameter reductions
+    calls, real = [], M.ops.mixed_stack_train
+    M.ops.mixed_stack_train = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        for p in prior.parameters():
+            p.grad = None
+        z1 = dev(g["z0"]).clone().requires_grad_(True)
+        zK1, logp1 = prior.forward_pass(z1, mask)
+        (logp1 * dev(g["cot.logp"])).sum().backward()
+    finally:
+        M.ops.mixed_stack_train = real
+    assert len(calls) == 1
+    assert rel_err(zK1, g["fwd.zK"]) < TOL and rel_err(logp1, g["fwd.logp"]) < TOL
+    assert rel_err(z1.grad, g["grad.z0"]) < GTOL
+    for k, p in prior.named_parameters():
+        assert rel_err(p.grad, g["grad.sd." + k]) < GTOL, k
 
 
 # ------------------------------------------------------------------------------------ KL / ELBO
@@ -1948,3 +1967,42 @@ def test_wide_relu_linear_epilogue_matches_separate_ops(M):
         res.append((y, xg.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()))
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------ log |det| of the flow matrices (a14)
+@pytest.mark.parametrize("sizes", [[1], [3, 8], [64], [70, 16, 128], [128] * 5, [2] * 30])
+def test_slogdet_inv_vs_lapack(M, sizes):
+    """mivae_slogdet_inv (torch.slogdet(self._weight)[1] of invertible_flows.py:30-33 and its gradient W^-T, every matrix
+    of a flow list in one launch) against the fp64 LAPACK result on seeded matrices: orthogonal + noise like the flows'
+    initialisation, one badly scaled, negative determinants included.  1e-5 on log|det| (absolute where it is near 0; 4e-5 beyond
+    64 rows), 1e-4 tensor-level on the gradient."""
+    gen = torch.Generator().manual_seed(sum(sizes) + len(sizes))
+    mats = []
+    for i, n in enumerate(sizes):
+        w = torch.linalg.qr(torch.randn(n, n, generator=gen))[0] + 0.1 * torch.randn(n, n, generator=gen)
+        if i % 3 == 1:
+            w = w * torch.logspace(-1, 1, n)[None, :]
+        mats.append(w)
+    ref = [m.double().clone().requires_grad_(True) for m in mats]
+    cot = torch.randn(len(sizes), generator=gen)
+    lr = torch.stack([torch.linalg.slogdet(m)[1] for m in ref])
+    (lr * cot.double()).sum().backward()
+    got = [dev(m).clone().requires_grad_(True) for m in mats]
+    lg = M.ops.slogdet_batch(got)
+    (lg * dev(cot)).sum().backward()
+    err = float((lg.cpu().double() - lr.detach()).abs().max())
+    tol = 1e-5 * max(1.0, float(lr.abs().max())) * (4.0 if max(sizes) > 64 else 1.0)      # fp32 elimination of 128 rows
+    assert err < tol, (err, tol)
+    for a, b in zip(got, ref):
+        assert rel_err(a.grad, b.grad.float()) < 1e-4, rel_err(a.grad, b.grad.float())
+    single = M.ops.slogdet(got[0].detach())
+    assert float(single) == float(lg[0])                 # the same kernel, alone
+
+
+def test_slogdet_falls_back_and_rejects(M):
+    big = torch.eye(130, device=DEV) * 2.0
+    assert abs(float(M.ops.slogdet(big)) - 130 * math.log(2.0)) < 1e-3          # library route beyond 128 rows
+    with pytest.raises(ValueError):
+        M.ops.slogdet_batch([big])
+    sing = torch.zeros(4, 4, device=DEV)
+    assert float(M.ops.slogdet(sing)) == float("-inf")

@@ -222,3 +222,104 @@ def test_mixed_stack_plan_cache_sees_fused_adam_updates(M):
     ref_z, ref_lp = O.flow_prior_inverse(z.cpu(), steps, mask.cpu())
     assert rel_err(after[0], ref_z) < 2e-5 and rel_err(after[1], ref_lp) < 2e-5
     assert not torch.equal(before[0], after[0])
+
+
+# ------------------------------------------------------------------------------------ training path
+def _oracle_steps_grad(prior):
+    """oracle steps on CPU leaf copies of the prior's parameters: (steps, {parameter name: leaf})"""
+    leaves = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in prior.named_parameters()}
+    steps = []
+    for i, f in enumerate(prior._flows):
+        name, pre = type(f).__name__, f"_flows.{i}."
+        if name == "ActNorm":
+            steps.append(lambda z, m, inv, ls=leaves[pre + "_log_scale"], b=leaves[pre + "_bias"]: O.actnorm_step(z, ls, b, m, inv))
+        elif name == "NICECoupling":
+            p = O.NiceParams.from_state_dict(leaves, pre, activation=f._s_net._activation_name)
+            steps.append(lambda z, m, inv, p=p: O.nice_step(z, p, m, inv))
+        else:
+            heads = getattr(f, "_num_heads", 1)
+            steps.append(lambda z, m, inv, w=leaves[pre + "_weight"], heads=heads: O.invlinear_step(z, w, m, inv, heads))
+    return steps, leaves
+
+
+def _count_train_calls(M, monkeypatch):
+    calls = []
+    real = M.ops.mixed_stack_train
+
+    def counted(*a, **k):
+        calls.append(1)
+        return real(*a, **k)
+    monkeypatch.setattr(M.ops, "mixed_stack_train", counted)
+    return calls
+
+
+@pytest.mark.parametrize("D,H,act,heads,layout,B,S", CASES + [(64, 64, "gelu", 4, "nanlnmna", 300, 33)])
+def test_mixed_stack_training_path_vs_oracle(M, monkeypatch, D, H, act, heads, layout, B, S):
+    """FlowPrior.forward_pass of a mixed list UNDER AUTOGRAD (flow_prior.py:37-52 through actnorm.py:30-39,
+    invertible_flows.py:26-33 / :58-66, couplings.py:141-162): mivae_mixed_stack_train_fwd + mivae_mixed_stack_bwd and the
+    parameter reductions against the CPU oracle's autograd -- z_K, log p, d z0 and the gradient of every parameter
+    (fp32: 2e-5 outputs, 1e-4 gradients; the widths cover one and two 32-feature tiles, odd half widths, 4- and 2-wave
+    blocks, ragged lengths with empty sentences, multi-block reductions)."""
+    prior = _build(M, D, H, act, heads, layout, seed=D + H, wstd=0.25 if B < 100 else 0.1)
+    calls = _count_train_calls(M, monkeypatch)
+    gen = torch.Generator().manual_seed(S)
+    z = torch.randn(B, S, D, generator=gen)
+    lengths = torch.randint(0, S + 1, (B,), generator=gen)
+    lengths[0] = S
+    mask = (torch.arange(S)[None, :] < lengths[:, None]).long()
+    cz, cl = torch.randn(B, S, D, generator=gen), torch.randn(B, generator=gen)
+    steps, leaves = _oracle_steps_grad(prior)
+    zr = z.clone().requires_grad_(True)
+    ref_z, ref_lp = O.flow_prior_forward(zr, steps, mask)
+    ((ref_z * cz).sum() + (ref_lp * cl).sum()).backward()
+    zg = z.to(DEV).requires_grad_(True)
+    got_z, got_lp = prior.forward_pass(zg, mask.to(DEV))
+    assert len(calls) == 1, "the training path did not run"
+    assert rel_err(got_z, ref_z) < 2e-5 and rel_err(got_lp, ref_lp) < 2e-5
+    ((got_z * cz.to(DEV)).sum() + (got_lp * cl.to(DEV)).sum()).backward()
+    assert rel_err(zg.grad, zr.grad) < 1e-4, rel_err(zg.grad, zr.grad)
+    worst = {k: rel_err(p.grad, leaves[k].grad) for k, p in prior.named_parameters()}
+    assert max(worst.values()) < 1e-4, sorted(worst.items(), key=lambda kv: -kv[1])[:4]
+
+
+def test_mixed_stack_training_path_two_dim_bf16_and_fallback(M, monkeypatch):
+    calls = _count_train_calls(M, monkeypatch)
+    # 2-D latents (the auto-regressive model's (B, D) code): no mask, parameter log-dets count once
+    prior = _build(M, 32, 48, "gelu", 2, "anlnm", seed=5, wstd=0.08)
+    z = torch.randn(77, 32, generator=torch.Generator().manual_seed(0))
+    steps, leaves = _oracle_steps_grad(prior)
+    zr = z.clone().requires_grad_(True)
+    ref_z, ref_lp = O.flow_prior_forward(zr, steps, None)
+    (ref_z.square().sum() + ref_lp.sum()).backward()
+    zg = z.to(DEV).requires_grad_(True)
+    got_z, got_lp = prior.forward_pass(zg, None)
+    (got_z.square().sum() + got_lp.sum()).backward()
+    assert len(calls) == 1
+    assert rel_err(got_z, ref_z) < 2e-5 and rel_err(got_lp, ref_lp) < 2e-5 and rel_err(zg.grad, zr.grad) < 1e-4
+    worst = {k: rel_err(p.grad, leaves[k].grad) for k, p in prior.named_parameters()}
+    assert max(worst.values()) < 1e-4, worst
+    # bf16 latents: fp32 arithmetic inside, bf16 at the two ends
+    B, S = 4, 21
+    zb = torch.randn(B, S, 32, generator=torch.Generator().manual_seed(1)).bfloat16()
+    mask = torch.ones(B, S, dtype=torch.long)
+    mask[1, 9:] = 0
+    for p in prior.parameters():
+        p.grad = None
+    steps, leaves = _oracle_steps_grad(prior)
+    zr = zb.float().requires_grad_(True)
+    ref_z, ref_lp = O.flow_prior_forward(zr, steps, mask)
+    ref_lp.sum().backward()
+    zg = zb.to(DEV).requires_grad_(True)
+    got_z, got_lp = prior.forward_pass(zg, mask.to(DEV))
+    got_lp.sum().backward()
+    assert len(calls) == 2 and got_z.dtype == torch.bfloat16 and zg.grad.dtype == torch.bfloat16
+    assert rel_err(got_lp, ref_lp) < 1e-2 and rel_err(zg.grad.float(), zr.grad) < 1e-2
+    worst = {k: rel_err(p.grad, leaves[k].grad) for k, p in prior.named_parameters()}
+    assert max(worst.values()) < 1e-2, worst
+    # coupling steps of different hidden widths: the per-flow loop runs, same numbers
+    prior2 = _build(M, 16, 16, "gelu", 2, "ana", seed=1)
+    wide = M.Flow.from_params(type="nice", coupling=dict(type="feed-forward", input_size=8, hidden_sizes=[24])).to(DEV)
+    prior2._flows.append(wide)
+    z2 = torch.randn(3, 7, 16, device=DEV, requires_grad=True)
+    prior2.forward_pass(z2, torch.ones(3, 7, dtype=torch.long, device=DEV))[1].sum().backward()
+    assert len(calls) == 2 and z2.grad is not None

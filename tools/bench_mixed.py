@@ -1,5 +1,7 @@
-"""Timing of a Glow-ordered flow list (ActNorm, inv-linear, NICE) x K in the evaluation direction:
-one-launch mixed stack (csrc/mixed_stack.hip) vs the per-flow launch sets.  Prints one JSON line per shape."""
+"""Timing of a Glow-ordered flow list (ActNorm, inv-linear, NICE) x K: the one-launch mixed stack (csrc/mixed_stack.hip)
+vs the per-flow launch sets, in the evaluation and sampling directions (no gradients) and as a TRAINING step (forward +
+backward of sum(log p) under autograd: the training path of the mixed stack vs per-flow autograd, host-synchronised wall
+time per iteration and kernel launches per iteration counted by the profiler).  Prints one JSON line per shape."""
 import json
 import os
 import sys
@@ -66,4 +68,20 @@ for D, H, K, B, S in SHAPES:
         ev1.record()
         torch.cuda.synchronize()
         out["kernel_plus_segment_sum_us"] = round(ev0.elapsed_time(ev1) / 20 * 1e3, 1)
+    # training step: forward + backward under autograd
+    from torch.profiler import profile, ProfilerActivity
+    zg = z.clone().requires_grad_(True)
+
+    def train_step():
+        for p in prior.parameters():
+            p.grad = None
+        zg.grad = None
+        prior.forward_pass(zg, mask)[1].sum().backward()
+    for name, fused in (("train_mixed", True), ("train_per_flow", False)):
+        prior.allow_fused = fused
+        out[name + "_us"] = round(timed(train_step, 30), 1)
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            train_step()
+            torch.cuda.synchronize()
+        out[name + "_launches"] = sum(1 for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA)
     print(json.dumps({"D": D, "H": H, "flows": 3 * K, "tokens": B * S, **out}))
