@@ -877,8 +877,10 @@ struct NetsArgs {
   const float* dlogp;   // (Bn) or null
   const T* dSdT;        // (K, 2, N, h)
   T* dz_in;             // (N, D): x0 half written here
-  T* hbuf;              // SAVE: (K, 2, N, Hp) hidden activations, token rows of Hp = 32 HC values
-  T* gbuf;              // SAVE: (K, 2, N, Hp) d pre-activation
+  T* hbuf;              // SAVE: (K, 2, HC, N, 32) hidden activations: chunk-major, 64 contiguous bytes per (chunk, token),
+                        //   the 32 units of a chunk in accumulator-pair order (position 8 g + j = unit 4 g + j, j < 4, or
+                        //   16 + 4 g + j - 4): one 16-byte store per lane and body, 1 KiB contiguous per wave instruction
+  T* gbuf;              // SAVE: same layout, d pre-activation
   int64_t N;
   int S, mask_div, D, K, h, H, HC;
   int act, base;
@@ -886,14 +888,12 @@ struct NetsArgs {
 };
 
 // hidden rows of a token no wave computes (dead tile): zeros, so that the weight-gradient products stay finite
-__device__ __forceinline__ void zero_hidden_rows(T* hbuf, T* gbuf, int64_t N, int K, int Hp, int64_t tok, int g) {
+__device__ __forceinline__ void zero_hidden_rows(T* hbuf, T* gbuf, int64_t N, int K, int HC, int64_t tok, int g) {
   const u16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int kn = 0; kn < 2 * K; ++kn) {
-    const int64_t row = ((int64_t)kn * N + tok) * Hp;
-    for (int f = 8 * g; f < Hp; f += 32) {
-      *reinterpret_cast<u16x8*>(hbuf + row + f) = zero;
-      *reinterpret_cast<u16x8*>(gbuf + row + f) = zero;
-    }
+  for (int q = 0; q < 2 * K * HC; ++q) {            // (kn, chunk) sections of (N, 32): the lane's 16-byte piece g
+    const int64_t at = ((int64_t)q * N + tok) * 32 + 8 * g;
+    *reinterpret_cast<u16x8*>(hbuf + at) = zero;
+    *reinterpret_cast<u16x8*>(gbuf + at) = zero;
   }
 }
 
@@ -928,12 +928,12 @@ __global__ void __launch_bounds__(512) k_big_nets(NetsArgs a) {
       const u16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
       T* drow = a.dz_in + tok * a.D;
       for (int f = 8 * g; f < h; f += 32) *reinterpret_cast<u16x8*>(drow + f) = zero;
-      if constexpr (SAVE) zero_hidden_rows(a.hbuf, a.gbuf, a.N, a.K, 32 * HC, tok, g);
+      if constexpr (SAVE) zero_hidden_rows(a.hbuf, a.gbuf, a.N, a.K, HC, tok, g);
     }
     return;
   }
   if constexpr (SAVE) {
-    if (!live && valid) zero_hidden_rows(a.hbuf, a.gbuf, a.N, a.K, 32 * HC, tok, g);
+    if (!live && valid) zero_hidden_rows(a.hbuf, a.gbuf, a.N, a.K, HC, tok, g);
   }
   const bool on = valid && m != 0.f;
   bf16x8 x0f[HT];
@@ -987,7 +987,7 @@ __global__ void __launch_bounds__(512) k_big_nets(NetsArgs a) {
     }
   };
   // stage B: d pre = dh * act'(pre) -> B fragment
-  //          (SAVE: task (j1, c1)'s hidden activations and d pre go to hbuf / gbuf, 4 hidden units = 8 bytes a store)
+  //          (SAVE: task (j1, c1)'s hidden activations and d pre go to hbuf / gbuf, one 16-byte store each)
   auto stage_b = [&](const f32x4 (&pre)[2], const f32x4 (&dh)[2], int j1, int c1) -> bf16x8 {
     f32x4 dlo, dhi;
     if constexpr (SAVE) {
@@ -996,13 +996,9 @@ __global__ void __launch_bounds__(512) k_big_nets(NetsArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) { dlo[r] *= dh[0][r]; dhi[r] *= dh[1][r]; }
       if (valid && j1 < NJ) {
-        const int64_t row = ((int64_t)kn_of(j1) * a.N + tok) * (32 * HC) + 32 * c1 + 4 * g;
-        const float h0[4] = {hlo[0], hlo[1], hlo[2], hlo[3]}, h1[4] = {hhi[0], hhi[1], hhi[2], hhi[3]};
-        const float g0[4] = {dlo[0], dlo[1], dlo[2], dlo[3]}, g1[4] = {dhi[0], dhi[1], dhi[2], dhi[3]};
-        RowIO<T, 4>::store(a.hbuf + row, h0);
-        RowIO<T, 4>::store(a.hbuf + row + 16, h1);
-        RowIO<T, 4>::store(a.gbuf + row, g0);
-        RowIO<T, 4>::store(a.gbuf + row + 16, g1);
+        const int64_t at = (((int64_t)kn_of(j1) * HC + c1) * a.N + tok) * 32 + 8 * g;
+        *reinterpret_cast<bf16x8*>(a.hbuf + at) = pair_to_b(hlo, hhi);
+        *reinterpret_cast<bf16x8*>(a.gbuf + at) = pair_to_b(dlo, dhi);
       }
     } else {
       act_pair_d<ACT>(a.act, pre[0], pre[1], dlo, dhi);
@@ -1463,8 +1459,8 @@ __global__ void __launch_bounds__(512) k_big_dw(DwBigArgs a) {
 struct Dw2Args {
   const T* z_in;        // (N, D)
   const T* dSdT;        // (K, 2, N, h)
-  const T* hbuf;        // (K, 2, N, Hp)
-  const T* gbuf;        // (K, 2, N, Hp)
+  const T* hbuf;        // (K, 2, HC, N, 32): chunk-major, units of a chunk in accumulator-pair order (NetsArgs)
+  const T* gbuf;        // same layout
   float* part;
   float* partb1;
   float* partb2;
@@ -1529,7 +1525,8 @@ __global__ void __launch_bounds__(512) k_big_dw2(Dw2Args a) {
   const int hrow = threadIdx.x >> 4;
   int hsc = (threadIdx.x & 15) ^ swz(hrow);
   if (128 * zb + 8 * hsc >= a.Hp) hsc = 0;
-  const int hcol = (128 * zb + 8 * hsc) * 2;
+  const int hchunk = (128 * zb + 8 * hsc) >> 5;                 // 32-unit chunk of this thread's 8 units
+  const int hcol = ((128 * zb + 8 * hsc) & 31) * 2;             // byte offset inside the chunk's 64-byte token row
   const char* gx = reinterpret_cast<const char*>(a.z_in);
   const char* gg = reinterpret_cast<const char*>(a.dSdT + (int64_t)kn * a.N * h);
   const char* gh = reinterpret_cast<const char*>(a.hbuf + (int64_t)kn * a.N * a.Hp);
@@ -1550,9 +1547,9 @@ __global__ void __launch_bounds__(512) k_big_dw2(Dw2Args a) {
       dma16(tx + ox, bx + u * NTH * 16);
       dma16(tg + og, bx + TILE + u * NTH * 16);
     }
-    const unsigned oh = (unsigned)((hrow <= lastrow ? hrow : lastrow) * a.Hp * 2 + hcol);
-    dma16(gh + t0 * a.Hp * 2 + oh, bx + 2 * TILE);
-    dma16(gd + t0 * a.Hp * 2 + oh, bx + 2 * TILE + HTILE);
+    const int64_t oh = ((int64_t)hchunk * a.N + t0 + (hrow <= lastrow ? hrow : lastrow)) * 64 + hcol;
+    dma16(gh + oh, bx + 2 * TILE);
+    dma16(gd + oh, bx + 2 * TILE + HTILE);
   };
   auto rows_of = [&](int n) -> int {
     if (n >= ntiles) return 0;
@@ -1679,7 +1676,14 @@ struct DwRedArgs {
   float *dW1, *db1, *dW2, *db2;   // (K, 2, H, h), (K, 2, H), (K, 2, h, H), (K, 2, h)
   const int64_t* sink;            // optional device table [K*2][4] of fp32 gradient addresses {W1, b1, W2, b2}: +=
   int K, h, H, HT, HW, nslab;
+  int perm;                       // 1: the 16-unit groups are in accumulator-pair order inside their 32-unit chunk (k_big_dw2)
 };
+// hidden unit of column `col` of 16-unit group `hw`
+__device__ __forceinline__ int dw_unit(int hw, int col, int perm) {
+  if (!perm) return 16 * hw + col;
+  const int p = 16 * (hw & 1) + col, gq = p >> 3, j = p & 7;
+  return 32 * (hw >> 1) + (j < 4 ? 4 * gq + j : 16 + 4 * gq + (j - 4));
+}
 // One thread per dumped accumulator element: sums the slabs in slab order (fixed order => bit-reproducible).
 __global__ void __launch_bounds__(256) k_big_dw_reduce(DwRedArgs a) {
   const int NF = 2 * a.HT;
@@ -1696,7 +1700,7 @@ __global__ void __launch_bounds__(256) k_big_dw_reduce(DwRedArgs a) {
     float s = 0.f;
     for (int sl = 0; sl < a.nslab; ++sl) s += p[sl * per_item];
     const int tt = e >> 8, ln = (e >> 2) & 63, r = e & 3;
-    const int hid = 16 * hw + (ln & 15);
+    const int hid = dw_unit(hw, ln & 15, a.perm);
     const int v = tt % NF;
     const int feat = 16 * v + 4 * (ln >> 4) + r;
     if (hid >= a.H || feat >= a.h) return;
@@ -1715,7 +1719,7 @@ __global__ void __launch_bounds__(256) k_big_dw_reduce(DwRedArgs a) {
     const int64_t q = idx >> 4;
     const int hw = (int)(q % a.HW);
     const int kn = (int)(q / a.HW);
-    const int hid = 16 * hw + col;
+    const int hid = dw_unit(hw, col, a.perm);
     if (hid >= a.H) return;
     const float* p = a.partb1 + (((int64_t)kn * a.HW + hw) * a.nslab) * 16 + col;
     float s = 0.f;
@@ -2010,6 +2014,7 @@ extern "C" int mivae_nice_big_bwd(const void* z_in, const void* z_out, const voi
     r.K = (int)K; r.h = g.h; r.H = g.H; r.HT = g.HT; r.HW = a.HW; r.nslab = a.nslab;
     // the sink table is [K][8] = {W1s,b1s,W2s,b2s,W1t,b1t,W2t,b2t}: exactly [kn][4] with kn = 2k + net
     r.sink = grad_ptrs;
+    r.perm = hidden ? 1 : 0;
     const int64_t nthreads = (int64_t)K * 2 * a.HW * 4 * g.HT * 256 + (int64_t)K * 2 * a.HW * 16 + (int64_t)K * 2 * 2 * g.HT * 16;
     k_big_dw_reduce<<<(unsigned)((nthreads + 255) / 256), 256, 0, st>>>(r);
     MIVAE_CHECK_LAUNCH("nice_big_dw_reduce");

@@ -6,6 +6,8 @@ Every numeric result on this path comes from a hand-written HIP kernel; inputs m
 import math
 from typing import Optional, Sequence, Tuple
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -2053,7 +2055,7 @@ def nice_big_pack_multi(params: Sequence[torch.Tensor], K: int, h: int, H: int, 
 # and d s / d t (k_big_dw, no extra memory); "auto": save when D/2 > 128 -- there the recompute kernel needs two passes
 # (register budget) and saving wins (C5: nets + dW 4.8 ms vs 6.2 ms), while at D/2 <= 128 the extra 2 x K 2 N Hp HBM
 # round trip costs more than the recompute it removes (C3: 952 us vs 886 us).
-NICE_BIG_SAVE_HIDDEN = "auto"
+NICE_BIG_SAVE_HIDDEN = {"0": False, "1": True}.get(os.environ.get("MIVAE_BIG_SAVE", ""), "auto")   # env: A/B runs
 
 
 def _nice_big_save_hidden(h: int) -> bool:
