@@ -236,10 +236,18 @@ def flow_kernel_times(model, tokens, dtype, reps=50, graph=True, family="nonauto
                                           L.ptr(per_seq), L.ptr(aux[0]), L.ptr(aux[1]), L.ptr(lce_ws), B, S, E, V, 0.0, L.stream()),
                 "lce_bwd": lambda: L.call("mivae_lce_bwd", L.ptr(hdec), L.ptr(w16), L.ptr(tokens), L.ptr(aux[0]),
                                           L.ptr(aux[1]), L.ptr(dper), L.ptr(dl16), B, S, E, V, 0.0, L.stream()),
-                "lce_bwd_dh": lambda: L.call("mivae_lce_bwd_dh", L.ptr(hdec), L.ptr(w16), L.ptr(wt16), L.ptr(tokens), L.ptr(aux[0]),
-                                             L.ptr(aux[1]), L.ptr(dper), L.ptr(dl16), L.ptr(dh_ws), L.ptr(dh16), B, S, E, V, 0.0,
-                                             L.stream()),
             })
+            # the training step's route: d W / d b from mivae_lce_dw (recomputed tiles), so the token-major pass writes no
+            # (N, V) gradient; without that kernel (E > 64) the pass also stores d logits for a library product
+            dw_slabs = L.query("mivae_lce_dw_slabs", N, E, V) if ops.LCE_RECOMPUTE_DW else 0
+            dl_arg = None if dw_slabs else dl16
+            calls["lce_bwd_dh"] = lambda: L.call("mivae_lce_bwd_dh", L.ptr(hdec), L.ptr(w16), L.ptr(wt16), L.ptr(tokens),
+                                                 L.ptr(aux[0]), L.ptr(aux[1]), L.ptr(dper), L.ptr(dl_arg), L.ptr(dh_ws),
+                                                 L.ptr(dh16), B, S, E, V, 0.0, L.stream())
+            if dw_slabs:
+                dw_part = torch.empty(dw_slabs, V, E + 8, dtype=torch.float32, device=dev)
+                calls["lce_dw"] = lambda: L.call("mivae_lce_dw", L.ptr(hdec), L.ptr(w16), L.ptr(tokens), L.ptr(aux[0]),
+                                                 L.ptr(aux[1]), L.ptr(dper), L.ptr(dw_part), B, S, E, V, 0.0, L.stream())
         calls.update({
             "nll_fwd": lambda: L.call("mivae_nll_fwd", L.ptr(logits), L.ptr(tokens), L.ptr(w), L.ptr(per_seq), L.ptr(aux[0]),
                                       L.ptr(aux[1]), L.ptr(aux[2]), B, S, V, 0.0, code, L.stream()),
@@ -340,17 +348,22 @@ def kernel_rooflines(name, model, tokens, kern, hbm_measured):
         "nll_bwd": (n_real + N) * VOCAB * e + 16 * N,
         "lce_fwd": N * D * 2 + VOCAB * D * 2 + 32 * N,
         "lce_bwd": N * VOCAB * 2 + N * D * 2 + VOCAB * D * 2 + 16 * N,
-        "lce_bwd_dh": N * VOCAB * 2 + N * D * 2 + 2 * VOCAB * D * 2 + 16 * N + N * D * 2,
+        # with mivae_lce_dw in the step the token-major pass stores no (N, V) gradient: h, W, W^T in, d h out
+        "lce_bwd_dh": (0 if "lce_dw" in kern else N * VOCAB * 2) + N * D * 2 + 2 * VOCAB * D * 2 + 16 * N + N * D * 2,
+        "lce_dw": N * D * 2 + VOCAB * D * 2 + 16 * N + VOCAB * (D + 1) * 4,
         # mu, pre-sigma in, z and sigma out (noise drawn in-kernel) + per-token log q; backward: dz, pre in, d mu, d pre out
         "reparam_fwd": 4 * n_real * D * e + mask_bytes + 4 * N,
         "reparam_bwd": 4 * n_real * D * e + mask_bytes,
     }
     flops = {"nll_fwd": 0, "nll_bwd": 0, "lce_fwd": 2 * N * VOCAB * D, "lce_bwd": 2 * N * VOCAB * D,
-             "lce_bwd_dh": 4 * N * VOCAB * D, "reparam_fwd": 0, "reparam_bwd": 0,
+             # logits recompute + the d h (d W) product: 2 N V E flops each
+             "lce_bwd_dh": 4 * N * VOCAB * D, "lce_dw": 4 * N * VOCAB * D, "reparam_fwd": 0, "reparam_bwd": 0,
              # one step = 2 nets x 2 GEMMs x 2 h H flops per REAL token; the backward's algorithmic count is twice the
              # forward's (d input + d weight per GEMM); recomputed activations are not algorithmic
              "nice_stack_fwd": 4 * K * n_real * D * H, "nice_stack_bwd_total": 8 * K * n_real * D * H}
     in_step = {"nll_fwd", "nll_bwd"} if not fused_lce else {"lce_fwd", "lce_bwd_dh" if ops.LCE_FUSED_DH else "lce_bwd"}
+    if fused_lce and "lce_dw" in kern:
+        in_step.add("lce_dw")
     mfma_peak = MFMA_PEAK_TFLOPS[dtype_name]
 
     def roof(label, pmc_keys, us_k, by, fl, note=None):
@@ -374,7 +387,7 @@ def kernel_rooflines(name, model, tokens, kern, hbm_measured):
             blk["note"] = note
         return blk
 
-    skip = {"nll_fwd", "nll_bwd", "lce_fwd", "lce_bwd", "lce_bwd_dh"} - in_step
+    skip = {"nll_fwd", "nll_bwd", "lce_fwd", "lce_bwd", "lce_bwd_dh", "lce_dw"} - in_step
     blocks = {}
     for k in kern:
         if k in ("nice_stack_bwd", "nice_dw") or k in skip or k not in algo:

@@ -444,6 +444,17 @@ int64_t mivae_lce_dh_workspace_floats(int64_t N, int64_t E, int64_t V);
 int mivae_lce_bwd_dh(const void* h, const void* W, const void* Wtp, const int64_t* target, const float* lse,
                      const float* tokscale, const float* dper_seq, void* dlogits, float* workspace, void* dh,
                      int64_t Bn, int64_t S, int64_t E, int64_t V, float smoothing, void* stream);
+/* d W = dlogits^T h and d bias = dlogits^T 1 of the same chain (autograd of the vocabulary projection w.r.t. its
+ * parameters, nonauto_lm/model.py:105 under trainer.py:284) WITHOUT a stored dlogits: a block owns 64 vocabulary rows
+ * and a share of the tokens, recomputes the logits tiles from h and W, forms the bf16 dlogits of mivae_lce_bwd in
+ * registers and contracts them with h on the matrix cores.  part (slabs, V, E + 8) fp32 with slabs =
+ * mivae_lce_dw_slabs(Bn*S, E, V) (0: shape not supported; E in {32, 64}): [d W | d bias | 7 unused columns] per token
+ * split, summed over the slab axis by mivae_fold_aug_sink (A = 8) or mivae_colsum.  With it mivae_lce_bwd_dh may be
+ * called with dlogits = NULL (E <= 64): the (N, V) gradient is then neither written nor read. */
+int64_t mivae_lce_dw_slabs(int64_t N, int64_t E, int64_t V);
+int mivae_lce_dw(const void* h, const void* W, const int64_t* target, const float* lse, const float* tokscale,
+                 const float* dper_seq, float* part, int64_t Bn, int64_t S, int64_t E, int64_t V, float smoothing,
+                 void* stream);
 
 /* ---- token-parallel small Linear layers ---------------------------------------------------------------- */
 /* torch.nn.Linear over many tokens and few features, bf16 operands, fp32 accumulation on the matrix cores: the

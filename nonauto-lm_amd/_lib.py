@@ -107,6 +107,8 @@ SIGNATURES = {
     "mivae_lce_pack2": [P, P, P, P, I64, I64, P],
     "mivae_lce_dh_workspace_floats": [I64, I64, I64],
     "mivae_lce_bwd_dh": [P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P],
+    "mivae_lce_dw_slabs": [I64, I64, I64],
+    "mivae_lce_dw": [P, P, P, P, P, P, P, I64, I64, I64, I64, F32, P],
     "mivae_maf_affine_fwd": [P, P, P, P, P, I64, I64, I32, I32, P],
     "mivae_maf_affine_bwd": [P, P, P, P, P, P, P, I64, I64, I32, I32, P],
     "mivae_maf_sequential_supported": [I64, I64],
@@ -155,6 +157,7 @@ _RET = {
     "mivae_layernorm_bwd_partial_add": I64,
     "mivae_layernorm_bwd_partial_add_twin": I64,
     "mivae_lce_dh_workspace_floats": I64,
+    "mivae_lce_dw_slabs": I64,
     "mivae_linear_wgrad_rows": I64,
     "mivae_layernorm_workspace_floats": I64,
     "mivae_nice_stack_npad": I64,

@@ -664,14 +664,16 @@ __global__ __launch_bounds__(256) void k_lce_bwd_s(LceArgs a) {
   if (p1 > npair) p1 = npair;
   const int orow = lane >> 3, ocol = (lane & 7) * 8;
   const bool live = __any(coef != 0.f) != 0;                 // wave-uniform; tiles past N are not live either
+  const bool store_dl = a.dlogits != nullptr;                // null: d h only (the d W product recomputes, k_lce_dw)
   if (!live) {                                               // padding tile: zero gradient rows, nothing read
     const u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int p = p0; p < p1; ++p)
+    if (store_dl)
+      for (int p = p0; p < p1; ++p)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int64_t row = tok0 + orow + 8 * i;
-        if (row < a.N) *reinterpret_cast<u16x8*>(a.dlogits + row * a.V + 64 * p + ocol) = z;
-      }
+        for (int i = 0; i < 4; ++i) {
+          const int64_t row = tok0 + orow + 8 * i;
+          if (row < a.N) *reinterpret_cast<u16x8*>(a.dlogits + row * a.V + 64 * p + ocol) = z;
+        }
     if (DH) {
       const f32x4 zf = {0.f, 0.f, 0.f, 0.f};
       for (int idx = lane; idx < 32 * (E / 4); idx += 64) {
@@ -736,7 +738,7 @@ __global__ __launch_bounds__(256) void k_lce_bwd_s(LceArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
               o[i] = f32_to_bf16(__uint_as_float(__float_as_uint(ex2(fmaf(x[4 * q + i], kLog2e, c0))) ^ sgn));
-            *reinterpret_cast<u16x4*>(stage + r32 * kLceStride + 32 * u + 8 * q + 4 * hh) = o;
+            if (store_dl) *reinterpret_cast<u16x4*>(stage + r32 * kLceStride + 32 * u + 8 * q + 4 * hh) = o;
             ov[q] = o;
           }
         } else {
@@ -750,7 +752,7 @@ __global__ __launch_bounds__(256) void k_lce_bwd_s(LceArgs a) {
               if (rel == i + 8 * q) g -= hot;
               o[i] = f32_to_bf16(g);
             }
-            *reinterpret_cast<u16x4*>(stage + r32 * kLceStride + 32 * u + 8 * q + 4 * hh) = o;
+            if (store_dl) *reinterpret_cast<u16x4*>(stage + r32 * kLceStride + 32 * u + 8 * q + 4 * hh) = o;
             ov[q] = o;
           }
         }
@@ -769,13 +771,15 @@ __global__ __launch_bounds__(256) void k_lce_bwd_s(LceArgs a) {
           }
         }
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_wave_barrier();
+      if (store_dl) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = orow + 8 * i;
-        const u16x8 v = *reinterpret_cast<const u16x8*>(stage + row * kLceStride + ocol);
-        if (tok0 + row < a.N) *reinterpret_cast<u16x8*>(a.dlogits + (tok0 + row) * a.V + 64 * p + ocol) = v;
+        for (int i = 0; i < 4; ++i) {
+          const int row = orow + 8 * i;
+          const u16x8 v = *reinterpret_cast<const u16x8*>(stage + row * kLceStride + ocol);
+          if (tok0 + row < a.N) *reinterpret_cast<u16x8*>(a.dlogits + (tok0 + row) * a.V + 64 * p + ocol) = v;
+        }
       }
     }
     if (p + 1 < p1) commit(b ^ 1);
@@ -801,6 +805,236 @@ __global__ __launch_bounds__(256) void k_lce_dh_combine(const float* __restrict_
   for (int v = 1; v < VSB; ++v) s += *reinterpret_cast<const f32x4*>(partial + (int64_t)v * NE + i);
   const u16x4 o = {f32_to_bf16(s[0]), f32_to_bf16(s[1]), f32_to_bf16(s[2]), f32_to_bf16(s[3])};
   *reinterpret_cast<u16x4*>(dh + i) = o;
+}
+
+// ---- d W, d b of the fused projection + NLL without the (N, V) d logits ------------------------------------------
+// Vocabulary-major: a block owns one chunk pair (64 vocabulary rows; its W fragments stay in registers) and a share of
+// the token tiles; every wave walks its tiles, RECOMPUTES the logits tile transposed (rows = tokens in the accumulator
+// registers, columns = vocabulary on the lanes: the same two operands of k_lce_bwd_s with their roles swapped), forms
+// the bf16 d logits exactly as that kernel does, and contracts them with h over the tokens -- the accumulator tile is
+// the B fragment (contraction index = accumulator row), h^T comes out of the wave's LDS copy of the h tile through the
+// transposing read in the same permuted token order.  d W^T (E x 64) and d b accumulate in registers over all tiles; the
+// four waves are combined through LDS in wave order and the block writes one partial per token split: part (TS, V, E + 8)
+// with d b in column E (the layout mivae_fold_aug_sink folds).  The 268 MB (C2) d logits tensor is neither written by
+// the backward pass nor read by a GEMM.
+struct LceDwArgs {
+  const unsigned short* h;
+  const unsigned short* W;      // packed (k_lce_pack)
+  const int64_t* target;
+  const float* lse;
+  const float* tokscale;
+  const float* dper;
+  float* part;                  // (TS, V, E + 8)
+  int64_t N;
+  int S, V, tiles_per_split;
+  float smoothing;
+};
+
+// f[j] = tile[16 s + 8 (j >> 2) + 4 hh + (j & 3)][fbase + r32]: the accumulator-row order of MmaBF16::from_acc<s>
+__device__ __forceinline__ lce_bf16x8 lce_tr_frag_perm(const unsigned short* tile, int stride, int fbase, int s, int lane) {
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+  const unsigned short* a0 = tile + (16 * s + 4 * (g >> 1) + q) * stride + fbase + 16 * (g & 1) + 4 * p;
+  typedef __attribute__((address_space(3))) bf16x4_tr* lds_ptr;
+  const bf16x4_tr v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(a0));
+  const bf16x4_tr v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(a0 + 8 * stride));
+  return __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int NKS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_lce_dw(LceDwArgs a) {
+  constexpr int NF = NKS + 1;
+  constexpr int E = 16 * NKS, EB = (E + 31) / 32;
+  constexpr int HST = E + 8;                                 // h tile row stride (elements)
+  constexpr int WB = 2 * NF * 1024;                          // bytes of W fragments per chunk pair
+  constexpr int ACC = EB * 2 * 16;                           // accumulator registers per lane
+  __shared__ __attribute__((aligned(16))) float red[2 * ACC * 64 + 2 * 2 * 64];   // wave-pair reduction (32 KiB at E = 64)
+  __shared__ __attribute__((aligned(16))) float tokc[4][3][32];
+  unsigned short* htile = reinterpret_cast<unsigned short*>(red) + (threadIdx.x >> 6) * (32 * HST);   // aliases `red`
+  const int lane = threadIdx.x & 63, r32 = lane & 31, hh = lane >> 5;
+  const int wave = threadIdx.x >> 6;
+  const int p = blockIdx.x, ts = blockIdx.y;
+  lce_bf16x8 wf[2][NF];
+  {
+    const char* wsrc = reinterpret_cast<const char*>(a.W) + (int64_t)p * WB;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int ks = 0; ks < NF; ++ks)
+        wf[u][ks] = *reinterpret_cast<const lce_bf16x8*>(wsrc + ((u * NF + ks) * 64 + lane) * 16);
+  }
+  f32x16 dW[EB][2];
+  float db[2] = {0.f, 0.f};
+#pragma unroll
+  for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dW[eb][u][r] = 0.f;
+  const bool smooth = a.smoothing > 0.f;
+  const float usc = smooth ? a.smoothing / (float)a.V : 0.f, hsc = smooth ? 1.f - a.smoothing : 1.f;
+  const int64_t ntiles = (a.N + 31) / 32;
+  const int64_t t0 = (int64_t)ts * a.tiles_per_split;
+  int64_t t1 = t0 + a.tiles_per_split;
+  if (t1 > ntiles) t1 = ntiles;
+  // the next tile's operands are requested while the current tile is being processed (two waves per SIMD do not hide
+  // a global round trip per tile on their own)
+  lce_bf16x8 hn[NKS];
+  float coef_n = 0.f, lse_n = 0.f;
+  int t_n = -1;
+  const u16x8 one_raw = {0x3F80, 0x3F80, 0, 0, 0, 0, 0, 0}, zero_raw = {0, 0, 0, 0, 0, 0, 0, 0};
+  const lce_bf16x8 hbias = __builtin_bit_cast(lce_bf16x8, hh == 0 ? one_raw : zero_raw);   // the [1, 1, 0, ...] bias column
+  auto request = [&](int64_t tile) {
+    const int64_t tok = tile * 32 + r32;
+    const bool valid = tile < t1 && tok < a.N;
+    const unsigned short* hp = a.h + (valid ? tok : 0) * E + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) hn[ks] = *reinterpret_cast<const lce_bf16x8*>(hp + 16 * ks);
+    coef_n = valid ? a.dper[tok / a.S] * a.tokscale[tok] : 0.f;
+    lse_n = valid ? a.lse[tok] : 0.f;
+    t_n = valid ? (int)a.target[tok] : -1;
+  };
+  request(t0 + wave);
+  for (int64_t tile = t0 + wave; tile < t1; tile += 4) {
+    lce_bf16x8 hf[NF];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) hf[ks] = hn[ks];
+    hf[NKS] = hbias;
+    const float coef = coef_n, lse = lse_n;
+    const int t = t_n;
+    request(tile + 4);
+    if (__any(coef != 0.f) == 0) continue;                   // padding tile: contributes nothing (wave-uniform)
+    // per-token scalars and the h tile through the wave's LDS area
+    if (hh == 0) {
+      tokc[wave][0][r32] = coef != 0.f ? __builtin_amdgcn_logf(fabsf(coef)) - lse * kLog2e : -INFINITY;
+      tokc[wave][1][r32] = coef;
+      tokc[wave][2][r32] = __int_as_float(t);
+    }
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+      *reinterpret_cast<lce_bf16x8*>(htile + r32 * HST + 16 * ks + 8 * hh) = hf[ks];
+    const bool slow = smooth || (__any((t >> 6) == p) != 0);
+    const bool negs = __any(coef < 0.f) != 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    lce_bf16x8 hT[EB][2];
+#pragma unroll
+    for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) hT[eb][s2] = lce_tr_frag_perm(htile, HST, 32 * eb, s2, lane);
+    f32x4 c0v[4];                                            // rows 8 q + 4 hh + {0..3} of this lane's accumulator
+    unsigned sgn = 0;                                        // bit r: coef of accumulator row r is negative
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      c0v[q] = *reinterpret_cast<const f32x4*>(&tokc[wave][0][8 * q + 4 * hh]);
+      const f32x4 cf = *reinterpret_cast<const f32x4*>(&tokc[wave][1][8 * q + 4 * hh]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sgn |= (__float_as_uint(cf[i]) >> 31) << (4 * q + i);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      f32x16 x;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < NF; ++ks) x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf[ks], wf[u][ks], x, 0, 0, 0);
+      const int v = 64 * p + 32 * u + r32;                   // this lane's vocabulary row
+      typedef float f32x2g __attribute__((ext_vector_type(2)));
+      typedef __bf16 bf16x2g __attribute__((ext_vector_type(2)));
+      typedef unsigned u32x4g __attribute__((ext_vector_type(4)));
+      u32x4g bw[2];
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        float g2[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          float g = ex2(fmaf(x[r + i], kLog2e, c0v[(r + i) >> 2][(r + i) & 3]));
+          if (negs)                                          // (wave-uniform) a negative cotangent in this tile: rare
+            g = __uint_as_float(__float_as_uint(g) ^ ((sgn >> (r + i)) << 31));
+          if (slow) {                                        // (wave-uniform) smoothing, or a target inside this pair
+            const int row = 8 * ((r + i) >> 2) + 4 * hh + ((r + i) & 3);
+            const float cf = tokc[wave][1][row];
+            g -= cf * usc;
+            if (__float_as_int(tokc[wave][2][row]) == v) g -= cf * hsc;
+          }
+          sum += g;                                          // d b from the unrounded values (fp32)
+          g2[i] = g;
+        }
+        const f32x2g pr = {g2[0], g2[1]};
+        bw[r >> 3][(r & 7) >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, bf16x2g));   // v_cvt_pk_bf16_f32
+      }
+      db[u] += sum;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const lce_bf16x8 bfr = __builtin_bit_cast(lce_bf16x8, bw[s2]);
+#pragma unroll
+        for (int eb = 0; eb < EB; ++eb) dW[eb][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hT[eb][s2], bfr, dW[eb][u], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();                         // the tile area is rewritten by the next iteration
+  }
+  // d b: the two lane halves hold the rows 4 hh + ... of the same column
+#pragma unroll
+  for (int u = 0; u < 2; ++u) db[u] += __shfl_xor(db[u], 32, 64);
+  // combine the four waves in fixed order: (0 + 2), (1 + 3), then (0 + 1)
+  __syncthreads();                                           // every wave is done with its h tile (aliases red)
+  float* slot = red + (wave & 1) * (ACC * 64) + lane;
+  float* dslot = red + 2 * ACC * 64 + (wave & 1) * 128 + lane;
+  if (wave >= 2) {
+#pragma unroll
+    for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slot[((eb * 2 + u) * 16 + r) * 64] = dW[eb][u][r];
+    dslot[0] = db[0]; dslot[64] = db[1];
+  }
+  __syncthreads();
+  if (wave < 2) {
+#pragma unroll
+    for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dW[eb][u][r] += slot[((eb * 2 + u) * 16 + r) * 64];
+    db[0] += dslot[0]; db[1] += dslot[64];
+  }
+  __syncthreads();
+  if (wave == 1) {
+#pragma unroll
+    for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((eb * 2 + u) * 16 + r) * 64 + lane] = dW[eb][u][r];
+    red[2 * ACC * 64 + lane] = db[0]; red[2 * ACC * 64 + 64 + lane] = db[1];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  float* P = a.part + ((int64_t)ts * a.V) * (E + 8);
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    float* row = P + (int64_t)(64 * p + 32 * u + r32) * (E + 8);
+#pragma unroll
+    for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = dW[eb][u][4 * q + i] + red[((eb * 2 + u) * 16 + 4 * q + i) * 64 + lane];
+        if (32 * eb + 8 * q + 4 * hh < E) *reinterpret_cast<f32x4*>(row + 32 * eb + 8 * q + 4 * hh) = o;
+      }
+    if (hh == 0) row[E] = db[u] + red[2 * ACC * 64 + 64 * u + lane];
+  }
+}
+
+// token splits of mivae_lce_dw: ~512 blocks of 4 waves (two resident per CU)
+static int lce_dw_splits(int64_t N, int64_t V) {
+  const int64_t pairs = V / 64, tiles = (N + 31) / 32;
+  int64_t tsn = (512 + pairs - 1) / pairs;
+  if (tsn > tiles / 4) tsn = tiles / 4;
+  if (tsn > 16) tsn = 16;
+  return tsn < 1 ? 1 : (int)tsn;
 }
 
 int lce_check(const char* name, int64_t Bn, int64_t S, int64_t E, int64_t V, float smoothing) {
@@ -943,15 +1177,16 @@ extern "C" int64_t mivae_lce_dh_workspace_floats(int64_t N, int64_t E, int64_t V
 }
 
 // mivae_lce_bwd that also produces d h (N, E) bf16 = dlogits W in the same pass (Wtp from mivae_lce_pack2,
-// workspace of mivae_lce_dh_workspace_floats(N, E, V) floats); dlogits is still written for the d W product.
+// workspace of mivae_lce_dh_workspace_floats(N, E, V) floats); dlogits is written for a d W product on it, or NULL
+// (E <= 64) when d W comes from mivae_lce_dw.
 extern "C" int mivae_lce_bwd_dh(const void* h, const void* W, const void* Wtp, const int64_t* target, const float* lse,
                                 const float* tokscale, const float* dper_seq, void* dlogits, float* workspace, void* dh,
                                 int64_t Bn, int64_t S, int64_t E, int64_t V, float smoothing, void* stream) {
   int rc = lce_check("lce_bwd_dh", Bn, S, E, V, smoothing);
   if (rc) return rc;
   if (Bn == 0) return MIVAE_OK;
-  MIVAE_REQUIRE(h && W && Wtp && target && lse && tokscale && dper_seq && dlogits && workspace && dh,
-                "lce_bwd_dh: null pointer");
+  MIVAE_REQUIRE(h && W && Wtp && target && lse && tokscale && dper_seq && workspace && dh, "lce_bwd_dh: null pointer");
+  MIVAE_REQUIRE(dlogits || E <= 64, "lce_bwd_dh: d logits may be omitted for E <= 64 only");
   MIVAE_REQUIRE(aligned16(h) && aligned16(W) && aligned16(Wtp) && aligned16(dlogits) && aligned16(workspace) &&
                 aligned16(dh), "lce_bwd_dh: operands must be 16-byte aligned");
   const int64_t N = Bn * S;
@@ -972,5 +1207,39 @@ extern "C" int mivae_lce_bwd_dh(const void* h, const void* W, const void* Wtp, c
   MIVAE_CHECK_LAUNCH("lce_bwd_dh");
   k_lce_dh_combine<<<(unsigned)((N * E / 4 + 255) / 256), 256, 0, st>>>(workspace, (unsigned short*)dh, N * E, VSB);
   MIVAE_CHECK_LAUNCH("lce_dh_combine");
+  return MIVAE_OK;
+}
+
+// number of partial slabs mivae_lce_dw writes (the G of mivae_fold_aug_sink); 0 when the shape is not supported
+extern "C" int64_t mivae_lce_dw_slabs(int64_t N, int64_t E, int64_t V) {
+  if (N <= 0 || V < 64 || V % 64 || (E != 32 && E != 64)) return 0;
+  return lce_dw_splits(N, V);
+}
+
+// part (slabs, V, E + 8) fp32: per token split the partial [d W | d b | 7 unused columns] of the fused projection + NLL,
+// d W = d logits^T h, d b = d logits^T 1 with the bf16 d logits of mivae_lce_bwd recomputed tile by tile (never stored).
+// Sum over the slab axis (mivae_fold_aug_sink / mivae_colsum) = the gradients.  E in {32, 64}.
+extern "C" int mivae_lce_dw(const void* h, const void* W, const int64_t* target, const float* lse, const float* tokscale,
+                            const float* dper_seq, float* part, int64_t Bn, int64_t S, int64_t E, int64_t V,
+                            float smoothing, void* stream) {
+  int rc = lce_check("lce_dw", Bn, S, E, V, smoothing);
+  if (rc) return rc;
+  if (E != 32 && E != 64) {
+    mivae_set_error("lce_dw: E must be 32 or 64 (got %lld)", (long long)E);
+    return MIVAE_EUNSUPPORTED;
+  }
+  MIVAE_REQUIRE(Bn >= 1, "lce_dw: empty batch");
+  MIVAE_REQUIRE(h && W && target && lse && tokscale && dper_seq && part, "lce_dw: null pointer");
+  MIVAE_REQUIRE(aligned16(h) && aligned16(W) && aligned16(part), "lce_dw: operands must be 16-byte aligned");
+  const int64_t N = Bn * S;
+  LceDwArgs a = {};
+  a.h = (const unsigned short*)h; a.W = (const unsigned short*)W; a.target = target; a.lse = lse; a.tokscale = tokscale;
+  a.dper = dper_seq; a.part = part; a.N = N; a.S = (int)S; a.V = (int)V; a.smoothing = smoothing;
+  const int TS = lce_dw_splits(N, V);
+  a.tiles_per_split = (int)(((N + 31) / 32 + TS - 1) / TS);
+  dim3 grid((unsigned)(V / 64), (unsigned)TS);
+  if (E == 32) k_lce_dw<2><<<grid, 256, 0, S_(stream)>>>(a);
+  else k_lce_dw<4><<<grid, 256, 0, S_(stream)>>>(a);
+  MIVAE_CHECK_LAUNCH("lce_dw");
   return MIVAE_OK;
 }

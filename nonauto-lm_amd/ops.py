@@ -1833,28 +1833,50 @@ class _LinearNLL(torch.autograd.Function):
     def backward(ctx, dper):
         h2, w16, wp, tgt, aux = ctx.saved_tensors
         Bn, S, E, V, smoothing, hshape, hdtype, wdtype, has_bias = ctx.meta
-        dl = torch.empty(Bn * S, V, dtype=torch.bfloat16, device=h2.device)
+        N = Bn * S
+        dpc = dper.contiguous().float()
+        want_dh, want_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        want_db = has_bias and ctx.needs_input_grad[2]
+        wpar, bpar = ctx.params
+        # d W / d b without a stored (N, V) gradient: mivae_lce_dw recomputes the logits tiles per 64 vocabulary rows and
+        # contracts the bf16 d logits with h in registers.  Then the token-major pass only has to produce d h.
+        slabs = L.query("mivae_lce_dw_slabs", N, E, V) if (LCE_RECOMPUTE_DW and want_dw and want_db) else 0
+        fused_dh = ctx.wtp is not None and want_dh
+        need_dl = slabs == 0 and (want_dw or want_db)
+        dl = None
+        if need_dl or (want_dh and not fused_dh):
+            dl = torch.empty(N, V, dtype=torch.bfloat16, device=h2.device)
         dh = dw = db = None
-        if ctx.wtp is not None and ctx.needs_input_grad[0]:
+        if fused_dh:
             # d h = dl W on the matrix cores inside the same pass (no (N, V) x (V, E) library GEMM, no re-read of dl)
-            N = Bn * S
             dh2 = torch.empty(N, E, dtype=torch.bfloat16, device=h2.device)
             ws = torch.empty(L.query("mivae_lce_dh_workspace_floats", N, E, V), dtype=torch.float32, device=h2.device)
             with _timed("lce_bwd"):
                 L.call("mivae_lce_bwd_dh", L.ptr(h2), L.ptr(wp), L.ptr(ctx.wtp), L.ptr(tgt), L.ptr(aux[0]), L.ptr(aux[1]),
-                       L.ptr(dper.contiguous().float()), L.ptr(dl), L.ptr(ws), L.ptr(dh2), Bn, S, E, V, smoothing,
-                       L.stream())
+                       L.ptr(dpc), L.ptr(dl), L.ptr(ws), L.ptr(dh2), Bn, S, E, V, smoothing, L.stream())
             dh = dh2.view(hshape).to(hdtype)
-        else:
+        elif dl is not None:
             with _timed("lce_bwd"):
                 L.call("mivae_lce_bwd", L.ptr(h2), L.ptr(wp), L.ptr(tgt), L.ptr(aux[0]), L.ptr(aux[1]),
-                       L.ptr(dper.contiguous().float()), L.ptr(dl), Bn, S, E, V, smoothing, L.stream())
-            if ctx.needs_input_grad[0]:
+                       L.ptr(dpc), L.ptr(dl), Bn, S, E, V, smoothing, L.stream())
+            if want_dh:
                 dh = dl.matmul(w16).view(hshape).to(hdtype)
-        want_db = has_bias and ctx.needs_input_grad[2]
-        wpar, bpar = ctx.params
+        if slabs:
+            part = torch.empty(slabs, V, E + 8, dtype=torch.float32, device=h2.device)
+            with _timed("lce_dw"):
+                L.call("mivae_lce_dw", L.ptr(h2), L.ptr(wp), L.ptr(tgt), L.ptr(aux[0]), L.ptr(aux[1]), L.ptr(dpc),
+                       L.ptr(part), Bn, S, E, V, smoothing, L.stream())
+            if grad_sink_ok(wpar, bpar) and wpar.grad.shape == (V, E):
+                L.call("mivae_fold_aug_sink", L.ptr(part), slabs, V, E, 8, L.ptr(wpar.grad), L.ptr(bpar.grad), L.stream())
+                sink_arrived(wpar.grad, bpar.grad)
+                return dh, None, None, None, None, None, None
+            # returned gradients: the same fixed-order fold as the sink route, into zeroed temporaries (bit-equal to it)
+            dwt = torch.zeros(V * E + V, dtype=torch.float32, device=h2.device)
+            dw_t, db_t = dwt[:V * E].view(V, E), dwt[V * E:]
+            L.call("mivae_fold_aug_sink", L.ptr(part), slabs, V, E, 8, L.ptr(dw_t), L.ptr(db_t), L.stream())
+            return dh, dw_t.to(wdtype), db_t.to(wdtype), None, None, None, None
         n = h2.size(0)
-        if (ctx.needs_input_grad[1] and want_db and n % 8 == 0 and n // 8 >= 1024 and grad_sink_ok(wpar, bpar)
+        if (want_dw and want_db and n % 8 == 0 and n // 8 >= 1024 and grad_sink_ok(wpar, bpar)
                 and wpar.grad.shape == (V, E)):
             # gradient sinks: [h | 1] lives in a persistent buffer whose ones block is written once, the 8 token-slab
             # partials of dl^T [h | 1] are folded straight into weight.grad / bias.grad (one launch, no accumulations)
@@ -1872,10 +1894,9 @@ class _LinearNLL(torch.autograd.Function):
                 L.call("mivae_fold_aug_sink", L.ptr(part), 8, V, E, 8, L.ptr(wpar.grad), L.ptr(bpar.grad), L.stream())
                 sink_arrived(wpar.grad, bpar.grad)
                 return dh, None, None, None, None, None, None
-        if ctx.needs_input_grad[1] and want_db:
+        if want_dw and want_db:
             # one dense product for both: d W = dl^T h and d b = dl^T 1 (a ones block appended to h)
             h_aug = torch.nn.functional.pad(h2, (0, 8), value=1.0)          # one launch (was ones + cat)
-            n = h2.size(0)
             G = 8 if (n % 8 == 0 and n // 8 >= 1024) else (4 if (n % 4 == 0 and n // 4 >= 1024) else 1)
             dwa = None
             if G > 1:
@@ -1890,7 +1911,7 @@ class _LinearNLL(torch.autograd.Function):
             if dwa is None:
                 dwa = dl.t().matmul(h_aug)
             dw, db = dwa[:, :E].to(wdtype), dwa[:, E].to(wdtype)
-        elif ctx.needs_input_grad[1]:
+        elif want_dw:
             dw = dl.t().matmul(h2).to(wdtype)
         elif want_db:
             db = dl.sum(0, dtype=torch.float32).to(wdtype)
@@ -1899,6 +1920,7 @@ class _LinearNLL(torch.autograd.Function):
 
 LCE_FEATURES = (32, 64, 128, 256)
 LCE_FUSED_DH = True        # d h inside the lce backward pass (mivae_lce_bwd_dh); False: library GEMM on d logits
+LCE_RECOMPUTE_DW = os.environ.get("MIVAE_LCE_DW", "1") != "0"   # d W / d b by mivae_lce_dw (E <= 64): no stored d logits
 
 
 def linear_nll_supported(h, weight) -> bool:

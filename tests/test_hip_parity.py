@@ -845,6 +845,47 @@ def test_lce_bwd_fused_dh_matches_library_product(M, Bn, S, E, V, sm):
     assert torch.equal(res[True][0][pad], torch.zeros_like(res[True][0][pad]))
 
 
+@pytest.mark.parametrize("Bn,S,E,V,sm", [(6, 9, 64, 128, 0.0), (4, 33, 32, 1024, 0.1), (256, 64, 64, 8192, 0.0), (37, 50, 64, 4096, 0.05),
+                                         (1, 1, 64, 64, 0.0)])
+def test_lce_dw_recompute_matches_product_on_stored_dlogits(M, Bn, S, E, V, sm):
+    """mivae_lce_dw (d W, d b of the fused projection + NLL from recomputed logits tiles: the (N, V) d logits are never
+    stored) vs the library product d logits^T [h | 1] on the d logits mivae_lce_bwd writes: the same bf16 d logits and
+    bf16 h on both sides, fp32 accumulation in a different order -> 2e-5 tensor-level (where the library route also keeps
+    fp32 partials); d h is the same kernel with and
+    without the store (bit equal).  Also through the gradient-sink route (folded straight into .grad)."""
+    gen = torch.Generator().manual_seed(Bn + S + E + V)
+    h = dev(torch.randn(Bn, S, E, generator=gen).to(torch.bfloat16))
+    W = dev(torch.randn(V, E, generator=gen) * 0.3)
+    b = dev(torch.randn(V, generator=gen))
+    target = torch.randint(1, V, (Bn, S), generator=gen)
+    lengths = torch.randint(0, S + 1, (Bn,), generator=gen)
+    lengths[0] = S
+    target[torch.arange(S)[None, :] >= lengths[:, None]] = 0
+    w = dev(O.tokens_mask(target).float())
+    gout = dev(torch.randn(Bn, generator=gen))
+    res = {}
+    for mode in ("recompute", "stored", "sink"):
+        M.ops.LCE_RECOMPUTE_DW = mode != "stored"
+        M.ops.GRAD_SINK = mode == "sink"
+        try:
+            hg, Wg, bg = h.clone().requires_grad_(True), W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            if mode == "sink":
+                Wg.grad, bg.grad = torch.zeros_like(Wg), torch.zeros_like(bg)
+            (M.ops.linear_nll(hg, Wg, bg, dev(target), w, sm) * gout).sum().backward()
+        finally:
+            M.ops.LCE_RECOMPUTE_DW = True
+            M.ops.GRAD_SINK = False
+        res[mode] = (hg.grad.float(), Wg.grad.clone(), bg.grad.clone())
+    assert torch.equal(res["recompute"][0], res["stored"][0])
+    # below 8192 tokens the stored route is ONE library product with a bf16 result (8e-3 like the oracle test above);
+    # above, split-K with fp32 partials
+    tol = 2e-5 if Bn * S >= 8192 else 8e-3
+    assert rel_err(res["recompute"][1], res["stored"][1]) < tol, rel_err(res["recompute"][1], res["stored"][1])
+    # d b: the kernel sums the UNROUNDED d logits in fp32, the product route their bf16 roundings
+    assert rel_err(res["recompute"][2], res["stored"][2]) < max(tol, 2e-3)
+    assert rel_err(res["sink"][1], res["recompute"][1]) < 1e-6 and rel_err(res["sink"][2], res["recompute"][2]) < 1e-6
+
+
 def test_fused_decode_matches_unfused(M):
     """NonAutoModel.decode: fused projection + NLL path (training_outputs_only, bf16 autocast) vs the unfused
     projection -> LabelSmoothingNLL path on the same weights and latents."""
