@@ -17,7 +17,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
          "-Wno-unused-result"]
 # The MFMA kernels keep their f32 VALU work single-issue: beside MFMAs a packed v_pk_*_f32 costs more than the two plain
 # instructions it replaces (MI355X_MICROARCH.md, "price of one filler beside MFMAs").
-EXTRA_FLAGS = {"nice_big.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"nice_big.hip": ["-fno-slp-vectorize"], "nll.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _newer(target, deps):

@@ -796,6 +796,238 @@ __global__ __launch_bounds__(256) void k_lce_bwd_s(LceArgs a) {
   }
 }
 
+// d h with NO stored d logits (the d W product recomputes, k_lce_dw): the same arithmetic as k_lce_bwd_s<NKS, true> with
+// dlogits = NULL, restructured so that the matrix pipe works under the exponentials instead of beside them.  Measured on
+// k_lce_bwd_s at config 2 (tools/bench_lce.py, variants with one part removed): exponentials + conversions 29 us, logits
+// MFMAs + their LDS reads 16, d h MFMAs 13, the per-pair barrier with its register-staged copy 14, the target-row branch
+// 8 -- the parts ADD UP to the kernel time, i.e. nothing overlapped: a wave issued its five dependent logits MFMAs
+// back to back (stalled 32 cycles each), then 130 VALU instructions, then four more MFMAs, and the partner wave on the
+// SIMD sat in the same phase behind the same barrier.  Here, per 32 x 32 tile i of the wave's stream:
+//   L(i+1)  logits MFMAs of the NEXT tile                      (matrix pipe)
+//   V(i)    p = exp2(x log2e + c0), sign, bf16 pairs           (VALU)
+//   D(i-1)  d h += W^T fragments x bf16 d logits of the PREVIOUS tile, fragments preloaded   (matrix pipe)
+// are independent and sit in one branch-free region which the scheduler interleaves; the W / W^T fragment images of a
+// chunk pair arrive by LDS-DMA (no registers, no ds_write) into a ring of three slots, requested two pairs ahead, one
+// barrier per pair.  A target row inside the tile (one tile in eight at V = 8192) is PATCHED after V(i): the one element
+// is recomputed with the `- hot` term and inserted into its packed word (wave-uniform register index), instead of a
+// second copy of the whole tile loop with a compare per element.
+typedef __attribute__((address_space(3))) void lce_lds_void_t;
+typedef const __attribute__((address_space(1))) void lce_glb_cvoid_t;
+typedef unsigned lce_u32x8 __attribute__((ext_vector_type(8)));
+typedef unsigned lce_u32x4 __attribute__((ext_vector_type(4)));
+typedef float lce_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 lce_bf16x2 __attribute__((ext_vector_type(2)));
+
+template <int NKS, bool SMOOTH, int DBG = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_lce_dh(LceArgs a) {
+  constexpr int NF = NKS + 1;
+  constexpr int E = 16 * NKS, EB = E / 32;
+  constexpr int WB = 2 * NF * 1024;                  // bytes of W fragments per chunk pair
+  constexpr int TB = 2 * 2 * EB * 1024;              // bytes of W^T fragments per chunk pair
+  constexpr int SB = WB + TB, NP = SB / 1024;        // ring slot: NP pieces of 1 KiB
+  constexpr int PW = (NP + 3) / 4;                   // LDS-DMA pieces per wave and pair
+  // three ring slots as three OBJECTS: the compiler's wait insertion then knows that the fragment reads of slots A, B do
+  // not touch the slot an LDS-DMA is filling (with one array and a computed slot it waits vmcnt(0) before every read)
+  __shared__ __attribute__((aligned(1024))) char ringA[SB];
+  __shared__ __attribute__((aligned(1024))) char ringB[SB];
+  __shared__ __attribute__((aligned(1024))) char ringC[SB];
+  __shared__ __attribute__((aligned(1024))) char ringD[SB];
+  const int lane = threadIdx.x & 63, r32 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  const int slice = (int)blockIdx.y;
+  const int64_t tok0 = tile * 32, tok = tok0 + r32;
+  const bool valid = tok < a.N;
+  const float coef = valid ? a.dper[tok / a.S] * a.tokscale[tok] : 0.f;
+  const int npair = a.V >> 6;
+  const int p0 = slice * a.per;
+  int p1 = p0 + a.per;
+  if (p1 > npair) p1 = npair;
+  const bool live = __any(coef != 0.f) != 0;                 // wave-uniform; tiles past N are not live either
+  if (!live || p0 >= p1) {                                   // padding tile, or a slice past the vocabulary: zero rows
+    const f32x4 zf = {0.f, 0.f, 0.f, 0.f};
+    for (int idx = lane; idx < 32 * (E / 4); idx += 64) {
+      const int row = idx / (E / 4), c4 = idx % (E / 4);
+      if (tok0 + row < a.N)
+        *reinterpret_cast<f32x4*>(a.dhp + ((int64_t)slice * a.N + tok0 + row) * E + 4 * c4) = zf;
+    }
+  }
+  if (!__syncthreads_or(live ? 1 : 0) || p0 >= p1) return;   // no live tile in this block: no weights needed
+  lce_bf16x8 hf[NF];
+  lce_load_h<NF>(a.h, live ? tok : 0, live && valid, hh, hf);
+  const int t = valid ? (int)a.target[tok] : -1;
+  f32x16 dh[EB];
+#pragma unroll
+  for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dh[eb][r] = 0.f;
+  const float c0 = valid ? __builtin_amdgcn_logf(fabsf(coef)) - a.lse[tok] * kLog2e : -INFINITY;
+  // d logits = sign(coef) (|coef| softmax - |coef| q): the sign of a token's cotangent is applied ONCE, to its finished
+  // d h column (rounding to bf16 and the fp32 accumulation are symmetric in the sign: bit-identical to applying it to
+  // every element), which takes a v_xor per element out of the loop
+  const unsigned sgn = __float_as_uint(coef) & 0x80000000u;
+  const float uni = fabsf(coef) * (SMOOTH ? a.smoothing / (float)a.V : 0.f);
+  const float hot = fabsf(coef) * (SMOOTH ? 1.f - a.smoothing : 1.f);
+  const char* wsrc = reinterpret_cast<const char*>(a.W);
+  const char* tsrc = reinterpret_cast<const char*>(a.Wt);
+  // LDS-DMA pieces round-robin over the four waves; every wave issues PW pieces per pair (the last may repeat one), from
+  // wave-uniform bases: piece q of pair p is at sbase[k] + p * sstride[k]
+  const char* sbase[PW];
+  int sstride[PW], soff[PW];
+#pragma unroll
+  for (int k = 0; k < PW; ++k) {
+    const int q = wave + 4 * k, piece = q < NP ? q : NP - 1;
+    const bool isw = piece < WB / 1024;
+    sbase[k] = isw ? wsrc + piece * 1024 : tsrc + (piece - WB / 1024) * 1024;
+    sstride[k] = isw ? WB : TB;
+    soff[k] = piece * 1024;
+  }
+  auto stage = [&](int p, char* slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < PW; ++k)
+      __builtin_amdgcn_global_load_lds((lce_glb_cvoid_t*)(sbase[k] + (int64_t)p * sstride[k] + (unsigned)(lane * 16)),
+                                       (lce_lds_void_t*)(slot + soff[k]), 16, 0, 0);
+  };
+  lce_bf16x8 wfn[NF];                                        // W fragments of the tile after the current one
+  auto load_w = [&](const char* slot, int u) {
+#pragma unroll
+    for (int ks = 0; ks < NF; ++ks) wfn[ks] = *reinterpret_cast<const lce_bf16x8*>(slot + ((u * NF + ks) * 64 + lane) * 16);
+  };
+  auto coefs = [&](const f32x16& x) -> lce_u32x8 {           // V: word w = bf16 pair of accumulator registers 2 w, 2 w + 1
+    lce_u32x8 o;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      if (DBG & 8) { o[w] = (__float_as_uint(x[2 * w]) ^ __float_as_uint(x[2 * w + 1])) & 0x3f803f80u; continue; }
+      float g0 = ex2(fmaf(x[2 * w], kLog2e, c0));
+      float g1 = ex2(fmaf(x[2 * w + 1], kLog2e, c0));
+      if (SMOOTH) { g0 -= uni; g1 -= uni; }
+      const lce_f32x2 pr = {g0, g1};
+      o[w] = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, lce_bf16x2));   // v_cvt_pk_bf16_f32
+    }
+    return o;
+  };
+  auto fix_targets = [&](lce_u32x8& o, const f32x16& x, int c) {   // rows that are some token's target in chunk c
+    unsigned long long m = __ballot(hh == 0 && (t >> 5) == c);
+    while (m) {
+      const int r = __builtin_ctzll(m);
+      m &= m - 1;
+      const int row = __builtin_amdgcn_readlane(t, r) - 32 * c;     // wave-uniform, 0 .. 31 = 8 q + 4 hh' + i
+      const int e = 4 * (row >> 3) + (row & 3), owner = r + 32 * ((row >> 2) & 1);
+      float g = ex2(fmaf(x[e], kLog2e, c0));
+      if (SMOOTH) g -= uni;
+      g -= hot;
+      const unsigned g16 = f32_to_bf16(g), old = o[e >> 1];
+      const unsigned nw = (e & 1) ? (old & 0xffffu) | (g16 << 16) : (old & 0xffff0000u) | g16;
+      o[e >> 1] = lane == owner ? nw : old;
+    }
+  };
+  lce_bf16x8 afp[2][EB];                                     // W^T fragments of the pending tile
+  auto load_wt = [&](const char* slot, int u) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int eb = 0; eb < EB; ++eb)
+        afp[s2][eb] = *reinterpret_cast<const lce_bf16x8*>(slot + WB + (((u * 2 + s2) * EB + eb) * 64 + lane) * 16);
+  };
+  auto product = [&](const lce_u32x8& o) {                   // D
+    if (DBG & 16) { dh[0][0] += __uint_as_float((o[0] ^ o[1] ^ o[2] ^ o[3] ^ o[4] ^ o[5] ^ o[6] ^ o[7]) & 0x3f803f80u); return; }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const lce_u32x4 b4 = {o[4 * s2], o[4 * s2 + 1], o[4 * s2 + 2], o[4 * s2 + 3]};
+      const lce_bf16x8 bfr = __builtin_bit_cast(lce_bf16x8, b4);
+#pragma unroll
+      for (int eb = 0; eb < EB; ++eb) dh[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afp[s2][eb], bfr, dh[eb], 0, 0, 0);
+    }
+  };
+  // order of one tile's region: the fragment reads of the NEXT region first (a full region to land), then one MFMA per
+  // five VALU / transcendental instructions (16 x (fma, exp) + 8 conversions beside NF + 2 EB MFMAs)
+  auto pipe = [&](bool dma) __attribute__((always_inline)) {
+    __builtin_amdgcn_sched_group_barrier(0x100, NF + 2 * EB, 0);
+#pragma unroll
+    for (int i = 0; i < NF + 2 * EB; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x402, (SMOOTH ? 56 : 40) / (NF + 2 * EB) + 1, 0);
+      if (dma && i >= NF + 2 * EB - PW) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // one LDS-DMA piece per late gap
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the reads landed long ago; the next region starts without a wait
+  };
+  stage(p0, ringA);
+  if (p0 + 1 < p1) stage(p0 + 1, ringB);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (p0 + 2 < p1) stage(p0 + 2, ringC);
+  f32x16 xa, xb;
+  lce_u32x8 ovp = {0, 0, 0, 0, 0, 0, 0, 0};                  // no pending tile yet: a zero product on finite fragments
+  load_w(ringA, 0);
+  xa = lce_tile<NF>(wfn, hf);
+  load_w(ringA, 1);
+  load_wt(ringA, 0);
+  __builtin_amdgcn_s_waitcnt(0xC07F);                        // lgkmcnt(0): the loop is entered with nothing in flight
+  // one chunk pair: slot `cur` holds pair p, `nxt` pair p + 1 (past the last pair: stale or unwritten data, whose tile
+  // is computed and discarded), pair p + 2 is in flight and `stg` receives pair p + 3: a request has two pair times to
+  // land (every block walks the pairs in step, so each pair's first touch is an L2 miss for all of them at once)
+  auto pair = [&](const char* cur, const char* nxt, char* stg, int p) __attribute__((always_inline)) {
+    const int pn = p + 3 < p1 ? p + 3 : p1 - 1;              // (past the end: a pair that is there already, into a free slot)
+    {                                                        // (a padding tile in a live block computes zeros: c0 = -inf)
+      {
+        xb = lce_tile<NF>(wfn, hf);                          // L(p, 1)
+        load_w(nxt, 0);
+        lce_u32x8 ov = coefs(xa);
+        product(ovp);
+        load_wt(cur, 0);
+        if (!(DBG & 1)) stage(pn, stg);
+        pipe(!(DBG & 1));
+        if (!(DBG & 4) && __any((t >> 5) == 2 * p)) fix_targets(ov, xa, 2 * p);
+        ovp = ov;
+      }
+      {
+        xa = lce_tile<NF>(wfn, hf);                          // L(p + 1, 0)
+        load_w(nxt, 1);
+        lce_u32x8 ov = coefs(xb);
+        product(ovp);
+        load_wt(cur, 1);
+        pipe(false);
+        if (!(DBG & 4) && __any((t >> 5) == 2 * p + 1)) fix_targets(ov, xb, 2 * p + 1);
+        ovp = ov;
+      }
+    }
+    if (!(DBG & 2)) {
+      // this wave's pieces of pair p + 2 have landed (all but the PW just issued), its fragment reads are complete; then
+      // the barrier: pair p + 2 is there for every wave and nobody reads slot `cur` any more.  (A raw barrier:
+      // __syncthreads() carries a fence that waits for EVERY outstanding request, the new ones included.)
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0x0070 | PW);               // vmcnt(PW) lgkmcnt(0), visible to the compiler's own counters
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+  };
+  for (int p = p0;;) {
+    pair(ringA, ringB, ringD, p);
+    if (++p >= p1) break;
+    pair(ringB, ringC, ringA, p);
+    if (++p >= p1) break;
+    pair(ringC, ringD, ringB, p);
+    if (++p >= p1) break;
+    pair(ringD, ringA, ringC, p);
+    if (++p >= p1) break;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // no LDS-DMA in flight when the wave ends
+  if (!live) return;
+  product(ovp);
+  if (valid) {
+#pragma unroll
+    for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = __uint_as_float(__float_as_uint(dh[eb][4 * q + i]) ^ sgn);
+        *reinterpret_cast<f32x4*>(a.dhp + ((int64_t)slice * a.N + tok) * E + 32 * eb + 8 * q + 4 * hh) = v;
+      }
+  }
+}
+
 // d h (N, E) bf16 = sum over the VSB vocabulary-slice partials, in slice order
 __global__ __launch_bounds__(256) void k_lce_dh_combine(const float* __restrict__ partial, unsigned short* __restrict__ dh,
                                                          int64_t NE, int VSB) {
@@ -1198,6 +1430,18 @@ extern "C" int mivae_lce_bwd_dh(const void* h, const void* W, const void* Wtp, c
   a.per = (int)((V / 64 + VSB - 1) / VSB);
   dim3 grid((unsigned)(((N + 31) / 32 + 3) / 4), (unsigned)VSB);
   hipStream_t st = S_(stream);
+  static const bool pipelined = !(getenv("MIVAE_LCE_DH_PIPE") && atoi(getenv("MIVAE_LCE_DH_PIPE")) == 0);
+  if (!dlogits && pipelined) {
+    if (E == 32) { if (smoothing > 0.f) k_lce_dh<2, true><<<grid, 256, 0, st>>>(a); else k_lce_dh<2, false><<<grid, 256, 0, st>>>(a); }
+    else { if (smoothing > 0.f) k_lce_dh<4, true><<<grid, 256, 0, st>>>(a); else {
+      static const int dbg = getenv("MIVAE_LCE_DBG") ? atoi(getenv("MIVAE_LCE_DBG")) : 0;
+      switch (dbg) {
+#define DBGCASE(n) case n: k_lce_dh<4, false, n><<<grid, 256, 0, st>>>(a); break;
+        DBGCASE(1) DBGCASE(3) DBGCASE(4) DBGCASE(7) DBGCASE(15) DBGCASE(23) DBGCASE(31) DBGCASE(12) DBGCASE(20)
+        default: k_lce_dh<4, false><<<grid, 256, 0, st>>>(a); break;
+      }
+    } }
+  } else
   switch (E) {
     case 32: k_lce_bwd_s<2, true><<<grid, 256, 0, st>>>(a); break;
     case 64: k_lce_bwd_s<4, true><<<grid, 256, 0, st>>>(a); break;

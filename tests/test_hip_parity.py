@@ -851,8 +851,8 @@ def test_lce_dw_recompute_matches_product_on_stored_dlogits(M, Bn, S, E, V, sm):
     """mivae_lce_dw (d W, d b of the fused projection + NLL from recomputed logits tiles: the (N, V) d logits are never
     stored) vs the library product d logits^T [h | 1] on the d logits mivae_lce_bwd writes: the same bf16 d logits and
     bf16 h on both sides, fp32 accumulation in a different order -> 2e-5 tensor-level (where the library route also keeps
-    fp32 partials); d h is the same kernel with and
-    without the store (bit equal).  Also through the gradient-sink route (folded straight into .grad)."""
+    fp32 partials); d h comes from the pipelined kernel without the store
+    (k_lce_dh) and from the storing kernel: equal to the last bf16 bit on all but a handful of elements.  Also through the gradient-sink route (folded straight into .grad)."""
     gen = torch.Generator().manual_seed(Bn + S + E + V)
     h = dev(torch.randn(Bn, S, E, generator=gen).to(torch.bfloat16))
     W = dev(torch.randn(V, E, generator=gen) * 0.3)
@@ -876,7 +876,14 @@ def test_lce_dw_recompute_matches_product_on_stored_dlogits(M, Bn, S, E, V, sm):
             M.ops.LCE_RECOMPUTE_DW = True
             M.ops.GRAD_SINK = False
         res[mode] = (hg.grad.float(), Wg.grad.clone(), bg.grad.clone())
-    assert torch.equal(res["recompute"][0], res["stored"][0])
+    # d h: the pipelined kernel (no store) applies the sign of a token's cotangent to its finished d h column, the storing
+    # kernel to every d logits element: equal up to the matrix pipe's last-bit asymmetry in the sign of an fp32
+    # accumulation, i.e. a bf16 result that sat on a rounding boundary (measured: 13 of 1 M elements, by a bf16 ulp or, where
+    # the sum cancelled to ~1e-8, a few; all in sentences with a negative cotangent)
+    dh_new, dh_old = res["recompute"][0], res["stored"][0]
+    differ = dh_new != dh_old
+    assert float(differ.float().mean()) < 1e-4, int(differ.sum())
+    assert rel_err(dh_new, dh_old) < 2e-4, rel_err(dh_new, dh_old)     # measured 8e-5 of the largest element
     # below 8192 tokens the stored route is ONE library product with a bf16 result (8e-3 like the oracle test above);
     # above, split-K with fp32 partials
     tol = 2e-5 if Bn * S >= 8192 else 8e-3
