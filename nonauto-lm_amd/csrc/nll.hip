@@ -327,6 +327,7 @@ __global__ __launch_bounds__(256) void k_lce_pack(const unsigned short* __restri
     const unsigned short hi = f32_to_bf16(b);
     v[0] = hi;
     v[1] = f32_to_bf16(b - bf16_to_f32(hi));
+    v[2] = v[3] = v[4] = 0x3F80;                   // against a per-token constant in slots 2..4 of h's column (k_lce_dwp)
   }
   *reinterpret_cast<u16x8*>(Wp + g * 8) = v;
 }
@@ -957,6 +958,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (p0 + 2 < p1) stage(p0 + 2, ringC);
+  if (DBG & 1) { stage(p0, ringD); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
   f32x16 xa, xb;
   lce_u32x8 ovp = {0, 0, 0, 0, 0, 0, 0, 0};                  // no pending tile yet: a zero product on finite fragments
   load_w(ringA, 0);
@@ -997,7 +999,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       // the barrier: pair p + 2 is there for every wave and nobody reads slot `cur` any more.  (A raw barrier:
       // __syncthreads() carries a fence that waits for EVERY outstanding request, the new ones included.)
       asm volatile("" ::: "memory");
-      __builtin_amdgcn_s_waitcnt(0x0070 | PW);               // vmcnt(PW) lgkmcnt(0), visible to the compiler's own counters
+      __builtin_amdgcn_s_waitcnt((DBG & 1) ? 0x0070 : (0x0070 | PW));               // vmcnt(PW) lgkmcnt(0), visible to the compiler's own counters
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     }
@@ -1260,6 +1262,260 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+// k_lce_dw for smoothing = 0, software-pipelined like k_lce_dh: per wave the stream of units (token tile i, chunk u of
+// the block's vocabulary pair) runs L(next unit) / V(current) / D(previous) in one scheduled region, the W fragments of
+// the pair stay in registers and the h tile goes through a private double-buffered LDS tile (written once per tile;
+// read back as the A fragments of L and, transposed by ds_read_b64_tr_b16, as the A fragments of D): no block barrier
+// and no shared staging inside the loop.  What made the un-pipelined loop slow is taken out of the per-element work:
+//  * the per-token constant c = ln|coef| - lse rides on the matrix pipe: it sits (as three bf16 pieces, ~24 bits) in
+//    slots 2..4 of the token side's bias column against ones on the vocabulary side, so the accumulator already holds
+//    x + c and a d logits element is exp2(acc log2e): one multiply, one exponential, one add (d b), half a conversion;
+//  * a target inside the unit (one unit in four at V = 8192) is patched afterwards: the one element is recomputed
+//    with its `- |coef|` term and inserted into the packed word (wave-uniform register index), d b corrected;
+//  * rows with a negative cotangent (none in training: the loss weights are positive) are sign-flipped the same way.
+// Padding tiles are computed (c = -1e30 gives exact zeros) rather than skipped.
+template <int NKS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_lce_dwp(LceDwArgs a) {
+  constexpr int NF = NKS + 1;
+  constexpr int E = 16 * NKS, EB = (E + 31) / 32;
+  constexpr int HST = E + 8;                                 // h tile row stride (elements): conflict-free b128 and tr reads
+  constexpr int TILE = 32 * HST;                             // elements per tile buffer
+  constexpr int WB = 2 * NF * 1024;
+  constexpr int ACC = EB * 2 * 16;
+  constexpr int RED = 2 * ACC * 64 + 2 * 2 * 64;             // floats of the end reduction
+  constexpr int LDSF = RED > 4 * 2 * TILE / 2 ? RED : 4 * 2 * TILE / 2;
+  __shared__ __attribute__((aligned(16))) float red[LDSF];   // the tile buffers alias the reduction area
+  const int lane = threadIdx.x & 63, r32 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned short* tbuf = reinterpret_cast<unsigned short*>(red) + wave * (2 * TILE);
+  const int p = blockIdx.x, ts = blockIdx.y;
+  lce_bf16x8 wf[2][NF];
+  {
+    const char* wsrc = reinterpret_cast<const char*>(a.W) + (int64_t)p * WB;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int ks = 0; ks < NF; ++ks)
+        wf[u][ks] = *reinterpret_cast<const lce_bf16x8*>(wsrc + ((u * NF + ks) * 64 + lane) * 16);
+  }
+  f32x16 dW[EB][2];
+  float db[2] = {0.f, 0.f};
+#pragma unroll
+  for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dW[eb][u][r] = 0.f;
+  const int64_t ntiles = (a.N + 31) / 32;
+  const int64_t t0 = (int64_t)ts * a.tiles_per_split;
+  int64_t t1 = t0 + a.tiles_per_split;
+  if (t1 > ntiles) t1 = ntiles;
+  const int niter = t1 > t0 + wave ? (int)((t1 - t0 - wave + 3) / 4) : 0;
+  // ---- stages ----
+  lce_bf16x8 hn[NKS];                                        // global -> register leg of the next tile's h rows
+  float coef_n = 0.f, lse_n = 0.f;
+  int t_n = -1;
+  auto request = [&](int i) __attribute__((always_inline)) {  // G: tile i of this wave's sequence (past the end: zeros)
+    const int64_t tile = t0 + wave + 4 * (int64_t)i;
+    const int64_t tok = tile * 32 + r32;
+    const bool valid = tile < t1 && tok < a.N;
+    const unsigned short* hp = a.h + (valid ? tok : 0) * E + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) hn[ks] = *reinterpret_cast<const lce_bf16x8*>(hp + 16 * ks);
+    coef_n = valid ? a.dper[tok / a.S] * a.tokscale[tok] : 0.f;
+    lse_n = valid ? a.lse[tok] : 0.f;
+    t_n = valid ? (int)a.target[tok] : -1;
+  };
+  auto store_tile = [&](unsigned short* buf) __attribute__((always_inline)) {   // S
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) *reinterpret_cast<lce_bf16x8*>(buf + r32 * HST + 16 * ks + 8 * hh) = hn[ks];
+  };
+  // the token side's last k-step: [1, 1, c_hi, c_lo, c_lo2, 0, 0, 0] in the hh = 0 lanes, c = ln|coef| - lse
+  auto bias_col = [&](float coef, float lse) __attribute__((always_inline)) -> lce_bf16x8 {
+    const float c = coef != 0.f ? (__builtin_amdgcn_logf(fabsf(coef)) - lse * kLog2e) * 0.6931471805599453f : -1e30f;
+    const unsigned short c1 = f32_to_bf16(c);
+    const float r1 = c - bf16_to_f32(c1);
+    const unsigned short c2 = f32_to_bf16(r1);
+    const unsigned short c3 = f32_to_bf16(r1 - bf16_to_f32(c2));
+    const u16x8 v = {0x3F80, 0x3F80, c1, c2, c3, 0, 0, 0}, z = {0, 0, 0, 0, 0, 0, 0, 0};
+    return __builtin_bit_cast(lce_bf16x8, hh == 0 ? v : z);
+  };
+  auto logits = [&](const unsigned short* buf, const lce_bf16x8& hb, int u) __attribute__((always_inline)) -> f32x16 {   // L
+    lce_bf16x8 hf[NF];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) hf[ks] = *reinterpret_cast<const lce_bf16x8*>(buf + r32 * HST + 16 * ks + 8 * hh);
+    hf[NKS] = hb;
+    f32x16 x;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < NF; ++ks) x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf[ks], wf[u][ks], x, 0, 0, 0);
+    return x;
+  };
+  auto coefs = [&](const f32x16& x, float& sum) __attribute__((always_inline)) -> lce_u32x8 {   // V
+    lce_u32x8 o;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      const float g0 = ex2(x[2 * w] * kLog2e), g1 = ex2(x[2 * w + 1] * kLog2e);
+      sum += g0;
+      sum += g1;
+      const lce_f32x2 pr = {g0, g1};
+      o[w] = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, lce_bf16x2));
+    }
+    return o;
+  };
+  lce_bf16x8 hT[2][EB];                                      // transposed fragments of the tile whose products are pending
+  auto load_ht = [&](const unsigned short* buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int eb = 0; eb < EB; ++eb) hT[s2][eb] = lce_tr_frag_perm(buf, HST, 32 * eb, s2, lane);
+  };
+  auto product = [&](const lce_u32x8& o, int u) __attribute__((always_inline)) {   // D
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const lce_u32x4 b4 = {o[4 * s2], o[4 * s2 + 1], o[4 * s2 + 2], o[4 * s2 + 3]};
+      const lce_bf16x8 bfr = __builtin_bit_cast(lce_bf16x8, b4);
+#pragma unroll
+      for (int eb = 0; eb < EB; ++eb) dW[eb][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hT[s2][eb], bfr, dW[eb][u], 0, 0, 0);
+    }
+  };
+  // rare fixes of one unit: rows (tokens) with a negative cotangent, then rows whose target lies in chunk c
+  auto fix = [&](lce_u32x8& o, const f32x16& x, float& sum, int c, int t, float coef) {
+    unsigned long long m = __ballot(hh == 0 && coef < 0.f);
+    while (m) {
+      const int row = __builtin_ctzll(m);
+      m &= m - 1;
+      const int e = 4 * (row >> 3) + (row & 3);
+      const bool mine = hh == ((row >> 2) & 1);
+      const float g = ex2(x[e] * kLog2e);
+      const unsigned old = o[e >> 1];
+      o[e >> 1] = mine ? old ^ ((e & 1) ? 0x80000000u : 0x00008000u) : old;
+      if (mine) sum -= 2.f * g;
+    }
+    m = __ballot(hh == 0 && (t >> 5) == c);
+    while (m) {
+      const int row = __builtin_ctzll(m);
+      m &= m - 1;
+      const int col = __builtin_amdgcn_readlane(t, row) & 31;
+      const float cf = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(coef), row));
+      const int e = 4 * (row >> 3) + (row & 3), owner = col + 32 * ((row >> 2) & 1);
+      float g = ex2(x[e] * kLog2e) - fabsf(cf);
+      if (cf < 0.f) g = -g;
+      const unsigned g16 = f32_to_bf16(g);
+      const unsigned old = o[e >> 1];
+      const unsigned nw = (e & 1) ? (old & 0xffffu) | (g16 << 16) : (old & 0xffff0000u) | g16;
+      o[e >> 1] = lane == owner ? nw : old;
+      if (lane == owner) sum -= cf;                          // sign(cf) |cf|
+    }
+  };
+  auto pipe = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_sched_group_barrier(0x100, NKS, 0);     // the A fragments of L first
+#pragma unroll
+    for (int i = 0; i < NF + 2 * EB; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x402, 56 / (NF + 2 * EB) + 1, 0);
+    }
+  };
+  // ---- prologue: tile 0 in buffer 0, tile 1 requested ----
+  unsigned short* bufc = tbuf;                               // tile i
+  unsigned short* bufn = tbuf + TILE;                        // tile i + 1
+  request(0);
+  store_tile(bufc);
+  float coef_c = coef_n;
+  int t_c = t_n;
+  lce_bf16x8 hb_c = bias_col(coef_n, lse_n);
+  request(1);
+  load_ht(bufc);
+  f32x16 x0 = logits(bufc, hb_c, 0), x1;
+  lce_u32x8 ovp = {0, 0, 0, 0, 0, 0, 0, 0};                  // no pending unit yet: a zero product
+  for (int i = 0; i < niter; ++i) {
+    lce_bf16x8 hb_n;
+    lce_u32x8 ov0, ov1;
+    {                                                        // region A: unit (i, 0)
+      x1 = logits(bufc, hb_c, 1);                            // L(i, 1)
+      ov0 = coefs(x0, db[0]);                                // V(i, 0)
+      product(ovp, 1);                                       // D(i - 1, 1) on the previous tile's transposed fragments
+      store_tile(bufn);                                      // S(i + 1): the rows requested a tile ago
+      hb_n = bias_col(coef_n, lse_n);
+      load_ht(bufc);                                         // for D(i, 0), D(i, 1)
+      pipe();
+      if (__any(coef_c < 0.f || (t_c >> 5) == 2 * p)) fix(ov0, x0, db[0], 2 * p, t_c, coef_c);
+    }
+    {                                                        // region B: unit (i, 1)
+      x0 = logits(bufn, hb_n, 0);                            // L(i + 1, 0)
+      ov1 = coefs(x1, db[1]);                                // V(i, 1)
+      product(ov0, 0);                                       // D(i, 0)
+      pipe();
+      if (__any(coef_c < 0.f || (t_c >> 5) == 2 * p + 1)) fix(ov1, x1, db[1], 2 * p + 1, t_c, coef_c);
+    }
+    ovp = ov1;
+    hb_c = hb_n;
+    coef_c = coef_n;
+    t_c = t_n;
+    request(i + 2);                                          // G(i + 2)
+    unsigned short* sw = bufc;
+    bufc = bufn;
+    bufn = sw;
+  }
+  product(ovp, 1);
+  (void)x0;
+  // d b: the two lane halves hold the rows 4 hh + ... of the same column
+#pragma unroll
+  for (int u = 0; u < 2; ++u) db[u] += __shfl_xor(db[u], 32, 64);
+  // combine the four waves in fixed order: (0 + 2), (1 + 3), then (0 + 1)
+  __syncthreads();                                           // every wave is done with its h tile (aliases red)
+  float* slot = red + (wave & 1) * (ACC * 64) + lane;
+  float* dslot = red + 2 * ACC * 64 + (wave & 1) * 128 + lane;
+  if (wave >= 2) {
+#pragma unroll
+    for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slot[((eb * 2 + u) * 16 + r) * 64] = dW[eb][u][r];
+    dslot[0] = db[0]; dslot[64] = db[1];
+  }
+  __syncthreads();
+  if (wave < 2) {
+#pragma unroll
+    for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dW[eb][u][r] += slot[((eb * 2 + u) * 16 + r) * 64];
+    db[0] += dslot[0]; db[1] += dslot[64];
+  }
+  __syncthreads();
+  if (wave == 1) {
+#pragma unroll
+    for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((eb * 2 + u) * 16 + r) * 64 + lane] = dW[eb][u][r];
+    red[2 * ACC * 64 + lane] = db[0]; red[2 * ACC * 64 + 64 + lane] = db[1];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  float* P = a.part + ((int64_t)ts * a.V) * (E + 8);
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    float* row = P + (int64_t)(64 * p + 32 * u + r32) * (E + 8);
+#pragma unroll
+    for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = dW[eb][u][4 * q + i] + red[((eb * 2 + u) * 16 + 4 * q + i) * 64 + lane];
+        if (32 * eb + 8 * q + 4 * hh < E) *reinterpret_cast<f32x4*>(row + 32 * eb + 8 * q + 4 * hh) = o;
+      }
+    if (hh == 0) row[E] = db[u] + red[2 * ACC * 64 + 64 * u + lane];
+  }
+}
+
+
 // token splits of mivae_lce_dw: ~512 blocks of 4 waves (two resident per CU)
 static int lce_dw_splits(int64_t N, int64_t V) {
   const int64_t pairs = V / 64, tiles = (N + 31) / 32;
@@ -1482,7 +1738,11 @@ extern "C" int mivae_lce_dw(const void* h, const void* W, const int64_t* target,
   const int TS = lce_dw_splits(N, V);
   a.tiles_per_split = (int)(((N + 31) / 32 + TS - 1) / TS);
   dim3 grid((unsigned)(V / 64), (unsigned)TS);
-  if (E == 32) k_lce_dw<2><<<grid, 256, 0, S_(stream)>>>(a);
+  static const bool pipelined = !(getenv("MIVAE_LCE_DW_PIPE") && atoi(getenv("MIVAE_LCE_DW_PIPE")) == 0);
+  if (pipelined && smoothing == 0.f) {
+    if (E == 32) k_lce_dwp<2><<<grid, 256, 0, S_(stream)>>>(a);
+    else k_lce_dwp<4><<<grid, 256, 0, S_(stream)>>>(a);
+  } else if (E == 32) k_lce_dw<2><<<grid, 256, 0, S_(stream)>>>(a);
   else k_lce_dw<4><<<grid, 256, 0, S_(stream)>>>(a);
   MIVAE_CHECK_LAUNCH("lce_dw");
   return MIVAE_OK;
