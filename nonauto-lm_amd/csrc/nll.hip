@@ -1312,23 +1312,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (t1 > ntiles) t1 = ntiles;
   const int niter = t1 > t0 + wave ? (int)((t1 - t0 - wave + 3) / 4) : 0;
   // ---- stages ----
-  lce_bf16x8 hn[NKS];                                        // global -> register leg of the next tile's h rows
-  float coef_n = 0.f, lse_n = 0.f;
-  int t_n = -1;
-  auto request = [&](int i) __attribute__((always_inline)) {  // G: tile i of this wave's sequence (past the end: zeros)
-    const int64_t tile = t0 + wave + 4 * (int64_t)i;
-    const int64_t tok = tile * 32 + r32;
-    const bool valid = tile < t1 && tok < a.N;
-    const unsigned short* hp = a.h + (valid ? tok : 0) * E + 8 * hh;
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) hn[ks] = *reinterpret_cast<const lce_bf16x8*>(hp + 16 * ks);
-    coef_n = valid ? a.dper[tok / a.S] * a.tokscale[tok] : 0.f;
-    lse_n = valid ? a.lse[tok] : 0.f;
-    t_n = valid ? (int)a.target[tok] : -1;
+  // G: the global -> register leg of one tile (tile i of this wave's sequence; past the end: zeros).  Raw loads only:
+  // any arithmetic on them here would wait for the round trip on the spot.
+  struct Req {
+    lce_bf16x8 h[NKS];
+    float dp, tsc, lse;
+    int t;
   };
-  auto store_tile = [&](unsigned short* buf) __attribute__((always_inline)) {   // S
+  auto is_valid = [&](int i) __attribute__((always_inline)) -> bool {
+    const int64_t tile = t0 + wave + 4 * (int64_t)i;
+    return tile < t1 && tile * 32 + r32 < a.N;
+  };
+  auto request = [&](int i, Req& r) __attribute__((always_inline)) {   // unconditional loads (token 0 when out of range)
+    const int64_t tok = is_valid(i) ? (t0 + wave + 4 * (int64_t)i) * 32 + r32 : 0;
+    const unsigned short* hp = a.h + tok * E + 8 * hh;
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) *reinterpret_cast<lce_bf16x8*>(buf + r32 * HST + 16 * ks + 8 * hh) = hn[ks];
+    for (int ks = 0; ks < NKS; ++ks) r.h[ks] = *reinterpret_cast<const lce_bf16x8*>(hp + 16 * ks);
+    r.dp = a.dper[(unsigned)tok / (unsigned)a.S];            // N < 2^31 (lce_check): 32-bit division
+    r.tsc = a.tokscale[tok];
+    r.lse = a.lse[tok];
+    r.t = reinterpret_cast<const int*>(a.target)[2 * tok];   // low half of the int64 (0 <= target < V)
+  };
+  auto store_tile = [&](unsigned short* buf, const Req& r) __attribute__((always_inline)) {   // S
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) *reinterpret_cast<lce_bf16x8*>(buf + r32 * HST + 16 * ks + 8 * hh) = r.h[ks];
   };
   // the token side's last k-step: [1, 1, c_hi, c_lo, c_lo2, 0, 0, 0] in the hh = 0 lanes, c = ln|coef| - lse
   auto bias_col = [&](float coef, float lse) __attribute__((always_inline)) -> lce_bf16x8 {
@@ -1420,28 +1427,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // ---- prologue: tile 0 in buffer 0, tile 1 requested ----
   unsigned short* bufc = tbuf;                               // tile i
   unsigned short* bufn = tbuf + TILE;                        // tile i + 1
-  request(0);
-  store_tile(bufc);
-  float coef_c = coef_n;
-  int t_c = t_n;
-  lce_bf16x8 hb_c = bias_col(coef_n, lse_n);
-  request(1);
+  Req rq;
+  request(0, rq);
+  store_tile(bufc, rq);
+  float coef_c = is_valid(0) ? rq.dp * rq.tsc : 0.f;
+  int t_c = is_valid(0) ? rq.t : -1;
+  lce_bf16x8 hb_c = bias_col(coef_c, rq.lse);
+  request(1, rq);
   load_ht(bufc);
   f32x16 x0 = logits(bufc, hb_c, 0), x1;
   lce_u32x8 ovp = {0, 0, 0, 0, 0, 0, 0, 0};                  // no pending unit yet: a zero product
-  for (int i = 0; i < niter; ++i) {
+  for (int i = 0; i < niter; ++i) {                          // rq holds tile i + 1 (requested a tile ago)
     lce_bf16x8 hb_n;
     lce_u32x8 ov0, ov1;
+    float coef_x;
+    int t_x;
     {                                                        // region A: unit (i, 0)
       x1 = logits(bufc, hb_c, 1);                            // L(i, 1)
       ov0 = coefs(x0, db[0]);                                // V(i, 0)
       product(ovp, 1);                                       // D(i - 1, 1) on the previous tile's transposed fragments
-      store_tile(bufn);                                      // S(i + 1): the rows requested a tile ago
-      hb_n = bias_col(coef_n, lse_n);
+      store_tile(bufn, rq);                                  // S(i + 1)
+      coef_x = is_valid(i + 1) ? rq.dp * rq.tsc : 0.f;
+      t_x = is_valid(i + 1) ? rq.t : -1;
+      hb_n = bias_col(coef_x, rq.lse);
       load_ht(bufc);                                         // for D(i, 0), D(i, 1)
       pipe();
       if (__any(coef_c < 0.f || (t_c >> 5) == 2 * p)) fix(ov0, x0, db[0], 2 * p, t_c, coef_c);
     }
+    request(i + 2, rq);                                      // G(i + 2): a region and a half to arrive, nothing of it used before
     {                                                        // region B: unit (i, 1)
       x0 = logits(bufn, hb_n, 0);                            // L(i + 1, 0)
       ov1 = coefs(x1, db[1]);                                // V(i, 1)
@@ -1451,9 +1464,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     ovp = ov1;
     hb_c = hb_n;
-    coef_c = coef_n;
-    t_c = t_n;
-    request(i + 2);                                          // G(i + 2)
+    coef_c = coef_x;
+    t_c = t_x;
     unsigned short* sw = bufc;
     bufc = bufn;
     bufn = sw;
