@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmivae.so")
-SOURCES = ["elementwise.hip", "nice_stack.hip", "nice_big.hip", "invlinear.hip", "pairwise.hip", "mixed_stack.hip", "attention.hip", "nll.hip", "optim.hip", "layernorm.hip", "linear.hip", "maf.hip"]
+SOURCES = ["elementwise.hip", "nice_stack.hip", "nice_small.hip", "nice_big.hip", "invlinear.hip", "pairwise.hip", "mixed_stack.hip", "attention.hip", "nll.hip", "optim.hip", "layernorm.hip", "linear.hip", "maf.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
          "-Wno-unused-result"]
 # The MFMA kernels keep their f32 VALU work single-issue: beside MFMAs a packed v_pk_*_f32 costs more than the two plain

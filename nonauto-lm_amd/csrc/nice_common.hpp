@@ -288,4 +288,120 @@ __device__ __forceinline__ void store_tile_t(T* __restrict__ base, int row0, uns
   }
 }
 
+
+// ==== shared by nice_stack.hip and nice_small.hip ==================================================
+// ---- packed weight streams -------------------------------------------------------------------------
+// The packed image is two linear streams of equally sized "task" regions laid out in exactly the
+// order the kernels consume them, so staging is a pure sequential copy:
+//   F stream (forward; steps reversed when packed with inverse = 1): task (kk, c, net), c = 32-wide hidden
+//     chunk, net 0 = s, 1 = t (a pair per iteration: the s and t nets run on sibling waves):
+//     [W1n: NKS frags][W2p: HT*NS frags][tail]                                                  (tbf bytes)
+//   B stream (backward, steps K-1 .. 0): task (kk, phase, c); phase 0 = s-net forward recompute
+//     ([W1n][W2p][pad]), phase 1 / 2 = s / t net backward ([W1n][W2Tp][W1Tp]); + [tail]       (tbb bytes)
+//   tail (1 KiB): b1[32c .. 32c+31] (32 floats) | b2[0 .. hp) -- biases travel with the weights.
+// a fragment = 64 lanes x EPF elements (1 KiB bf16 / 256 B fp32); every task is a multiple of 1 KiB.
+struct Geom {
+  int h, H, hp, Hp, HT, HC, K;
+  int fe, nks, ns, esize;
+  int64_t nfe_f, nfe_b;   // fragment elements per task
+  int64_t tbf, tbb;       // bytes per task
+  int64_t off_b, total;
+};
+constexpr int kTailBytes = 1024;
+static inline Geom make_geom(int h, int H, int K, bool bf16) {
+  Geom g;
+  g.h = h; g.H = H; g.K = K;
+  g.hp = (h + 31) / 32 * 32; g.Hp = (H + 31) / 32 * 32;
+  g.HT = g.hp / 32; g.HC = g.Hp / 32;
+  const int epf = bf16 ? 8 : 1, ks = bf16 ? 16 : 2;
+  g.esize = bf16 ? 2 : 4;
+  g.fe = 64 * epf; g.nks = g.hp / ks; g.ns = 32 / ks;
+  g.nfe_f = (int64_t)(g.nks + g.HT * g.ns) * g.fe;
+  g.nfe_b = (int64_t)(g.nks + 2 * g.HT * g.ns) * g.fe;
+  g.tbf = g.nfe_f * g.esize + kTailBytes;
+  g.tbb = g.nfe_b * g.esize + kTailBytes;
+  g.off_b = (int64_t)K * 2 * g.HC * g.tbf;
+  g.total = g.off_b + (int64_t)K * 3 * g.HC * g.tbb;
+  return g;
+}
+
+struct StackArgs {
+  const void* z_in;     // (N, D)
+  void* z_out;          // (N, D)
+  void* x1_hist;        // (K, N, h) or null            [fwd: written, bwd: read]
+  const int64_t* mask;  // (Bn / mask_div, S) or null
+  const char* packed;
+  float* tok_val;       // (N) per-token masked log-det (+ base log-prob)
+  int64_t N;
+  int S, mask_div, D, K;
+  int inverse, base, act;
+  int G;                // tasks per staged block
+  int dbg;              // timing ablations (MIVAE_DBG env): 1 = no weight staging, 2 = no arithmetic
+  float mu, inv2var, cst;  // base dist: -(z-mu)^2 * inv2var - cst
+  // backward only
+  const void* dz_out;   // (N, D) or null
+  const float* dlogp;   // (Bn) or null: d loss / d (per-sentence sum of tok_val)
+  void* dz_in;          // (N, D)
+  void* Gt;             // (K, 2, Hp, Npad) d pre-activation, token-contiguous
+  void* Ht;             // (K, 2, Hp, Npad) hidden activations
+  void* dSt;            // (K, 2, hp, Npad) ds / dt
+  void* x0t;            // (hp, Npad) x0 * mask
+  int64_t Npad;
+  Geom g;
+};
+
+// 32 consecutive biases from the staged tail -> accumulator layout (broadcast ds_read_b128)
+__device__ __forceinline__ f32x16 bias_tile(const float* B, int hh) {
+  f32x16 a;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(B + 8 * q + 4 * hh);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[4 * q + i] = v[i];
+  }
+  return a;
+}
+
+// accumulator tiles <-> per-wave private LDS area (64 B per lane per tile, lane-linear)
+template <int HT>
+__device__ __forceinline__ void stash_put(float* st, const f32x16 (&x)[HT]) {
+#pragma unroll
+  for (int t = 0; t < HT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v = {x[t][4 * q], x[t][4 * q + 1], x[t][4 * q + 2], x[t][4 * q + 3]};
+      *reinterpret_cast<f32x4*>(st + t * 1024 + q * 256) = v;
+    }
+}
+template <int HT>
+__device__ __forceinline__ void stash_get(const float* st, f32x16 (&x)[HT]) {
+#pragma unroll
+  for (int t = 0; t < HT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(st + t * 1024 + q * 256);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[t][4 * q + e] = v[e];
+    }
+}
+
+struct DwArgs {
+  const void *Gt, *Ht, *dSt, *x0t;
+  float* part;    // [items][HT][64][16]
+  float* partb1;  // [items][32]        (type 0 items only are meaningful)
+  float* partb2;  // [K*2][nslab][hp]
+  float *dW1, *db1, *dW2, *db2;
+  const int64_t* sink;   // optional device table [K*2][4] of fp32 gradient addresses {W1, b1, W2, b2}: accumulate there
+  int64_t Npad;
+  int K, h, H, hp, Hp, HT, HC, nslab, slab_len;
+  int x0_per_step;   // 0: one x0t section shared by all steps (a coupling-only stack never changes x0); 1: one per step
+  int64_t nitems;
+};
+
+// fixed-order fold of the dumped partials (k_dw_reduce, nice_stack.hip)
+int nice_dw_reduce_launch(const DwArgs& a, hipStream_t st);
+// backward of small bf16 stacks with the nets of all steps side by side (k_stack_bwd_par, nice_small.hip)
+bool nice_small_bwd_takes(const StackArgs& a, bool bf16, bool vec);
+int nice_small_bwd_launch(const StackArgs& a, hipStream_t st);
+
 }  // namespace mivae

@@ -1,0 +1,345 @@
+// Backward of small fused NICE stacks with the coupling nets of all steps running side by side (gfx950).
+// Reference semantics: autograd of NICECoupling.forward (vae_lm/models/base/flows/couplings.py:141-162) with
+// FeedForwardCoupling nets (couplings.py:50-51, nn/feedforward.py:93-98) iterated by FlowPrior.forward_pass
+// (nonauto_lm/priors/flow_prior.py:37-52) + base log-prob (priors/prior.py:148-158) -- the same outputs as
+// mivae_nice_stack_bwd + mivae_nice_dw (nice_stack.hip), re-split for the shapes where that pair is latency-bound.
+#include "nice_common.hpp"
+#include <stdlib.h>
+
+using namespace mivae;
+
+namespace {
+
+// ---- one-launch backward with in-kernel weight gradients (small stacks) ------------------------------
+// For the stacks whose backward is latency- rather than MFMA-bound (bf16, h <= 32, H <= 64, K <= 4: BASELINE C2 / C4)
+// the work is re-split: the K x 2 coupling nets only depend on x0, so a block of 2K waves gives every (step, net) its
+// own wave for a 32-token tile and the nets run side by side instead of one after another.
+//   phase 1  every wave recomputes ITS net's hidden layer (value + derivative) from x0 with its weights held in
+//            registers for the whole kernel (no LDS staging, no per-task barrier); the s-net waves finish s_k and
+//            publish exp(s_k) in LDS;                                                              -- barrier A
+//   chain    every wave walks the affine chain down to its own step on the published exponentials (K x 16 fmuls
+//            per lane, redundantly) and forms its d s_k / d t_k in registers;
+//   phase 2  d hid = W2^T d out, d pre = d hid act', d x0 partial = W1^T d pre (accumulator -> B operand);
+//   phase 3  weight gradients of the wave's own net, tokens as the contraction: hid, d pre, d out and x0 are parked as
+//            [token][feature] bf16 images in the wave's LDS (8-byte slots XOR-swizzled: packed writes and the
+//            transposing reads are both conflict free) and come back through ds_read_b64_tr_b16 as the A / B
+//            fragments of dW1 += d pre x0^T, dW2^T += hid d out^T; bias gradients ride in one more accumulator tile
+//            against selector columns;                                                              -- barrier B
+//   reduce   the 2K partial d x0 tiles are summed in wave order and stored with the upstream x0 cotangent.
+// Accumulators live across the block's tiles and are dumped once, in k_dw_partial's format: k_dw_reduce folds the
+// per-block partials in fixed order.  No Gt / Ht / dSt / x0t side outputs, no second pass over the tokens.
+constexpr int kImgBytes = 2048;   // 32 tokens x 32 features bf16, 64-byte rows
+
+__device__ __forceinline__ int img_off(int row, int slot) { return row * 64 + 8 * (slot ^ ((row >> 1) & 7)); }
+
+// Per-lane byte offsets inside an image, computed once per kernel: po[g] = the 8-byte slot of accumulator registers
+// 4g .. 4g+3 (features 8g + 4hh ..) in the lane's token row; fo[0 / 1] = the two transposing reads of k-step 0
+// (k-step 1 is 1 KiB further: 16 rows, same swizzle).
+struct ImgLane {
+  int po[4], fo[2];
+  __device__ __forceinline__ void init(int lane) {
+    const int r32 = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) po[g] = img_off(r32, 2 * g + hh);
+    const int g4 = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int row = 8 * (g4 >> 1) + q, slot = 4 * (g4 & 1) + p;
+    fo[0] = img_off(row, slot);
+    fo[1] = img_off(row + 4, slot);
+  }
+};
+// accumulator tile (feature rows in the registers, token on the lane) -> [token][feature] image
+__device__ __forceinline__ void img_put(char* img, const ImgLane& L, const f32x16& x) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    u16x4 v = {f32_to_bf16(x[4 * g]), f32_to_bf16(x[4 * g + 1]), f32_to_bf16(x[4 * g + 2]), f32_to_bf16(x[4 * g + 3])};
+    *reinterpret_cast<u16x4*>(img + L.po[g]) = v;
+  }
+}
+// MFMA fragment of k-step s with the TOKENS as the contraction: f[j] = img[token 16 s + 8 hh + j][feature r32]
+// (A operand: row = feature; B operand: column = feature).  EXEC must be all ones.
+__device__ __forceinline__ bf16x8 img_frag(const char* img, const ImgLane& L, int s) {
+  typedef __attribute__((address_space(3))) bf16x4_tr* lds_ptr;
+  const bf16x4_tr v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(img + s * 1024 + L.fo[0]));
+  const bf16x4_tr v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(img + s * 1024 + L.fo[1]));
+  return __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// Backward of mivae_nice_stack_bwd for the shapes where nice_stack.hip's kernel is latency-bound (bf16, h <= 32,
+// H <= 64, K <= 4: BASELINE C2 / C4).  There a wave owns 32 tokens and walks 3 K HC staged weight tasks one after
+// another (24 barrier-separated tasks at C2, two waves per CU).  Here the work is re-split: the K x 2 coupling nets only
+// depend on x0, so a block of 2K waves gives every (step, net) its own wave for a 32-token tile.
+//   phase 1  every wave recomputes ITS net's hidden layer (value + derivative) from x0 with its own weight fragments
+//            (straight from the packed stream in L2: no LDS staging, no per-task barrier); the s-net waves finish s_k
+//            and publish exp(s_k) in LDS;                                                            -- barrier A
+//   chain    every wave walks the affine chain down to its own step on the published exponentials (<= K x 16 fmuls
+//            per lane, redundantly) and forms its d s_k / d t_k in registers;
+//   phase 2  d hid = W2^T d out, d pre = d hid act', d x0 partial = W1^T d pre (accumulator -> B operand);
+//   emit     hid, d pre, d out (and x0) are parked as [token][feature] bf16 images in the wave's LDS (8-byte slots
+//            XOR-swizzled: packed writes and transposing reads both conflict free) and leave through
+//            ds_read_b64_tr_b16 as 16-byte pieces of k_dw_partial's token-blocked layout: a lane holds 8 consecutive
+//            tokens of one feature, 32 lanes cover 512 contiguous bytes (the old kernel stored 2 bytes per lane);
+//                                                                                                    -- barrier B
+//   reduce   the 2K partial d x0 tiles are summed in wave order and stored with the upstream x0 cotangent.
+template <int ACT, int HC>
+__global__ void __launch_bounds__(512) k_stack_bwd_par(StackArgs a, int ntiles, int zero) {
+  typedef MmaBF16 P;
+  typedef unsigned short T;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const Geom& g = a.g;
+  const int lane = threadIdx.x & 63, r32 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int NW = blockDim.x >> 6;                       // = 2 K
+  const int k = wave >> 1, net = wave & 1;
+  const int h = g.h;
+  // LDS: [K] exp(s_k) tiles | [NW] d x0 partial tiles | x0 image | per wave: HC hid + HC (act' then d pre) + d out
+  // images, biases (b1 | b2)
+  float* sbuf = reinterpret_cast<float*>(smem);
+  float* dxbuf = sbuf + a.K * 1024;
+  char* x0img = reinterpret_cast<char*>(dxbuf + NW * 1024);
+  constexpr int kWaveBytes = (2 * HC + 1) * kImgBytes + 512;
+  char* const wbase = x0img + kImgBytes + wave * kWaveBytes;
+  constexpr int oHid = 0, oDpre = HC * kImgBytes, oDout = 2 * HC * kImgBytes, oBias = (2 * HC + 1) * kImgBytes;
+  ImgLane L;
+  L.init(lane);
+  // this wave's weights: fragments of the packed backward stream (k_nice_pack), tasks (phase, c): 0 = [W1n s][W2p s],
+  // 1 / 2 = s / t net [W1n][W2Tp][W1Tp]; 16 KB per wave, L2-resident, fetched per tile
+  const char* pk = a.packed + g.off_b + (int64_t)(a.K - 1 - k) * 3 * HC * g.tbb;
+  const bf16x8* f0 = reinterpret_cast<const bf16x8*>(pk) + lane;
+  const int tstride = (int)(g.tbb / 16);
+#pragma unroll
+  for (int c = 0; c < HC; ++c) {
+    const float* tail = reinterpret_cast<const float*>(pk + (int64_t)((1 + net) * HC + c) * g.tbb + g.nfe_b * 2);
+    float* bl0 = reinterpret_cast<float*>(wbase + oBias);
+    if (lane < 32) bl0[32 * c + lane] = tail[lane];
+    else if (c == 0) bl0[32 * HC + lane - 32] = tail[lane];
+  }
+  const float c2 = 2.0f * a.inv2var;
+  const T* zin = reinterpret_cast<const T*>(a.z_in);
+  const T* zout = reinterpret_cast<const T*>(a.z_out);
+  const T* gout = reinterpret_cast<const T*>(a.dz_out);
+  T* dzin = reinterpret_cast<T*>(a.dz_in);
+  // side outputs (token-blocked, 8 tokens per 16 bytes): this wave's sections
+  const int64_t ldn = a.Npad;
+  T* const Gt = reinterpret_cast<T*>(a.Gt) + (int64_t)wave * g.Hp * ldn;
+  T* const Ht = reinterpret_cast<T*>(a.Ht) + (int64_t)wave * g.Hp * ldn;
+  T* const dSt = reinterpret_cast<T*>(a.dSt) + (int64_t)wave * g.hp * ldn;
+  T* const x0t = reinterpret_cast<T*>(a.x0t);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // `vz` is zero, but not to the compiler: what is addressed through it is computed inside the loop instead of being
+    // hoisted out of it (hoisted, the bias tiles, image addresses and fragment pointers cost > 100 registers)
+    const int vz = tile * zero;
+    char* const wb = wbase + vz;
+    const float* const bl = reinterpret_cast<const float*>(wb + oBias);
+    char* const x0i = x0img + vz;
+    const bf16x8* const fv = f0 + vz;
+    const int64_t tok = (int64_t)tile * 32 + r32;
+    const bool valid = tok < a.N;
+    float m = 0.f, dl = 0.f;
+    if (valid) {
+      const int64_t bn = tok / a.S;
+      m = 1.f;
+      if (a.mask) m = (float)a.mask[(bn / a.mask_div) * a.S + (tok - bn * a.S)];
+      if (a.dlogp) dl = a.dlogp[bn] * m;
+    }
+    const bool withbase = a.base && a.dlogp;
+    const bool on = valid && m != 0.f;
+    // tiles of padding only are computed like any other: x0, cotangents and history read as zeros, every emitted
+    // column is an exact zero (k_dw_partial reads all Npad columns)
+    bf16x8 x0f[2];
+    load_x0_bf16<T, true, 2>(zin + tok * a.D, on, h, hh, x0f);
+    f32x16 g1[1], x1[1];
+    if (gout) load_acc<T, true, 1>(gout + tok * a.D + h, valid, h, hh, g1);
+    else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) g1[0][r] = 0.f;
+    }
+    if (withbase) {   // d / d z_K of the base log-prob: dl * -(z_K - mu) / std^2
+      f32x16 zk[1];
+      load_acc<T, true, 1>(zout + tok * a.D + h, valid, h, hh, zk);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) g1[0][r] += (acc_row(r, hh) < h) ? -dl * (zk[0][r] - a.mu) * c2 : 0.f;
+    }
+    if (net == 0)   // the step's saved input half (the forward writes no history for all-padding tiles: never read)
+      load_acc<T, true, 1>(reinterpret_cast<const T*>(a.x1_hist) + ((int64_t)k * a.N + tok) * h, on, h, hh, x1);
+    if (wave == 0) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const u16x8 raw = __builtin_bit_cast(u16x8, x0f[ks]);
+        const u16x4 lo = {raw[0], raw[1], raw[2], raw[3]}, hi = {raw[4], raw[5], raw[6], raw[7]};
+        *reinterpret_cast<u16x4*>(x0i + img_off(r32, 4 * ks + 2 * hh)) = lo;
+        *reinterpret_cast<u16x4*>(x0i + img_off(r32, 4 * ks + 2 * hh + 1)) = hi;
+      }
+    }
+    // ---- phase 1: hidden layer of this wave's net (value -> image, derivative -> lane-linear bf16), s-net: exp(s_k)
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+    {
+      bf16x8 w1n[HC][2], w2p[HC][2];
+#pragma unroll
+      for (int c = 0; c < HC; ++c)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          w1n[c][i] = fv[((1 + net) * HC + c) * tstride + i * 64];
+          if (net == 0) w2p[c][i] = fv[c * tstride + (2 + i) * 64];
+        }
+#pragma unroll
+      for (int c = 0; c < HC; ++c) {
+        f32x16 hid = bias_tile(bl + 32 * c, hh), dact;
+        hid = P::mma(w1n[c][0], x0f[0], hid);
+        hid = P::mma(w1n[c][1], x0f[1], hid);
+        act_tile_fd<ACT, true>(a.act, hid, dact);
+        img_put(wb + oHid + c * kImgBytes, L, hid);
+        {   // act' parked as bf16 in the lane's own 32 bytes (d pre is rounded to bf16 for its products anyway), in the
+            // area the d pre image of the chunk takes over in phase 2
+          u16x8 d0, d1;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { d0[j] = f32_to_bf16(dact[j]); d1[j] = f32_to_bf16(dact[8 + j]); }
+          *reinterpret_cast<u16x8*>(wb + oDpre + c * kImgBytes + lane * 16) = d0;
+          *reinterpret_cast<u16x8*>(wb + oDpre + c * kImgBytes + 1024 + lane * 16) = d1;
+        }
+        if (net == 0) {
+          sacc = P::mma(w2p[c][0], P::from_acc<0>(hid), sacc);
+          sacc = P::mma(w2p[c][1], P::from_acc<1>(hid), sacc);
+        }
+      }
+    }
+    if (net == 0) {
+      const f32x16 bt = bias_tile(bl + 32 * HC, hh);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[r] = fast_exp(sacc[r] + bt[r]);
+      const f32x16 e1[1] = {sacc};
+      stash_put<1>(sbuf + k * 1024 + lane * 4 + vz, e1);
+    }
+    // the weights of phase 2 are requested before the barrier: their L2 round trip passes while the block assembles
+    bf16x8 w2t[HC][2], w1t[HC][2];
+#pragma unroll
+    for (int c = 0; c < HC; ++c)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        w2t[c][i] = fv[((1 + net) * HC + c) * tstride + (2 + i) * 64];
+        w1t[c][i] = fv[((1 + net) * HC + c) * tstride + (4 + i) * 64];
+      }
+    __syncthreads();   // A: every exp(s_j) of this tile is published, the x0 image is complete
+    // ---- affine chain down to this wave's step: d t_k = g m prod_{j > k} e_j, d s_k = d t_k e_k x1_k + d logdet
+    f32x16 dout;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dout[r] = g1[0][r] * m;
+    for (int j = a.K - 1; j > k; --j) {
+      f32x16 ej[1];
+      stash_get<1>(sbuf + j * 1024 + lane * 4 + vz, ej);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dout[r] *= ej[0][r];
+    }
+    if (net == 0) {
+      f32x16 ge[1];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        ge[0][r] = dout[r] * sacc[r];
+        dout[r] = (acc_row(r, hh) < h) ? ge[0][r] * x1[0][r] + dl : 0.f;
+      }
+      if (k == 0) store_acc<T, true, 1>(dzin + tok * a.D + h, valid, h, hh, ge);   // d z_in, x1 half
+    }
+    // ---- phase 2: this net's backward
+    img_put(wb + oDout, L, dout);
+    f32x16 dx0p;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dx0p[r] = 0.f;
+    {
+      const bf16x8 bo0 = P::from_acc<0>(dout), bo1 = P::from_acc<1>(dout);
+#pragma unroll
+      for (int c = 0; c < HC; ++c) {
+        f32x16 dh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dh[r] = 0.f;
+        dh = P::mma(w2t[c][0], bo0, dh);
+        dh = P::mma(w2t[c][1], bo1, dh);
+        {
+          const u16x8 d0 = *reinterpret_cast<const u16x8*>(wb + oDpre + c * kImgBytes + lane * 16);
+          const u16x8 d1 = *reinterpret_cast<const u16x8*>(wb + oDpre + c * kImgBytes + 1024 + lane * 16);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { dh[j] *= bf16_to_f32(d0[j]); dh[8 + j] *= bf16_to_f32(d1[j]); }
+        }
+        // every lane has read its act' (LDS accesses of a wave complete in order): the area becomes the d pre image
+        img_put(wb + oDpre + c * kImgBytes, L, dh);
+        dx0p = P::mma(w1t[c][0], P::from_acc<0>(dh), dx0p);
+        dx0p = P::mma(w1t[c][1], P::from_acc<1>(dh), dx0p);
+      }
+    }
+    {
+      const f32x16 d1[1] = {dx0p};
+      stash_put<1>(dxbuf + wave * 1024 + lane * 4 + vz, d1);
+    }
+    // ---- emit the operands of the weight-gradient products: element (feature f, token t) of a section with F rows
+    // at ((t / 8) F + f) 8 + t % 8; a fragment = 8 consecutive tokens (16 s + 8 hh ..) of feature r32 = one 16-byte piece
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int64_t tb = (int64_t)tile * 4 + 2 * s + hh;      // 8-token block of this lane's piece
+#pragma unroll
+      for (int c = 0; c < HC; ++c) {
+        *reinterpret_cast<bf16x8*>(Ht + (tb * g.Hp + 32 * c + r32) * 8) = img_frag(wb + oHid + c * kImgBytes, L, s);
+        *reinterpret_cast<bf16x8*>(Gt + (tb * g.Hp + 32 * c + r32) * 8) = img_frag(wb + oDpre + c * kImgBytes, L, s);
+      }
+      *reinterpret_cast<bf16x8*>(dSt + (tb * g.hp + r32) * 8) = img_frag(wb + oDout, L, s);
+      if (wave == 0) *reinterpret_cast<bf16x8*>(x0t + (tb * g.hp + r32) * 8) = img_frag(x0i, L, s);
+    }
+    __syncthreads();   // B: all partial d x0 tiles are in LDS; every wave is done with sbuf and the x0 image
+    // ---- d z_in, x0 half: upstream cotangent (+ base term) + the 2K partial tiles in wave order
+    for (int q = wave; q < 4; q += NW) {
+      const int f = 8 * q + 4 * hh;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (valid && f < h) {
+        if (gout) RowIO<T, 4>::load(gout + tok * a.D + f, v);
+        if (withbase) {
+          float zk[4];
+          RowIO<T, 4>::load(zout + tok * a.D + f, zk);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] += -dl * (zk[i] - a.mu) * c2;
+        }
+      }
+      f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+      for (int w = NW - 1; w >= 0; --w) sum += *reinterpret_cast<const f32x4*>(dxbuf + w * 1024 + q * 256 + lane * 4 + vz);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = v[i] * m + sum[i];
+      if (valid && f < h) RowIO<T, 4>::store(dzin + tok * a.D + f, v);
+    }
+  }
+}
+
+}  // namespace
+
+// ---- host side: called by mivae_nice_stack_bwd (nice_stack.hip) --------------------------------------
+bool mivae::nice_small_bwd_takes(const StackArgs& a, bool bf16, bool vec) {
+  const char* e = getenv("MIVAE_NICE_BWD_PAR");     // read per call: tests and A/B timings switch it inside one process
+  const bool off = e && atoi(e) == 0;
+  const Geom& g = a.g;
+  return !off && bf16 && vec && g.HT == 1 && g.HC <= 2 && g.h % 8 == 0 && a.K <= 4 && a.x1_hist && a.Gt && a.Ht && a.dSt &&
+         a.x0t && aligned16(a.Gt) && aligned16(a.Ht) && aligned16(a.dSt) && aligned16(a.x0t);
+}
+
+int mivae::nice_small_bwd_launch(const StackArgs& a, hipStream_t st) {
+  const Geom& g = a.g;
+  const int ntiles = (int)(a.Npad / 32);                    // Npad is a multiple of 64: tiles past N emit zero columns
+  const int nblk = ntiles < 256 ? ntiles : 256, NW = 2 * a.K;
+  const size_t lds = (size_t)(a.K + NW) * 4096 + kImgBytes + (size_t)NW * ((2 * g.HC + 1) * kImgBytes + 512);
+#define MIVAE_BWD_PAR_LAUNCH(A_, HC_)                                                                              \
+  do {                                                                                                             \
+    if (lds > 64 * 1024)                                                                                           \
+      (void)hipFuncSetAttribute((const void*)k_stack_bwd_par<A_, HC_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds);                                                                         \
+    k_stack_bwd_par<A_, HC_><<<nblk, NW * 64, lds, st>>>(a, ntiles, 0);                                            \
+  } while (0)
+  if (a.act == ACT_GELU) {
+    if (g.HC == 1) MIVAE_BWD_PAR_LAUNCH(ACT_GELU, 1); else MIVAE_BWD_PAR_LAUNCH(ACT_GELU, 2);
+  } else {
+    if (g.HC == 1) MIVAE_BWD_PAR_LAUNCH(-1, 1); else MIVAE_BWD_PAR_LAUNCH(-1, 2);
+  }
+#undef MIVAE_BWD_PAR_LAUNCH
+  MIVAE_CHECK_LAUNCH("nice_stack_bwd (parallel nets)");
+  return MIVAE_OK;
+}
