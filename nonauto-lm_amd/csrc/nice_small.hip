@@ -10,6 +10,9 @@ using namespace mivae;
 
 namespace {
 
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_cvoid_t;
+
 // ---- one-launch backward with in-kernel weight gradients (small stacks) ------------------------------
 // For the stacks whose backward is latency- rather than MFMA-bound (bf16, h <= 32, H <= 64, K <= 4: BASELINE C2 / C4)
 // the work is re-split: the K x 2 coupling nets only depend on x0, so a block of 2K waves gives every (step, net) its
@@ -80,6 +83,10 @@ __device__ __forceinline__ bf16x8 img_frag(const char* img, const ImgLane& L, in
 //            tokens of one feature, 32 lanes cover 512 contiguous bytes (the old kernel stored 2 bytes per lane);
 //                                                                                                    -- barrier B
 //   reduce   the 2K partial d x0 tiles are summed in wave order and stored with the upstream x0 cotangent.
+// Block barrier that only waits for the wave's LDS traffic.  __syncthreads() also drains vmcnt: here that would wait out
+// the weight fragments requested ahead of barrier A and the side-output stores issued ahead of barrier B (1-2 us each).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int ACT, int HC>
 __global__ void __launch_bounds__(512) k_stack_bwd_par(StackArgs a, int ntiles, int zero) {
   typedef MmaBF16 P;
@@ -96,7 +103,7 @@ __global__ void __launch_bounds__(512) k_stack_bwd_par(StackArgs a, int ntiles, 
   float* sbuf = reinterpret_cast<float*>(smem);
   float* dxbuf = sbuf + a.K * 1024;
   char* x0img = reinterpret_cast<char*>(dxbuf + NW * 1024);
-  constexpr int kWaveBytes = (2 * HC + 1) * kImgBytes + 512;
+  constexpr int kWaveBytes = (2 * HC + 1) * kImgBytes + 512;   // biases: HC x [b1 chunk (32 floats) | b2 (32 floats)]
   char* const wbase = x0img + kImgBytes + wave * kWaveBytes;
   constexpr int oHid = 0, oDpre = HC * kImgBytes, oDout = 2 * HC * kImgBytes, oBias = (2 * HC + 1) * kImgBytes;
   ImgLane L;
@@ -106,12 +113,13 @@ __global__ void __launch_bounds__(512) k_stack_bwd_par(StackArgs a, int ntiles, 
   const char* pk = a.packed + g.off_b + (int64_t)(a.K - 1 - k) * 3 * HC * g.tbb;
   const bf16x8* f0 = reinterpret_cast<const bf16x8*>(pk) + lane;
   const int tstride = (int)(g.tbb / 16);
+  // biases: the 256-byte tail of the net's task c ([b1 chunk c | b2]) goes straight to the wave's LDS by LDS-DMA (one
+  // instruction per chunk, no register, no wait here: the first tile's loads are issued behind it and one vmcnt(0)
+  // ahead of phase 1 covers both)
 #pragma unroll
   for (int c = 0; c < HC; ++c) {
-    const float* tail = reinterpret_cast<const float*>(pk + (int64_t)((1 + net) * HC + c) * g.tbb + g.nfe_b * 2);
-    float* bl0 = reinterpret_cast<float*>(wbase + oBias);
-    if (lane < 32) bl0[32 * c + lane] = tail[lane];
-    else if (c == 0) bl0[32 * HC + lane - 32] = tail[lane];
+    const char* tail = pk + (int64_t)((1 + net) * HC + c) * g.tbb + g.nfe_b * 2;
+    __builtin_amdgcn_global_load_lds((glb_cvoid_t*)(tail + lane * 4), (lds_void_t*)(wbase + oBias + c * 256), 4, 0, 0);
   }
   const float c2 = 2.0f * a.inv2var;
   const T* zin = reinterpret_cast<const T*>(a.z_in);
@@ -124,8 +132,6 @@ __global__ void __launch_bounds__(512) k_stack_bwd_par(StackArgs a, int ntiles, 
   T* const Ht = reinterpret_cast<T*>(a.Ht) + (int64_t)wave * g.Hp * ldn;
   T* const dSt = reinterpret_cast<T*>(a.dSt) + (int64_t)wave * g.hp * ldn;
   T* const x0t = reinterpret_cast<T*>(a.x0t);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     // `vz` is zero, but not to the compiler: what is addressed through it is computed inside the loop instead of being
@@ -142,28 +148,49 @@ __global__ void __launch_bounds__(512) k_stack_bwd_par(StackArgs a, int ntiles, 
       const int64_t bn = tok / a.S;
       m = 1.f;
       if (a.mask) m = (float)a.mask[(bn / a.mask_div) * a.S + (tok - bn * a.S)];
-      if (a.dlogp) dl = a.dlogp[bn] * m;
+      if (a.dlogp) dl = a.dlogp[bn];
     }
     const bool withbase = a.base && a.dlogp;
-    const bool on = valid && m != 0.f;
     // tiles of padding only are computed like any other: x0, cotangents and history read as zeros, every emitted
-    // column is an exact zero (k_dw_partial reads all Npad columns)
+    // column is an exact zero (k_dw_partial reads all Npad columns).  Every load below is issued on `valid` alone and
+    // zeroed by a select once the mask has arrived: one memory round trip per tile instead of two.
     bf16x8 x0f[2];
-    load_x0_bf16<T, true, 2>(zin + tok * a.D, on, h, hh, x0f);
+    load_x0_bf16<T, true, 2>(zin + tok * a.D, valid, h, hh, x0f);
     f32x16 g1[1], x1[1];
     if (gout) load_acc<T, true, 1>(gout + tok * a.D + h, valid, h, hh, g1);
     else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) g1[0][r] = 0.f;
     }
-    if (withbase) {   // d / d z_K of the base log-prob: dl * -(z_K - mu) / std^2
-      f32x16 zk[1];
-      load_acc<T, true, 1>(zout + tok * a.D + h, valid, h, hh, zk);
+    f32x16 zk1[1];
+    if (withbase) load_acc<T, true, 1>(zout + tok * a.D + h, valid, h, hh, zk1);
+    if (net == 0)   // the step's saved input half (the forward writes no history for all-padding tiles: selected away)
+      load_acc<T, true, 1>(reinterpret_cast<const T*>(a.x1_hist) + ((int64_t)k * a.N + tok) * h, valid, h, hh, x1);
+    // upstream cotangent (+ base term input) of the x0 slices this wave reduces after barrier B
+    u16x4 g0raw[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, z0raw[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
-      for (int r = 0; r < 16; ++r) g1[0][r] += (acc_row(r, hh) < h) ? -dl * (zk[0][r] - a.mu) * c2 : 0.f;
+    for (int i = 0; i < 2; ++i) {
+      const int q = wave + i * NW, f = 8 * q + 4 * hh;
+      if (q < 4 && valid && f < h) {
+        if (gout) g0raw[i] = *reinterpret_cast<const u16x4*>(gout + tok * a.D + f);
+        if (withbase) z0raw[i] = *reinterpret_cast<const u16x4*>(zout + tok * a.D + f);
+      }
     }
-    if (net == 0)   // the step's saved input half (the forward writes no history for all-padding tiles: never read)
-      load_acc<T, true, 1>(reinterpret_cast<const T*>(a.x1_hist) + ((int64_t)k * a.N + tok) * h, on, h, hh, x1);
+    {   // the mask has arrived: padding tokens contribute exact zeros
+      const bool on = m != 0.f;
+      dl *= m;
+      const u16x8 zr = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) x0f[ks] = on ? x0f[ks] : __builtin_bit_cast(bf16x8, zr);
+      if (net == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x1[0][r] = on ? x1[0][r] : 0.f;
+      }
+      if (withbase) {   // d / d z_K of the base log-prob: dl * -(z_K - mu) / std^2
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g1[0][r] += (acc_row(r, hh) < h) ? -dl * (zk1[0][r] - a.mu) * c2 : 0.f;
+      }
+    }
     if (wave == 0) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -173,6 +200,7 @@ __global__ void __launch_bounds__(512) k_stack_bwd_par(StackArgs a, int ntiles, 
         *reinterpret_cast<u16x4*>(x0i + img_off(r32, 4 * ks + 2 * hh + 1)) = hi;
       }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of the biases is not in the compiler's count
     // ---- phase 1: hidden layer of this wave's net (value -> image, derivative -> lane-linear bf16), s-net: exp(s_k)
     f32x16 sacc;
 #pragma unroll
@@ -188,7 +216,7 @@ __global__ void __launch_bounds__(512) k_stack_bwd_par(StackArgs a, int ntiles, 
         }
 #pragma unroll
       for (int c = 0; c < HC; ++c) {
-        f32x16 hid = bias_tile(bl + 32 * c, hh), dact;
+        f32x16 hid = bias_tile(bl + 64 * c, hh), dact;
         hid = P::mma(w1n[c][0], x0f[0], hid);
         hid = P::mma(w1n[c][1], x0f[1], hid);
         act_tile_fd<ACT, true>(a.act, hid, dact);
@@ -208,7 +236,7 @@ __global__ void __launch_bounds__(512) k_stack_bwd_par(StackArgs a, int ntiles, 
       }
     }
     if (net == 0) {
-      const f32x16 bt = bias_tile(bl + 32 * HC, hh);
+      const f32x16 bt = bias_tile(bl + 32, hh);
 #pragma unroll
       for (int r = 0; r < 16; ++r) sacc[r] = fast_exp(sacc[r] + bt[r]);
       const f32x16 e1[1] = {sacc};
@@ -223,7 +251,7 @@ __global__ void __launch_bounds__(512) k_stack_bwd_par(StackArgs a, int ntiles, 
         w2t[c][i] = fv[((1 + net) * HC + c) * tstride + (2 + i) * 64];
         w1t[c][i] = fv[((1 + net) * HC + c) * tstride + (4 + i) * 64];
       }
-    __syncthreads();   // A: every exp(s_j) of this tile is published, the x0 image is complete
+    lds_barrier();     // A: every exp(s_j) of this tile is published, the x0 image is complete
     // ---- affine chain down to this wave's step: d t_k = g m prod_{j > k} e_j, d s_k = d t_k e_k x1_k + d logdet
     f32x16 dout;
 #pragma unroll
@@ -288,19 +316,18 @@ __global__ void __launch_bounds__(512) k_stack_bwd_par(StackArgs a, int ntiles, 
       *reinterpret_cast<bf16x8*>(dSt + (tb * g.hp + r32) * 8) = img_frag(wb + oDout, L, s);
       if (wave == 0) *reinterpret_cast<bf16x8*>(x0t + (tb * g.hp + r32) * 8) = img_frag(x0i, L, s);
     }
-    __syncthreads();   // B: all partial d x0 tiles are in LDS; every wave is done with sbuf and the x0 image
+    lds_barrier();     // B: all partial d x0 tiles are in LDS; every wave is done with sbuf and the x0 image
     // ---- d z_in, x0 half: upstream cotangent (+ base term) + the 2K partial tiles in wave order
-    for (int q = wave; q < 4; q += NW) {
-      const int f = 8 * q + 4 * hh;
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
-      if (valid && f < h) {
-        if (gout) RowIO<T, 4>::load(gout + tok * a.D + f, v);
-        if (withbase) {
-          float zk[4];
-          RowIO<T, 4>::load(zout + tok * a.D + f, zk);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] += -dl * (zk[i] - a.mu) * c2;
-        }
+    for (int qi = 0; qi < 2; ++qi) {
+      const int q = wave + qi * NW;
+      if (q >= 4) break;                       // wave-uniform
+      const int f = 8 * q + 4 * hh;
+      float v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[i] = bf16_to_f32(g0raw[qi][i]);
+        if (withbase && valid && f < h) v[i] += -dl * (bf16_to_f32(z0raw[qi][i]) - a.mu) * c2;
       }
       f32x4 sum = {0.f, 0.f, 0.f, 0.f};
       for (int w = NW - 1; w >= 0; --w) sum += *reinterpret_cast<const f32x4*>(dxbuf + w * 1024 + q * 256 + lane * 4 + vz);

@@ -728,15 +728,33 @@ __global__ void __launch_bounds__(256) k_dw_reduce(DwArgs a) {
   if (idx < nb1) {
     const int row = (int)(idx % a.H); const int kn = (int)(idx / a.H);
     const int64_t item0 = (((int64_t)kn * 2 + 0) * a.HC + row / 32) * a.nslab;
+    const float* p = a.partb1 + item0 * 32 + row % 32;
     float s = 0.f;
-    for (int sl = 0; sl < a.nslab; ++sl) s += a.partb1[(item0 + sl) * 32 + row % 32];
+    int sl = 0;
+    for (; sl + 8 <= a.nslab; sl += 8) {         // eight loads in flight, summed in slab order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(sl + u) * 32];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; sl < a.nslab; ++sl) s += p[sl * 32];
     if (a.sink) reinterpret_cast<float*>(a.sink[kn * 4 + 1])[row] += s;
     else a.db1[idx] = s;
   } else if (idx < nb1 + nb2) {
     idx -= nb1;
     const int out = (int)(idx % a.h); const int kn = (int)(idx / a.h);
+    const float* p = a.partb2 + (int64_t)kn * a.nslab * a.hp + out;
     float s = 0.f;
-    for (int sl = 0; sl < a.nslab; ++sl) s += a.partb2[((int64_t)kn * a.nslab + sl) * a.hp + out];
+    int sl = 0;
+    for (; sl + 8 <= a.nslab; sl += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(sl + u) * a.hp];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; sl < a.nslab; ++sl) s += p[(int64_t)sl * a.hp];
     if (a.sink) reinterpret_cast<float*>(a.sink[kn * 4 + 3])[out] += s;
     else a.db2[idx] = s;
   }
