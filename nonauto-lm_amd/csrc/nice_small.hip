@@ -143,52 +143,81 @@ __global__ void __launch_bounds__(512) k_stack_bwd_par(StackArgs a, int ntiles, 
     const bf16x8* const fv = f0 + vz;
     const int64_t tok = (int64_t)tile * 32 + r32;
     const bool valid = tok < a.N;
-    float m = 0.f, dl = 0.f;
-    if (valid) {
-      const int64_t bn = tok / a.S;
-      m = 1.f;
-      if (a.mask) m = (float)a.mask[(bn / a.mask_div) * a.S + (tok - bn * a.S)];
-      if (a.dlogp) dl = a.dlogp[bn];
-    }
     const bool withbase = a.base && a.dlogp;
-    // tiles of padding only are computed like any other: x0, cotangents and history read as zeros, every emitted
-    // column is an exact zero (k_dw_partial reads all Npad columns).  Every load below is issued on `valid` alone and
-    // zeroed by a select once the mask has arrived: one memory round trip per tile instead of two.
-    bf16x8 x0f[2];
-    load_x0_bf16<T, true, 2>(zin + tok * a.D, valid, h, hh, x0f);
-    f32x16 g1[1], x1[1];
-    if (gout) load_acc<T, true, 1>(gout + tok * a.D + h, valid, h, hh, g1);
-    else {
+    // ---- every global load of the tile, branch-free and back to back: addresses are clamped into range (token N - 1,
+    // feature 0) and what must not count is zeroed by a select afterwards.  (A load inside `if (valid && f < h)` makes the
+    // compiler wait for it inside the branch: twelve serialised round trips per tile.)  Tiles of padding only are
+    // computed like any other: x0, cotangents and history select to zeros, every emitted column is an exact zero.
+    const int64_t tc = valid ? tok : a.N - 1;
+    const int tc32 = (int)tc, bn = tc32 / a.S;             // N < 2^31 (host check): 32-bit divisions
+    // the int64 0 / 1 mask is read as its low word; converted after the wait below, not inside this branch
+    int mraw = a.mask ? reinterpret_cast<const int*>(a.mask)[2 * ((int64_t)(bn / a.mask_div) * a.S + (tc32 - bn * a.S))] : 1;
+    float dlraw = a.dlogp ? a.dlogp[bn] : 0.f;
+    const T* zr = zin + tc * a.D;
+    u16x8 x0raw[2];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) g1[0][r] = 0.f;
+    for (int ks = 0; ks < 2; ++ks) x0raw[ks] = *reinterpret_cast<const u16x8*>(zr + (16 * ks + 8 * hh < h ? 16 * ks + 8 * hh : 0));
+    int fcl[4];                                            // the lane's four 4-feature groups, clamped
+#pragma unroll
+    for (int q = 0; q < 4; ++q) fcl[q] = 8 * q + 4 * hh < h ? 8 * q + 4 * hh : 0;
+    u16x4 g1raw[4], zkraw[4], x1raw[4];
+    const u16x4 zero4 = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      g1raw[q] = gout ? *reinterpret_cast<const u16x4*>(gout + tc * a.D + h + fcl[q]) : zero4;
+      zkraw[q] = withbase ? *reinterpret_cast<const u16x4*>(zout + tc * a.D + h + fcl[q]) : zero4;
+      x1raw[q] = net == 0 ? *reinterpret_cast<const u16x4*>(reinterpret_cast<const T*>(a.x1_hist) + ((int64_t)k * a.N + tc) * h + fcl[q])
+                          : zero4;
     }
-    f32x16 zk1[1];
-    if (withbase) load_acc<T, true, 1>(zout + tok * a.D + h, valid, h, hh, zk1);
-    if (net == 0)   // the step's saved input half (the forward writes no history for all-padding tiles: selected away)
-      load_acc<T, true, 1>(reinterpret_cast<const T*>(a.x1_hist) + ((int64_t)k * a.N + tok) * h, valid, h, hh, x1);
     // upstream cotangent (+ base term input) of the x0 slices this wave reduces after barrier B
-    u16x4 g0raw[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, z0raw[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    u16x4 g0raw[2], z0raw[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int q = wave + i * NW, f = 8 * q + 4 * hh;
-      if (q < 4 && valid && f < h) {
-        if (gout) g0raw[i] = *reinterpret_cast<const u16x4*>(gout + tok * a.D + f);
-        if (withbase) z0raw[i] = *reinterpret_cast<const u16x4*>(zout + tok * a.D + f);
-      }
+      const int q = wave + i * NW < 4 ? wave + i * NW : 0;
+      g0raw[i] = gout ? *reinterpret_cast<const u16x4*>(gout + tc * a.D + fcl[q]) : zero4;
+      z0raw[i] = withbase ? *reinterpret_cast<const u16x4*>(zout + tc * a.D + fcl[q]) : zero4;
     }
-    {   // the mask has arrived: padding tokens contribute exact zeros
-      const bool on = m != 0.f;
-      dl *= m;
-      const u16x8 zr = {0, 0, 0, 0, 0, 0, 0, 0};
+    // this tile's weight fragments (L2): both phases requested here, behind the activations
+    bf16x8 w1n[HC][2], w2p[HC][2], w2t[HC][2], w1t[HC][2];
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) x0f[ks] = on ? x0f[ks] : __builtin_bit_cast(bf16x8, zr);
-      if (net == 0) {
+    for (int c = 0; c < HC; ++c)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) x1[0][r] = on ? x1[0][r] : 0.f;
+      for (int i = 0; i < 2; ++i) {
+        w1n[c][i] = fv[((1 + net) * HC + c) * tstride + i * 64];
+        w2p[c][i] = fv[c * tstride + (2 + i) * 64];       // s-net waves only use it (t-net waves: a dead load)
+        w2t[c][i] = fv[((1 + net) * HC + c) * tstride + (2 + i) * 64];
+        w1t[c][i] = fv[((1 + net) * HC + c) * tstride + (4 + i) * 64];
       }
-      if (withbase) {   // d / d z_K of the base log-prob: dl * -(z_K - mu) / std^2
+    // one wait for everything requested above (the LDS-DMA of the biases is not in the compiler's count)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(mraw), "+v"(dlraw) : : "memory");
+    // ---- selects: padding tokens, tokens past N and padded features contribute exact zeros
+    const float m = valid ? (float)mraw : 0.f;
+    const float dl = valid ? dlraw * m : 0.f;
+    const bool on = m != 0.f;
+    bf16x8 x0f[2];
+    f32x16 g1[1], x1[1];
+    {
+      const u16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) g1[0][r] += (acc_row(r, hh) < h) ? -dl * (zk1[0][r] - a.mu) * c2 : 0.f;
+      for (int ks = 0; ks < 2; ++ks)
+        x0f[ks] = __builtin_bit_cast(bf16x8, (on && 16 * ks + 8 * hh < h) ? x0raw[ks] : zero8);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool in = 8 * q + 4 * hh < h;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float gv = (valid && in) ? bf16_to_f32(g1raw[q][i]) : 0.f;
+          // d / d z_K of the base log-prob: dl * -(z_K - mu) / std^2
+          if (withbase) gv += in ? -dl * (bf16_to_f32(zkraw[q][i]) - a.mu) * c2 : 0.f;
+          g1[0][4 * q + i] = gv;
+          x1[0][4 * q + i] = (on && in) ? bf16_to_f32(x1raw[q][i]) : 0.f;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bool in = wave + i * NW < 4 && valid && 8 * (wave + i * NW) + 4 * hh < h;
+        g0raw[i] = in ? g0raw[i] : zero4;
+        z0raw[i] = in ? z0raw[i] : zero4;
       }
     }
     if (wave == 0) {
@@ -200,20 +229,11 @@ __global__ void __launch_bounds__(512) k_stack_bwd_par(StackArgs a, int ntiles, 
         *reinterpret_cast<u16x4*>(x0i + img_off(r32, 4 * ks + 2 * hh + 1)) = hi;
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of the biases is not in the compiler's count
     // ---- phase 1: hidden layer of this wave's net (value -> image, derivative -> lane-linear bf16), s-net: exp(s_k)
     f32x16 sacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
     {
-      bf16x8 w1n[HC][2], w2p[HC][2];
-#pragma unroll
-      for (int c = 0; c < HC; ++c)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          w1n[c][i] = fv[((1 + net) * HC + c) * tstride + i * 64];
-          if (net == 0) w2p[c][i] = fv[c * tstride + (2 + i) * 64];
-        }
 #pragma unroll
       for (int c = 0; c < HC; ++c) {
         f32x16 hid = bias_tile(bl + 64 * c, hh), dact;
@@ -242,15 +262,6 @@ __global__ void __launch_bounds__(512) k_stack_bwd_par(StackArgs a, int ntiles, 
       const f32x16 e1[1] = {sacc};
       stash_put<1>(sbuf + k * 1024 + lane * 4 + vz, e1);
     }
-    // the weights of phase 2 are requested before the barrier: their L2 round trip passes while the block assembles
-    bf16x8 w2t[HC][2], w1t[HC][2];
-#pragma unroll
-    for (int c = 0; c < HC; ++c)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        w2t[c][i] = fv[((1 + net) * HC + c) * tstride + (2 + i) * 64];
-        w1t[c][i] = fv[((1 + net) * HC + c) * tstride + (4 + i) * 64];
-      }
     lds_barrier();     // A: every exp(s_j) of this tile is published, the x0 image is complete
     // ---- affine chain down to this wave's step: d t_k = g m prod_{j > k} e_j, d s_k = d t_k e_k x1_k + d logdet
     f32x16 dout;
@@ -327,7 +338,7 @@ __global__ void __launch_bounds__(512) k_stack_bwd_par(StackArgs a, int ntiles, 
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         v[i] = bf16_to_f32(g0raw[qi][i]);
-        if (withbase && valid && f < h) v[i] += -dl * (bf16_to_f32(z0raw[qi][i]) - a.mu) * c2;
+        if (withbase && f < h) v[i] += -dl * (bf16_to_f32(z0raw[qi][i]) - a.mu) * c2;     // dl is zero past N
       }
       f32x4 sum = {0.f, 0.f, 0.f, 0.f};
       for (int w = NW - 1; w >= 0; --w) sum += *reinterpret_cast<const f32x4*>(dxbuf + w * 1024 + q * 256 + lane * 4 + vz);
@@ -351,6 +362,7 @@ bool mivae::nice_small_bwd_takes(const StackArgs& a, bool bf16, bool vec) {
 
 int mivae::nice_small_bwd_launch(const StackArgs& a, hipStream_t st) {
   const Geom& g = a.g;
+  MIVAE_REQUIRE(a.Npad < (int64_t)1 << 31, "nice_stack_bwd: too many tokens for the small-stack kernel");
   const int ntiles = (int)(a.Npad / 32);                    // Npad is a multiple of 64: tiles past N emit zero columns
   const int nblk = ntiles < 256 ? ntiles : 256, NW = 2 * a.K;
   const size_t lds = (size_t)(a.K + NW) * 4096 + kImgBytes + (size_t)NW * ((2 * g.HC + 1) * kImgBytes + 512);
