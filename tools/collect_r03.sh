@@ -1,11 +1,11 @@
 #!/bin/bash
-# usage (GPU box): tools/collect_r03.sh <outdir-under-gpurun_out>
+# usage (GPU box): tools/collect_r03.sh <outdir-under-gpurun_out> ["c2 c3 c5"]
 # Round-3 evidence set: FETCH_SIZE / WRITE_SIZE passes of tools/pmc_target.py for c2, c3, c5 (-> profiles/pmc_traffic.json
 # through tools/pmc_traffic.py), rocprofv3 kernel stats of the graph-replayed C2 step and of the eager C4 step.
 out=$GRAFT_REPO_ROOT/gpurun_out/$1
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-for cfg in c2 c3 c5; do
+for cfg in ${2:-c2 c3 c5}; do
   for ctr in FETCH_SIZE WRITE_SIZE; do
     timeout -s KILL 200 rocprofv3 --pmc $ctr --output-format csv -d $out/pmc_${cfg}_$ctr -o p -- python3 $GRAFT_REPO_ROOT/tools/pmc_target.py $cfg 3 > $out/pmc_${cfg}_$ctr.log 2>&1 || { tail -5 $out/pmc_${cfg}_$ctr.log; exit 1; }
   done
