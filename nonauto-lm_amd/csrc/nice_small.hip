@@ -133,30 +133,55 @@ __global__ void __launch_bounds__(512) k_stack_bwd_par(StackArgs a, int ntiles, 
   T* const dSt = reinterpret_cast<T*>(a.dSt) + (int64_t)wave * g.hp * ldn;
   T* const x0t = reinterpret_cast<T*>(a.x0t);
 
+  // this wave's 16 weight fragments stay in registers for all of the block's tiles.  (Fetched per tile they were the
+  // largest single cost of a tile: 8 waves x 16 KB through the CU's 64 B/clk vector-memory path = 2 k cycles of issue,
+  // during which the last wave has not even started -- stamped with s_memtime: loads issued 5.5 k / 9.2 k cycles after
+  // tile start for waves 0 / 7 of a 22 k-cycle tile.)  They were live through most of a tile anyway: same register peak.
+  bf16x8 w1n[HC][2], w2p[HC][2], w2t[HC][2], w1t[HC][2];
+#pragma unroll
+  for (int c = 0; c < HC; ++c)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      w1n[c][i] = f0[((1 + net) * HC + c) * tstride + i * 64];
+      w2p[c][i] = f0[c * tstride + (2 + i) * 64];       // s-net waves only use it
+      w2t[c][i] = f0[((1 + net) * HC + c) * tstride + (2 + i) * 64];
+      w1t[c][i] = f0[((1 + net) * HC + c) * tstride + (4 + i) * 64];
+    }
+
+  // What phase 1 needs of a tile -- x0, the mask word, the sentence's log-det cotangent -- is requested one tile AHEAD
+  // (a tile's HBM round trip is ~3.6 k of its ~21 k cycles: stamped); everything else of a tile is requested at its top
+  // and lands under phase 1.  `head` issues those three loads for the tile of lane-token `t` (clamped into range).
+  u16x8 x0raw[2];
+  int mraw;
+  float dlraw;
+  auto head = [&](int64_t t, u16x8 (&x0r)[2], int& mr, float& dr) __attribute__((always_inline)) {
+    const int64_t tcl = t < a.N ? t : a.N - 1;
+    const int t32 = (int)tcl, bn = t32 / a.S;              // N < 2^31 (host check): 32-bit divisions
+    // the int64 0 / 1 mask is read as its low word
+    mr = a.mask ? reinterpret_cast<const int*>(a.mask)[2 * ((int64_t)(bn / a.mask_div) * a.S + (t32 - bn * a.S))] : 1;
+    dr = a.dlogp ? a.dlogp[bn] : 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      x0r[ks] = *reinterpret_cast<const u16x8*>(zin + tcl * a.D + (16 * ks + 8 * hh < h ? 16 * ks + 8 * hh : 0));
+  };
+  head((int64_t)blockIdx.x * 32 + r32, x0raw, mraw, dlraw);
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(mraw), "+v"(dlraw) : : "memory");   // also the LDS-DMA of the biases, which the
+                                                                                // compiler does not count
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     // `vz` is zero, but not to the compiler: what is addressed through it is computed inside the loop instead of being
-    // hoisted out of it (hoisted, the bias tiles, image addresses and fragment pointers cost > 100 registers)
+    // hoisted out of it (hoisted, the bias tiles and image addresses cost > 100 registers)
     const int vz = tile * zero;
     char* const wb = wbase + vz;
     const float* const bl = reinterpret_cast<const float*>(wb + oBias);
     char* const x0i = x0img + vz;
-    const bf16x8* const fv = f0 + vz;
     const int64_t tok = (int64_t)tile * 32 + r32;
     const bool valid = tok < a.N;
     const bool withbase = a.base && a.dlogp;
-    // ---- every global load of the tile, branch-free and back to back: addresses are clamped into range (token N - 1,
+    // ---- the tile's other global loads, branch-free and back to back: addresses are clamped into range (token N - 1,
     // feature 0) and what must not count is zeroed by a select afterwards.  (A load inside `if (valid && f < h)` makes the
     // compiler wait for it inside the branch: twelve serialised round trips per tile.)  Tiles of padding only are
     // computed like any other: x0, cotangents and history select to zeros, every emitted column is an exact zero.
     const int64_t tc = valid ? tok : a.N - 1;
-    const int tc32 = (int)tc, bn = tc32 / a.S;             // N < 2^31 (host check): 32-bit divisions
-    // the int64 0 / 1 mask is read as its low word; converted after the wait below, not inside this branch
-    int mraw = a.mask ? reinterpret_cast<const int*>(a.mask)[2 * ((int64_t)(bn / a.mask_div) * a.S + (tc32 - bn * a.S))] : 1;
-    float dlraw = a.dlogp ? a.dlogp[bn] : 0.f;
-    const T* zr = zin + tc * a.D;
-    u16x8 x0raw[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) x0raw[ks] = *reinterpret_cast<const u16x8*>(zr + (16 * ks + 8 * hh < h ? 16 * ks + 8 * hh : 0));
     int fcl[4];                                            // the lane's four 4-feature groups, clamped
 #pragma unroll
     for (int q = 0; q < 4; ++q) fcl[q] = 8 * q + 4 * hh < h ? 8 * q + 4 * hh : 0;
@@ -177,49 +202,19 @@ __global__ void __launch_bounds__(512) k_stack_bwd_par(StackArgs a, int ntiles, 
       g0raw[i] = gout ? *reinterpret_cast<const u16x4*>(gout + tc * a.D + fcl[q]) : zero4;
       z0raw[i] = withbase ? *reinterpret_cast<const u16x4*>(zout + tc * a.D + fcl[q]) : zero4;
     }
-    // this tile's weight fragments (L2): both phases requested here, behind the activations
-    bf16x8 w1n[HC][2], w2p[HC][2], w2t[HC][2], w1t[HC][2];
-#pragma unroll
-    for (int c = 0; c < HC; ++c)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        w1n[c][i] = fv[((1 + net) * HC + c) * tstride + i * 64];
-        w2p[c][i] = fv[c * tstride + (2 + i) * 64];       // s-net waves only use it (t-net waves: a dead load)
-        w2t[c][i] = fv[((1 + net) * HC + c) * tstride + (2 + i) * 64];
-        w1t[c][i] = fv[((1 + net) * HC + c) * tstride + (4 + i) * 64];
-      }
-    // one wait for everything requested above (the LDS-DMA of the biases is not in the compiler's count)
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(mraw), "+v"(dlraw) : : "memory");
     // ---- selects: padding tokens, tokens past N and padded features contribute exact zeros
     const float m = valid ? (float)mraw : 0.f;
     const float dl = valid ? dlraw * m : 0.f;
     const bool on = m != 0.f;
     bf16x8 x0f[2];
-    f32x16 g1[1], x1[1];
     {
       const u16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
         x0f[ks] = __builtin_bit_cast(bf16x8, (on && 16 * ks + 8 * hh < h) ? x0raw[ks] : zero8);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const bool in = 8 * q + 4 * hh < h;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float gv = (valid && in) ? bf16_to_f32(g1raw[q][i]) : 0.f;
-          // d / d z_K of the base log-prob: dl * -(z_K - mu) / std^2
-          if (withbase) gv += in ? -dl * (bf16_to_f32(zkraw[q][i]) - a.mu) * c2 : 0.f;
-          g1[0][4 * q + i] = gv;
-          x1[0][4 * q + i] = (on && in) ? bf16_to_f32(x1raw[q][i]) : 0.f;
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const bool in = wave + i * NW < 4 && valid && 8 * (wave + i * NW) + 4 * hh < h;
-        g0raw[i] = in ? g0raw[i] : zero4;
-        z0raw[i] = in ? z0raw[i] : zero4;
-      }
     }
+    // the next tile's head, behind this tile's loads in the queue (the last tile re-reads its own: harmless)
+    head((int64_t)(tile + (int)gridDim.x < ntiles ? tile + (int)gridDim.x : tile) * 32 + r32, x0raw, mraw, dlraw);
     if (wave == 0) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -264,9 +259,19 @@ __global__ void __launch_bounds__(512) k_stack_bwd_par(StackArgs a, int ntiles, 
     }
     lds_barrier();     // A: every exp(s_j) of this tile is published, the x0 image is complete
     // ---- affine chain down to this wave's step: d t_k = g m prod_{j > k} e_j, d s_k = d t_k e_k x1_k + d logdet
-    f32x16 dout;
+    f32x16 dout, x1[1];      // the cotangent / history words requested at the top of the tile have landed under phase 1
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dout[r] = g1[0][r] * m;
+    for (int q = 0; q < 4; ++q) {
+      const bool in = 8 * q + 4 * hh < h;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float gv = (valid && in) ? bf16_to_f32(g1raw[q][i]) : 0.f;
+        // d / d z_K of the base log-prob: dl * -(z_K - mu) / std^2
+        if (withbase) gv += in ? -dl * (bf16_to_f32(zkraw[q][i]) - a.mu) * c2 : 0.f;
+        dout[4 * q + i] = gv * m;
+        x1[0][4 * q + i] = (on && in) ? bf16_to_f32(x1raw[q][i]) : 0.f;
+      }
+    }
     for (int j = a.K - 1; j > k; --j) {
       f32x16 ej[1];
       stash_get<1>(sbuf + j * 1024 + lane * 4 + vz, ej);
@@ -337,7 +342,7 @@ __global__ void __launch_bounds__(512) k_stack_bwd_par(StackArgs a, int ntiles, 
       float v[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        v[i] = bf16_to_f32(g0raw[qi][i]);
+        v[i] = (valid && f < h) ? bf16_to_f32(g0raw[qi][i]) : 0.f;
         if (withbase && f < h) v[i] += -dl * (bf16_to_f32(z0raw[qi][i]) - a.mu) * c2;     // dl is zero past N
       }
       f32x4 sum = {0.f, 0.f, 0.f, 0.f};

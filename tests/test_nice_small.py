@@ -46,7 +46,7 @@ def _case(B, S, D, H, K, act, seed, full=False, holes=False):
 
 
 def _run_gpu(M, flat, z0, mask, cz, cl, H, act, one_pass, use_cz=True, base=True):
-    os.environ["MIVAE_NICE_BWD_PAR"] = "1" if one_pass else "0"
+    os.environ["MIVAE_NICE_BWD_PAR"] = "1" if one_pass else "0"      # 0: the task-serial kernel of nice_stack.hip
     try:
         gp = [t.detach().to(DEV).clone().requires_grad_(True) for t in flat]
         zg = z0.to(DEV).bfloat16().requires_grad_(True)
