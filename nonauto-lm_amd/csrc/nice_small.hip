@@ -96,7 +96,9 @@ __global__ void __launch_bounds__(512) k_stack_bwd_par(StackArgs a, int ntiles, 
   const int lane = threadIdx.x & 63, r32 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int NW = blockDim.x >> 6;                       // = 2 K
-  const int k = wave >> 1, net = wave & 1;
+  // waves 0 .. K-1 run the s-nets, K .. 2K-1 the t-nets: with waves dealt round-robin to the four SIMDs every SIMD gets one
+  // of each (the s-net waves also finish s_k and publish exp(s_k): paired on a SIMD they were the last at barrier A)
+  const int k = wave % a.K, net = wave / a.K;
   const int h = g.h;
   // LDS: [K] exp(s_k) tiles | [NW] d x0 partial tiles | x0 image | per wave: HC hid + HC (act' then d pre) + d out
   // images, biases (b1 | b2)
@@ -128,9 +130,9 @@ __global__ void __launch_bounds__(512) k_stack_bwd_par(StackArgs a, int ntiles, 
   T* dzin = reinterpret_cast<T*>(a.dz_in);
   // side outputs (token-blocked, 8 tokens per 16 bytes): this wave's sections
   const int64_t ldn = a.Npad;
-  T* const Gt = reinterpret_cast<T*>(a.Gt) + (int64_t)wave * g.Hp * ldn;
-  T* const Ht = reinterpret_cast<T*>(a.Ht) + (int64_t)wave * g.Hp * ldn;
-  T* const dSt = reinterpret_cast<T*>(a.dSt) + (int64_t)wave * g.hp * ldn;
+  T* const Gt = reinterpret_cast<T*>(a.Gt) + (int64_t)(2 * k + net) * g.Hp * ldn;
+  T* const Ht = reinterpret_cast<T*>(a.Ht) + (int64_t)(2 * k + net) * g.Hp * ldn;
+  T* const dSt = reinterpret_cast<T*>(a.dSt) + (int64_t)(2 * k + net) * g.hp * ldn;
   T* const x0t = reinterpret_cast<T*>(a.x0t);
 
   // this wave's 16 weight fragments stay in registers for all of the block's tiles.  (Fetched per tile they were the
