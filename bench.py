@@ -361,7 +361,7 @@ def kernel_rooflines(name, model, tokens, kern, hbm_measured):
              # one step = 2 nets x 2 GEMMs x 2 h H flops per REAL token; the backward's algorithmic count is twice the
              # forward's (d input + d weight per GEMM); recomputed activations are not algorithmic
              "nice_stack_fwd": 4 * K * n_real * D * H, "nice_stack_bwd_total": 8 * K * n_real * D * H}
-    in_step = {"nll_fwd", "nll_bwd"} if not fused_lce else {"lce_fwd", "lce_bwd_dh" if ops.LCE_FUSED_DH else "lce_bwd"}
+    in_step = {"nll_fwd", "nll_bwd"} if not fused_lce else {"lce_fwd", "lce_bwd_dh" if ops.lce_fused_dh(D) else "lce_bwd"}
     if fused_lce and "lce_dw" in kern:
         in_step.add("lce_dw")
     mfma_peak = MFMA_PEAK_TFLOPS[dtype_name]

@@ -390,10 +390,10 @@ __global__ __launch_bounds__(256) void k_lce_fwd(LceArgs a) {
 // LDS-staged forward for E <= 64 (see k_lce_bwd_s): the block's 4 waves share one vocabulary slice, so the W fragments of
 // every chunk pair are fetched once per block (register-staged into a double LDS buffer, one barrier per pair) instead
 // of once per wave through the CU's L1.
-template <int NKS, bool SMOOTH>
+template <int NKS, bool SMOOTH, int CPS = 2>
 __global__ __launch_bounds__(256) void k_lce_fwd_s(LceArgs a) {
   constexpr int NF = NKS + 1;
-  constexpr int WB = 2 * NF * 1024;                  // bytes of W fragments per chunk pair
+  constexpr int WB = CPS * NF * 1024;                // bytes of W fragments per stage (CPS chunks: a pair, or one chunk at E = 256)
   constexpr int NV = (WB / 16 + 255) / 256;
   __shared__ __attribute__((aligned(16))) char wbuf[2][WB];
   const int lane = threadIdx.x & 63, r32 = lane & 31, hh = lane >> 5;
@@ -408,8 +408,8 @@ __global__ __launch_bounds__(256) void k_lce_fwd_s(LceArgs a) {
   lce_bf16x8 hf[NF];
   lce_load_h<NF>(a.h, live ? tok : 0, live && valid, hh, hf);
   const int t = valid ? (int)a.target[tok] : -1;
-  const int npair = (a.V >> 5) >> 1;                 // V is a multiple of 64
-  const int per2 = (a.per + 1) >> 1;                 // chunk pairs per slice (per = chunks per slice, even here)
+  const int npair = (a.V >> 5) / CPS;                // stages; V is a multiple of 64
+  const int per2 = (a.per + CPS - 1) / CPS;          // stages per slice (per = chunks per slice, a multiple of CPS here)
   const int p0 = blockIdx.y * per2;
   int p1 = p0 + per2;
   if (p1 > npair) p1 = npair;
@@ -437,8 +437,8 @@ __global__ __launch_bounds__(256) void k_lce_fwd_s(LceArgs a) {
     if (p + 1 < p1) fetch(p + 1);
     if (live) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int c = 2 * p + u;
+      for (int u = 0; u < CPS; ++u) {
+        const int c = CPS * p + u;
         lce_bf16x8 wf[NF];
 #pragma unroll
         for (int ks = 0; ks < NF; ++ks)
@@ -641,12 +641,14 @@ __global__ __launch_bounds__(256) void k_lce_bwd(LceArgs a) {
 // than its 64 B/clk -- the kernel was L1-bound, not HBM-bound.  Here the block fetches each pair's fragment image
 // ONCE (register-staged: loads for pair p+1 are in flight under pair p's math, committed to the other LDS buffer at
 // the end of the iteration, one barrier per pair) and every wave reads its fragments with conflict-free ds_read_b128.
-template <int NKS, bool DH>
+template <int NKS, bool DH, int CPS = 2>
 __global__ __launch_bounds__(256) void k_lce_bwd_s(LceArgs a) {
   constexpr int NF = NKS + 1;
   constexpr int E = 16 * NKS, EB = (E + 31) / 32;
-  constexpr int WB = 2 * NF * 1024;                  // bytes of W fragments per chunk pair
-  constexpr int TB = DH ? 2 * 2 * EB * 1024 : 0;     // bytes of W^T fragments per chunk pair
+  // a stage = a chunk PAIR (one 64-column piece of d logits), or, CPS = 1 (E >= 128: a pair's W + W^T fragments would
+  // not leave room for two buffers), one chunk: a pair is then walked as two stages
+  constexpr int WB = CPS * NF * 1024;                // bytes of W fragments per stage
+  constexpr int TB = DH ? CPS * 2 * EB * 1024 : 0;   // bytes of W^T fragments per stage
   constexpr int SB = WB + TB;
   constexpr int NV = (SB / 16 + 255) / 256;          // 16-byte vectors per thread and stage
   __shared__ __attribute__((aligned(16))) unsigned short stage_all[4][32 * kLceStride];
@@ -716,20 +718,24 @@ __global__ __launch_bounds__(256) void k_lce_bwd_s(LceArgs a) {
       if (off < SB) *reinterpret_cast<u16x8*>(wbuf[b] + off) = pre[v];
     }
   };
-  if (p0 < p1) { fetch(p0); commit(0); }
+  constexpr int SPP = 2 / CPS;                       // stages per pair
+  const int s0 = p0 * SPP, s1 = p1 * SPP;
+  if (s0 < s1) { fetch(s0); commit(0); }
   __syncthreads();
-  for (int p = p0; p < p1; ++p) {
-    const int b = (p - p0) & 1;
-    if (p + 1 < p1) fetch(p + 1);                            // in flight under this pair's math
+  for (int sg = s0; sg < s1; ++sg) {
+    const int b = (sg - s0) & 1;
+    const int p = sg / SPP;
+    if (sg + 1 < s1) fetch(sg + 1);                          // in flight under this stage's math
     if (live) {
       const bool slow = smooth || (__any((t >> 6) == p) != 0);
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int uu = 0; uu < CPS; ++uu) {
+        const int u = CPS == 2 ? uu : (sg & 1);              // chunk of the pair
         const int c = 2 * p + u;
         lce_bf16x8 wf[NF];
 #pragma unroll
         for (int ks = 0; ks < NF; ++ks)
-          wf[ks] = *reinterpret_cast<const lce_bf16x8*>(wbuf[b] + ((u * NF + ks) * 64 + lane) * 16);
+          wf[ks] = *reinterpret_cast<const lce_bf16x8*>(wbuf[b] + ((uu * NF + ks) * 64 + lane) * 16);
         const f32x16 x = lce_tile<NF>(wf, hf);
         u16x4 ov[4];
         if (!slow) {
@@ -766,13 +772,13 @@ __global__ __launch_bounds__(256) void k_lce_bwd_s(LceArgs a) {
 #pragma unroll
             for (int eb = 0; eb < EB; ++eb) {
               const lce_bf16x8 af = *reinterpret_cast<const lce_bf16x8*>(
-                  wbuf[b] + WB + (((u * 2 + s2) * EB + eb) * 64 + lane) * 16);
+                  wbuf[b] + WB + (((uu * 2 + s2) * EB + eb) * 64 + lane) * 16);
               dh[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, dh[eb], 0, 0, 0);
             }
           }
         }
       }
-      if (store_dl) {
+      if (store_dl && (CPS == 2 || (sg & 1))) {              // both chunks of the pair are in the wave's transpose stage
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -783,8 +789,8 @@ __global__ __launch_bounds__(256) void k_lce_bwd_s(LceArgs a) {
         }
       }
     }
-    if (p + 1 < p1) commit(b ^ 1);
-    __syncthreads();       // pair p+1 visible; every wave is done with buffer b and with its transpose stage
+    if (sg + 1 < s1) commit(b ^ 1);
+    __syncthreads();       // stage sg+1 visible; every wave is done with buffer b and with its transpose stage
   }
   if (DH && live && valid) {
 #pragma unroll
@@ -1557,6 +1563,12 @@ int lce_slices(int64_t N, int64_t units) {
   return (int)vs;
 }
 
+// E = 128 / 256: LDS-staged W fragments as for E <= 64 (MIVAE_LCE_WIDE_STAGED=0: one fetch per wave through L1)
+static bool lce_wide_staged() {
+  const char* e = getenv("MIVAE_LCE_WIDE_STAGED");
+  return !(e && atoi(e) == 0);
+}
+
 }  // namespace
 
 extern "C" int64_t mivae_lce_workspace_floats(int64_t N, int64_t V) {
@@ -1602,7 +1614,7 @@ extern "C" int mivae_lce_fwd(const void* h, const void* W, const int64_t* target
   a.N = N; a.S = (int)S; a.V = (int)V; a.smoothing = smoothing;
   const int VS = lce_slices(N, V / 32);
   a.per = (int)((V / 32 + VS - 1) / VS);
-  if (E <= 64) a.per = (a.per + 1) / 2 * 2;          // the staged kernel walks chunk PAIRS: whole pairs per slice
+  if (E <= 128) a.per = (a.per + 1) / 2 * 2;         // the staged kernel walks chunk PAIRS: whole pairs per slice
   float* tok_nll = workspace + (int64_t)VS * N * 4;
   dim3 grid((unsigned)(((N + 31) / 32 + 3) / 4), (unsigned)VS);
   hipStream_t st = S_(stream);
@@ -1619,8 +1631,13 @@ extern "C" int mivae_lce_fwd(const void* h, const void* W, const int64_t* target
   switch (E) {
     case 32: LCE_FWD_S(2); break;
     case 64: LCE_FWD_S(4); break;
-    case 128: LCE_FWD(8); break;
-    default: LCE_FWD(16); break;
+    case 128: if (lce_wide_staged()) LCE_FWD_S(8); else LCE_FWD(8); break;
+    default:
+      if (lce_wide_staged()) {
+        if (smoothing > 0.f) k_lce_fwd_s<16, true, 1><<<grid, 256, 0, st>>>(a);
+        else k_lce_fwd_s<16, false, 1><<<grid, 256, 0, st>>>(a);
+      } else LCE_FWD(16);
+      break;
   }
 #undef LCE_FWD
 #undef LCE_FWD_S
@@ -1653,8 +1670,8 @@ extern "C" int mivae_lce_bwd(const void* h, const void* W, const int64_t* target
   switch (E) {
     case 32: k_lce_bwd_s<2, false><<<grid, 256, 0, st>>>(a); break;
     case 64: k_lce_bwd_s<4, false><<<grid, 256, 0, st>>>(a); break;
-    case 128: k_lce_bwd<8, false><<<grid, 256, 0, st>>>(a); break;
-    default: k_lce_bwd<16, false><<<grid, 256, 0, st>>>(a); break;
+    case 128: if (lce_wide_staged()) k_lce_bwd_s<8, false, 1><<<grid, 256, 0, st>>>(a); else k_lce_bwd<8, false><<<grid, 256, 0, st>>>(a); break;
+    default: if (lce_wide_staged()) k_lce_bwd_s<16, false, 1><<<grid, 256, 0, st>>>(a); else k_lce_bwd<16, false><<<grid, 256, 0, st>>>(a); break;
   }
   MIVAE_CHECK_LAUNCH("lce_bwd");
   return MIVAE_OK;
@@ -1713,8 +1730,8 @@ extern "C" int mivae_lce_bwd_dh(const void* h, const void* W, const void* Wtp, c
   switch (E) {
     case 32: k_lce_bwd_s<2, true><<<grid, 256, 0, st>>>(a); break;
     case 64: k_lce_bwd_s<4, true><<<grid, 256, 0, st>>>(a); break;
-    case 128: k_lce_bwd<8, true><<<grid, 256, 0, st>>>(a); break;
-    default: k_lce_bwd<16, true><<<grid, 256, 0, st>>>(a); break;
+    case 128: if (lce_wide_staged()) k_lce_bwd_s<8, true, 1><<<grid, 256, 0, st>>>(a); else k_lce_bwd<8, true><<<grid, 256, 0, st>>>(a); break;
+    default: if (lce_wide_staged()) k_lce_bwd_s<16, true, 1><<<grid, 256, 0, st>>>(a); else k_lce_bwd<16, true><<<grid, 256, 0, st>>>(a); break;
   }
   MIVAE_CHECK_LAUNCH("lce_bwd_dh");
   k_lce_dh_combine<<<(unsigned)((N * E / 4 + 255) / 256), 256, 0, st>>>(workspace, (unsigned short*)dh, N * E, VSB);

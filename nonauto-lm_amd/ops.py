@@ -1812,7 +1812,7 @@ class _LinearNLL(torch.autograd.Function):
         b32 = None if bias is None else bias.detach().float().contiguous()
         # fragment-ordered weight + bias image for the two kernels
         wp = torch.empty(L.query("mivae_lce_pack_elems", V, E), dtype=torch.bfloat16, device=h.device)
-        wtp = torch.empty(V * E, dtype=torch.bfloat16, device=h.device) if LCE_FUSED_DH and h.requires_grad else None
+        wtp = torch.empty(V * E, dtype=torch.bfloat16, device=h.device) if lce_fused_dh(E) and h.requires_grad else None
         L.call("mivae_lce_pack2", L.ptr(w16), L.ptr(b32), L.ptr(wp), L.ptr(wtp), V, E, L.stream())
         tgt = target.reshape(Bn, S).contiguous().long()
         w = weights.reshape(Bn, S).contiguous().float()
@@ -1920,6 +1920,12 @@ class _LinearNLL(torch.autograd.Function):
 
 LCE_FEATURES = (32, 64, 128, 256)
 LCE_FUSED_DH = True        # d h inside the lce backward pass (mivae_lce_bwd_dh); False: library GEMM on d logits
+LCE_FUSED_DH_MAX_E = 128   # at E = 256 the d h accumulators (128 registers) leave one wave per SIMD: the pass that only stores
+                           # d logits (232 us at C3) + the library product beat the fused pass (526 us); C3 step 4.95 -> 4.88 ms
+
+
+def lce_fused_dh(E: int) -> bool:
+    return bool(LCE_FUSED_DH and E <= LCE_FUSED_DH_MAX_E)
 LCE_RECOMPUTE_DW = os.environ.get("MIVAE_LCE_DW", "1") != "0"   # d W / d b by mivae_lce_dw (E <= 64): no stored d logits
 
 

@@ -29,11 +29,12 @@ dh_ws = e(max(L.query("mivae_lce_dh_workspace_floats", N, E, V), 1))
 dh = e(N, E, dt=torch.bfloat16)
 slabs = L.query("mivae_lce_dw_slabs", N, E, V)
 part = e(max(slabs, 1), V, E + 8)
+dl = None if slabs else e(N, V, dt=torch.bfloat16)     # E > 64: the token-major pass stores d logits for a library product
 calls = {
     "lce_fwd": lambda: L.call("mivae_lce_fwd", L.ptr(h), L.ptr(wp), L.ptr(tokens), L.ptr(w), L.ptr(per_seq), L.ptr(aux[0]),
                               L.ptr(aux[1]), L.ptr(lce_ws), B, S, E, V, 0.0, L.stream()),
     "lce_bwd_dh": lambda: L.call("mivae_lce_bwd_dh", L.ptr(h), L.ptr(wp), L.ptr(wt), L.ptr(tokens), L.ptr(aux[0]),
-                                 L.ptr(aux[1]), L.ptr(dper), None, L.ptr(dh_ws), L.ptr(dh), B, S, E, V, 0.0, L.stream()),
+                                 L.ptr(aux[1]), L.ptr(dper), L.ptr(dl), L.ptr(dh_ws), L.ptr(dh), B, S, E, V, 0.0, L.stream()),
 }
 if slabs:
     calls["lce_dw"] = lambda: L.call("mivae_lce_dw", L.ptr(h), L.ptr(wp), L.ptr(tokens), L.ptr(aux[0]), L.ptr(aux[1]),
