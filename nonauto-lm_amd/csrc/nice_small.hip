@@ -179,10 +179,32 @@ __global__ void __launch_bounds__(512) k_stack_bwd_par(StackArgs a, int ntiles, 
     const int64_t tok = (int64_t)tile * 32 + r32;
     const bool valid = tok < a.N;
     const bool withbase = a.base && a.dlogp;
+    // ---- a tile of padding only (every wave of the block sees the same 32 mask words: block-uniform, no barrier inside):
+    // zero gradient rows and zero side-output columns (k_dw_partial reads all Npad columns), nothing else read or computed
+    if (!__any(valid && mraw != 0)) {
+      head((int64_t)(tile + (int)gridDim.x < ntiles ? tile + (int)gridDim.x : tile) * 32 + r32, x0raw, mraw, dlraw);
+      const u16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+      const u16x4 z4 = {0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int64_t tb = (int64_t)tile * 4 + 2 * s + hh;
+#pragma unroll
+        for (int c = 0; c < HC; ++c) {
+          *reinterpret_cast<u16x8*>(Ht + (tb * g.Hp + 32 * c + r32) * 8) = z8;
+          *reinterpret_cast<u16x8*>(Gt + (tb * g.Hp + 32 * c + r32) * 8) = z8;
+        }
+        *reinterpret_cast<u16x8*>(dSt + (tb * g.hp + r32) * 8) = z8;
+        if (wave == 0) *reinterpret_cast<u16x8*>(x0t + (tb * g.hp + r32) * 8) = z8;
+      }
+      for (int q = wave; q < 8; q += NW) {                 // d z_in row of the lane's token: eight 4-feature groups per half pair
+        const int f = 8 * (q & 3) + 4 * hh;
+        if (valid && f < h) *reinterpret_cast<u16x4*>(dzin + tok * a.D + (q >> 2) * h + f) = z4;
+      }
+      continue;
+    }
     // ---- the tile's other global loads, branch-free and back to back: addresses are clamped into range (token N - 1,
     // feature 0) and what must not count is zeroed by a select afterwards.  (A load inside `if (valid && f < h)` makes the
-    // compiler wait for it inside the branch: twelve serialised round trips per tile.)  Tiles of padding only are
-    // computed like any other: x0, cotangents and history select to zeros, every emitted column is an exact zero.
+    // compiler wait for it inside the branch: twelve serialised round trips per tile.)
     const int64_t tc = valid ? tok : a.N - 1;
     int fcl[4];                                            // the lane's four 4-feature groups, clamped
 #pragma unroll

@@ -18,8 +18,8 @@ import re
 # device kernel (regex on the demangled name) -> logical entry point of bench.py's kernel table
 NAMES = {r"k_nll_fwd<": "nll_fwd", r"k_nll_bwd<": "nll_bwd", r"k_stack_fwd<": "nice_stack_fwd",
          r"k_stack_bwd<": "nice_stack_bwd", r"k_stack_bwd_par<": "nice_stack_bwd", r"k_dw_partial[<(]": "nice_dw", r"k_dw_reduce[<(]": "nice_dw",
-         r"k_lce_fwd(_s)?<": "lce_fwd", r"k_lce_combine\(": "lce_fwd", r"k_lce_bwd(_s)?<\d+, false>": "lce_bwd",
-         r"k_lce_bwd(_s)?<\d+, true>": "lce_bwd_dh", r"k_lce_dh_combine\(": "lce_bwd_dh", r"k_lce_dh<": "lce_bwd_dh", r"k_lce_dw<": "lce_dw", r"k_lce_dwp<": "lce_dw",
+         r"k_lce_fwd(_s)?<": "lce_fwd", r"k_lce_combine\(": "lce_fwd", r"k_lce_bwd(_s)?<\d+, false[,>]": "lce_bwd",
+         r"k_lce_bwd(_s)?<\d+, true[,>]": "lce_bwd_dh", r"k_lce_dh_combine\(": "lce_bwd_dh", r"k_lce_dh<": "lce_bwd_dh", r"k_lce_dw<": "lce_dw", r"k_lce_dwp<": "lce_dw",
          r"k_reparam_fwd<": "reparam_fwd", r"k_reparam_bwd<": "reparam_bwd",
          r"k_post_fwd<": "reparam_fwd", r"k_post_bwd<": "reparam_bwd",      # sigma head + sample + log q in one launch
          # wide-latent path (csrc/nice_big.hip): MODE 0 = forward, 2 = backward chain
