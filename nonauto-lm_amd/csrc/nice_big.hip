@@ -1698,7 +1698,15 @@ __global__ void __launch_bounds__(256) k_big_dw_reduce(DwRedArgs a) {
     const int kn = (int)(q / a.HW);
     const float* p = a.part + (((int64_t)kn * a.HW + hw) * a.nslab) * per_item + e;
     float s = 0.f;
-    for (int sl = 0; sl < a.nslab; ++sl) s += p[sl * per_item];
+    int sl = 0;
+    for (; sl + 8 <= a.nslab; sl += 8) {           // eight loads in flight, summed in slab order (was one dependent
+      float v[8];                                  // round trip per slab: 35 us at C3, 100 us at C5)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(sl + u) * per_item];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; sl < a.nslab; ++sl) s += p[sl * per_item];
     const int tt = e >> 8, ln = (e >> 2) & 63, r = e & 3;
     const int hid = dw_unit(hw, ln & 15, a.perm);
     const int v = tt % NF;

@@ -103,7 +103,7 @@ def test_parallel_nets_backward_without_z_cotangent_and_per_token_cotangent(M):
     B, S, D, H, K = 8, 40, 64, 64, 4
     ps, flat, z0, mask, cz, cl = _case(B, S, D, H, K, "gelu", seed=5)
     for one_pass in (True, False):
-        M.ops.NICE_BWD_DW = one_pass
+        os.environ["MIVAE_NICE_BWD_PAR"] = "1" if one_pass else "0"
         try:
             gp = [t.detach().to(DEV).clone().requires_grad_(True) for t in flat]
             zg = z0.to(DEV).bfloat16().requires_grad_(True)
