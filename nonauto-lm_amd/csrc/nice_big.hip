@@ -1396,7 +1396,8 @@ __global__ void __launch_bounds__(512) k_big_dw(DwBigArgs a) {
 #pragma unroll
       for (int i = 0; i < NST; ++i) {
         __builtin_amdgcn_sched_barrier(0);
-        if (i + 1 < NST) reads(step_of(i + 1), (i + 1) & 1);
+        // (the reads of step 1 go out after the activation: both fragment buffers live across it cost registers)
+        if (i + 1 < NST && i != 0) reads(step_of(i + 1), (i + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
         if (step_of(i) == 0) {   // the activation of tile n, right before the first A chunk overwrites pre_c / dh_c
           if (DO1) {
@@ -1412,6 +1413,7 @@ __global__ void __launch_bounds__(512) k_big_dw(DwBigArgs a) {
 #pragma unroll
           for (int tt = 0; tt < 2; ++tt) { pre_c[tt] = f32x4{b1v, b1v, b1v, b1v}; dh_c[tt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
           __builtin_amdgcn_sched_barrier(0);
+          if (i + 1 < NST) { reads(step_of(i + 1), (i + 1) & 1); __builtin_amdgcn_sched_barrier(0); }
         }
         mfmas(step_of(i), i & 1);
       }
