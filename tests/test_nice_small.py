@@ -117,3 +117,29 @@ def test_parallel_nets_backward_without_z_cotangent_and_per_token_cotangent(M):
             first = res
     assert rel_err(first[0], res[0]) < 1.6e-2
     assert max(rel_err(a, b) for a, b in zip(first[1], res[1])) < 1e-2
+
+
+def test_parallel_nets_backward_random_shapes(M):
+    """Seeded sweep over small shapes (odd token counts, h and H that are not multiples of 32, K = 1 .. 4, every
+    activation): the parallel-nets kernel against the task-serial one on the same inputs."""
+    import random
+    rnd = random.Random(20240607)
+    acts = ["gelu", "relu", "tanh", "sigmoid", "swish"]
+    worst = (0.0, 0.0)
+    for it in range(24):
+        B, S = rnd.randint(1, 12), rnd.randint(1, 70)
+        D = rnd.choice([16, 32, 48, 64])
+        H = rnd.choice([8, 16, 24, 40, 48, 64])
+        K = rnd.randint(1, 4)
+        act = rnd.choice(acts)
+        ps, flat, z0, mask, cz, cl = _case(B, S, D, H, K, act, seed=1000 + it, holes=(it % 5 == 0))
+        zK, lp, dz, grads = _run_gpu(M, flat, z0, mask, cz, cl, H, act, one_pass=True)
+        zK2, lp2, dz2, grads2 = _run_gpu(M, flat, z0, mask, cz, cl, H, act, one_pass=False)
+        assert torch.equal(zK, zK2) and torch.equal(lp, lp2)
+        assert not torch.isnan(dz.float()).any() and all(not torch.isnan(g).any() for g in grads)
+        e_dz = rel_err(dz.float(), dz2.float())
+        e_w = max(rel_err(a, b) for a, b in zip(grads, grads2))
+        worst = (max(worst[0], e_dz), max(worst[1], e_w))
+        assert e_dz < 8e-3 and e_w < 1.2e-2, (B, S, D, H, K, act, e_dz, e_w)
+        assert float((dz.float() * (1 - mask.to(DEV).float()).unsqueeze(-1)).abs().max()) == 0.0
+    print(f"parallel-nets bwd, 24 random shapes: worst dz {worst[0]:.2e} dW {worst[1]:.2e} vs the task-serial kernel")
