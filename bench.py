@@ -8,7 +8,7 @@ plus the roofline fraction of the dominant hand-written kernel and a CPU baselin
 One step = the reference's `_train_batch` (training/trainers/trainer.py:277-303): forward ELBO of the VAE
 (encoder/decoder bracket + latent path on the HIP kernels), backward, bucketed RCCL gradient all-reduce overlapped with
 backward, clip (norm 5, value 2), Adam step.  Inputs are resident in HBM before the timed region.  Weak scaling: the
-per-GPU batch is fixed; value = global sentences / max-over-ranks time.
+per-GPU batch is fixed; value = global sentences / max-over-ranks time (--strong splits the 1-GPU batch over the ranks).
 
 Workload of the headline line = BASELINE configs[1] ("C2"): B=256, S=64, D=64, K=4 NICE-FF steps (H=64), bf16.
 With the default --config the other BASELINE configs (C3, C4, C5) are timed afterwards with fewer steps and embedded
@@ -418,6 +418,10 @@ def run_config(name, steps, warmup, args, rank, world, dev, hbm_measured, want_c
     from nonauto_lm_amd import dp
     from nonauto_lm_amd.step import TrainStep
     B, S, D, H, K, dtype_name, ragged = CONFIGS[name]
+    if args.strong:                                # strong scaling: the 1-GPU batch split over the ranks
+        if B % world:
+            sys.exit(f"bench.py --strong: batch {B} does not split over {world} ranks")
+        B //= world
     auto = FAMILY.get(name) == "auto"
     amp_dtype = torch.bfloat16 if dtype_name == "bf16" else None
     torch.manual_seed(13)                          # identical init on every rank (train_worker.py:48)
@@ -511,6 +515,8 @@ def main():
     ap.add_argument("--torch-adam", action="store_true", help="stock torch.optim.Adam + separate clip passes")
     ap.add_argument("--no-sdpa", action="store_true", help="explicit masked-softmax attention in the bracket")
     ap.add_argument("--eager", action="store_true", help="no HIP-graph replay of the step (hook-overlapped all-reduce)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: the config's 1-GPU batch is split over the ranks (default: weak, fixed per-GPU batch)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -563,9 +569,9 @@ def main():
             "metric": "train sentences/sec (ELBO fwd+bwd)", "value": main_res["value"],
             "unit": "sentences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": main_res["ms_per_step"], "ms_per_step_median": main_res["ms_per_step_median"],
-            "higher_is_better": True, "scaling": "weak",
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
-            "config": {"workload": main_res["workload"], "global_batch": world * B, "seq_len": S, "latent_dim": D,
+            "config": {"workload": main_res["workload"], "global_batch": main_res["global_batch"], "seq_len": S, "latent_dim": D,
                        "flow_steps": K, "parallelism": f"dp{world}"},
             "roofline": main_res.get("roofline"), "roofline_flow": main_res.get("roofline_flow"),
             "hbm_measured_GBps": None if hbm_measured is None else round(hbm_measured, 1),
