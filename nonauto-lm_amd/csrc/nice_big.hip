@@ -1824,7 +1824,11 @@ static void dw_big_geom(int64_t N, const BigGeom& g, int& nslab, int& slab_tiles
   const int64_t ntiles = (N + 31) / 32;
   const int nw = 8;                                      // hidden 16-groups (waves) per block
   const int64_t blocks0 = (int64_t)g.K * 2 * ((g.Hp / 16 + nw - 1) / nw);
-  int64_t want = (768 + blocks0 - 1) / blocks0;          // ~3 blocks per CU in total
+  // one block per CU in total (MIVAE_BIG_DW_BLOCKS overrides the 256): every further slab costs a prologue (the wave's
+  // weight fragments from the fp32 parameters) and 16 KB of partials per wave to dump and fold -- C3 backward with 768 /
+  // 512 / 256 blocks: 1037 / 1023 / 995 us
+  static const int target = [] { const char* e = getenv("MIVAE_BIG_DW_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 256; }();
+  int64_t want = (target + blocks0 - 1) / blocks0;
   const int64_t maxs = (ntiles + 15) / 16;               // at least 16 token tiles per slab
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
