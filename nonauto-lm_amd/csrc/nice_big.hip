@@ -252,7 +252,7 @@ struct Ring {
 
 // ---- pack ----------------------------------------------------------------------------------------------
 // ptrs[k][8] = {W1s, b1s, W2s, b2s, W1t, b1t, W2t, b2t} (fp32, torch.nn.Linear layout: W1 (H, h), W2 (h, H)).
-// One thread per bf16 element of the stream (or per float of the bias array).
+// One thread per eight bf16 elements of the stream (or per float of the bias array).
 __device__ __forceinline__ void task_of(const BigGeom& g, int st, int64_t i, int& k, int& net, int& c) {
   c = (int)(i % g.HC);
   if (st == ST_CHAIN) { k = g.K - 1 - (int)(i / g.HC); net = 0; return; }
@@ -274,11 +274,13 @@ __device__ __forceinline__ void pack_elem(const int64_t* __restrict__ ptrs, char
     reinterpret_cast<float*>(out)[idx] = v;
     return;
   }
+  // one thread per 16-byte group of the stream: the eight k-slots j of one lane of one fragment (eight loads in flight,
+  // one 16-byte store; was one element per thread: C5 137 us, C3 21 us per launch)
   const int per_item = g.item / 2;
   const int64_t nitems = stream_items(g, st), Tn = stream_tasks(g, st);
-  if (idx >= nitems * per_item) return;
-  const int64_t q = idx / per_item;
-  const int e = (int)(idx % per_item);
+  if (idx >= nitems * (per_item / 8)) return;
+  const int64_t q = idx / (per_item / 8);
+  const int e = (int)(idx % (per_item / 8)) * 8;
   int64_t task;
   int kind;
   if (st == ST_NETS) {
@@ -295,33 +297,40 @@ __device__ __forceinline__ void pack_elem(const int64_t* __restrict__ ptrs, char
       if (((q - 2) & 1) == 0) { task = i; kind = KIND_W2; } else { task = i + 2; kind = KIND_W1; }
     }
   }
-  float v = 0.f;
+  u16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
   if (task < Tn) {
     int k, net, c;
     task_of(g, st, task, k, net, c);
     const float* W1 = reinterpret_cast<const float*>(ptrs[k * 8 + net * 4 + 0]);
     const float* W2 = reinterpret_cast<const float*>(ptrs[k * 8 + net * 4 + 2]);
     // fragments of v_mfma_f32_16x16x32_bf16: lane (r = lane & 15, g = lane >> 4) holds A[row r][k-slot (g, j)]
-    const int frag = e >> 9, lane = (e >> 3) & 63, j = e & 7;
+    const int frag = e >> 9, lane = (e >> 3) & 63;
     const int r = lane & 15, gq = lane >> 4;
-    const int perm = j < 4 ? 4 * gq + j : 16 + 4 * gq + (j - 4);   // k order of an accumulator pair used as B operand
-    if (kind == KIND_W1) {          // frag = u * HT + ks: A[row = hidden 32c + 16u + r][k = in 32ks + 8g + j]
-      const int u = frag / g.HT, ks = frag % g.HT;
-      const int row = 32 * c + 16 * u + r, col = 32 * ks + 8 * gq + j;
-      if (row < g.H && col < g.h) v = W1[(int64_t)row * g.h + col];
-    } else if (kind == KIND_W2) {   // frag = v: A[row = out 16v + r][k = hidden 32c + perm]
-      const int row = 16 * frag + r, col = 32 * c + perm;
-      if (row < g.h && col < g.H) v = W2[(int64_t)row * g.H + col];
-    } else if (kind == KIND_W2T) {  // frag = u * HT + ks: A[row = hidden 32c + 16u + r][k = out 32ks + 8g + j] = W2[out][hidden]
-      const int u = frag / g.HT, ks = frag % g.HT;
-      const int row = 32 * ks + 8 * gq + j, col = 32 * c + 16 * u + r;
-      if (row < g.h && col < g.H) v = W2[(int64_t)row * g.H + col];
-    } else {                        // KIND_W1T, frag = v: A[row = in 16v + r][k = hidden 32c + perm] = W1[hidden][in]
-      const int row = 32 * c + perm, col = 16 * frag + r;
-      if (row < g.H && col < g.h) v = W1[(int64_t)row * g.h + col];
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int perm = j < 4 ? 4 * gq + j : 16 + 4 * gq + (j - 4);   // k order of an accumulator pair used as B operand
+      v[j] = 0.f;
+      if (kind == KIND_W1) {          // frag = u * HT + ks: A[row = hidden 32c + 16u + r][k = in 32ks + 8g + j]
+        const int u = frag / g.HT, ks = frag % g.HT;
+        const int row = 32 * c + 16 * u + r, col = 32 * ks + 8 * gq + j;
+        if (row < g.H && col < g.h) v[j] = W1[(int64_t)row * g.h + col];
+      } else if (kind == KIND_W2) {   // frag = v: A[row = out 16v + r][k = hidden 32c + perm]
+        const int row = 16 * frag + r, col = 32 * c + perm;
+        if (row < g.h && col < g.H) v[j] = W2[(int64_t)row * g.H + col];
+      } else if (kind == KIND_W2T) {  // frag = u * HT + ks: A[row = hidden 32c + 16u + r][k = out 32ks + 8g + j] = W2[out][hidden]
+        const int u = frag / g.HT, ks = frag % g.HT;
+        const int row = 32 * ks + 8 * gq + j, col = 32 * c + 16 * u + r;
+        if (row < g.h && col < g.H) v[j] = W2[(int64_t)row * g.H + col];
+      } else {                        // KIND_W1T, frag = v: A[row = in 16v + r][k = hidden 32c + perm] = W1[hidden][in]
+        const int row = 32 * c + perm, col = 16 * frag + r;
+        if (row < g.H && col < g.h) v[j] = W1[(int64_t)row * g.h + col];
+      }
     }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = f32_to_bf16(v[j]);
   }
-  reinterpret_cast<unsigned short*>(out)[idx] = f32_to_bf16(v);
+  *reinterpret_cast<u16x8*>(reinterpret_cast<unsigned short*>(out) + idx * 8) = o;
 }
 __global__ void __launch_bounds__(256) k_big_pack(const int64_t* __restrict__ ptrs, char* __restrict__ out, BigGeom g, int st) {
   pack_elem(ptrs, out, g, st, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
@@ -1857,7 +1866,7 @@ extern "C" int mivae_nice_big_pack(const int64_t* ptr_table, void* out, int64_t 
   MIVAE_REQUIRE(stream_kind >= 0 && stream_kind <= ST_BIAS, "nice_big_pack: bad stream kind %d", stream_kind);
   MIVAE_REQUIRE(aligned16(out), "nice_big_pack: output must be 16-byte aligned");
   const BigGeom g = big_geom_inst((int)h, (int)H, (int)K);
-  const int64_t n = stream_kind == ST_BIAS ? K * 2 * kBiasBlockFloats : stream_items(g, stream_kind) * (g.item / 2);
+  const int64_t n = stream_kind == ST_BIAS ? K * 2 * kBiasBlockFloats : stream_items(g, stream_kind) * (g.item / 16);   // threads
   k_big_pack<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(ptr_table, (char*)out, g, stream_kind);
   MIVAE_CHECK_LAUNCH("nice_big_pack");
   return MIVAE_OK;
@@ -1877,7 +1886,7 @@ extern "C" int mivae_nice_big_pack_multi(const int64_t* ptr_table, void* const* 
     m.out[st] = (char*)outs[st];
     if (!outs[st]) continue;
     MIVAE_REQUIRE(aligned16(outs[st]), "nice_big_pack_multi: outputs must be 16-byte aligned");
-    const int64_t n = st == ST_BIAS ? K * 2 * kBiasBlockFloats : stream_items(g, st) * (g.item / 2);
+    const int64_t n = st == ST_BIAS ? K * 2 * kBiasBlockFloats : stream_items(g, st) * (g.item / 16);   // threads
     total += (unsigned)((n + 255) / 256);
   }
   m.first[ST_BIAS + 1] = total;
