@@ -499,6 +499,47 @@ __global__ __launch_bounds__(256) void k_lce_combine(const f32x4* __restrict__ p
   lse_out[r] = lse;
 }
 
+// k_lce_combine and k_nll_seq in one launch: a wave per sentence folds the slice partials of its tokens (same arithmetic
+// as k_lce_combine), then reduces them exactly as k_nll_seq does (lane-strided sums, wave_sum): bit-identical outputs.
+__global__ __launch_bounds__(kBlock) void k_lce_combine_seq(const f32x4* __restrict__ partial, const float* __restrict__ weights,
+                                                             float* __restrict__ tok_nll, float* __restrict__ lse_out,
+                                                             float* __restrict__ per_seq, float* __restrict__ tokscale,
+                                                             int64_t N, int64_t Bn, int S, int VS, int V, float smoothing) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (b >= Bn) return;
+  float a = 0.0f, ws = 0.0f;
+  for (int sp = lane; sp < S; sp += 64) {
+    const int64_t r = b * S + sp;
+    const float w = weights[r];
+    float tn = 0.f, lse = 0.f;
+    if (w != 0.f) {
+      float M = -INFINITY, s = 0.f, sx = 0.f, xt = 0.f;
+      for (int v = 0; v < VS; ++v) {
+        const f32x4 p = partial[(int64_t)v * N + r];
+        const float Mn = fmaxf(M, p[0]);
+        s = (M == -INFINITY ? 0.f : s * ex2(M - Mn)) + (p[0] == -INFINITY ? 0.f : p[1] * ex2(p[0] - Mn));
+        M = Mn;
+        sx += p[2];
+        xt += p[3];
+      }
+      lse = (M + __builtin_amdgcn_logf(s)) * kLn2;
+      float nll = lse - xt;
+      if (smoothing > 0.f) nll = (1.f - smoothing) * nll + smoothing * lse - (smoothing / (float)V) * sx;
+      tn = nll * w;
+    }
+    tok_nll[r] = tn;
+    lse_out[r] = lse;
+    a += tn;
+    ws += w;
+  }
+  a = wave_sum(a);
+  ws = wave_sum(ws);
+  const float inv = 1.0f / fmaxf(ws, 1e-13f);
+  if (lane == 0) per_seq[b] = a * inv;
+  for (int sp = lane; sp < S; sp += 64) tokscale[b * S + sp] = weights[b * S + sp] * inv;
+}
+
 constexpr int kLceStride = 72;   // bf16 per staged token row (64 + pad): 144 B keeps 16-byte alignment
 
 // DH: every wave also accumulates d h^T (E x 32 tokens) += W^T dl on the matrix cores from the bf16 d logits it has
@@ -1642,6 +1683,12 @@ extern "C" int mivae_lce_fwd(const void* h, const void* W, const int64_t* target
 #undef LCE_FWD
 #undef LCE_FWD_S
   MIVAE_CHECK_LAUNCH("lce_fwd");
+  if (S >= 16 && S <= 128) {   // one launch: a wave per sentence folds its tokens' partials (at most two per lane) and reduces them
+    k_lce_combine_seq<<<(unsigned)((Bn + kBlock / 64 - 1) / (kBlock / 64)), kBlock, 0, st>>>(a.partial, weights, tok_nll, lse, per_seq,
+                                                                                     tokscale, N, Bn, (int)S, VS, (int)V, smoothing);
+    MIVAE_CHECK_LAUNCH("lce_combine_seq");
+    return MIVAE_OK;
+  }                    // very short or long sentences: a thread per token, then a wave per sentence
   k_lce_combine<<<(unsigned)((N + 255) / 256), 256, 0, st>>>(a.partial, weights, tok_nll, lse, N, VS, (int)V, smoothing);
   MIVAE_CHECK_LAUNCH("lce_combine");
   k_nll_seq<<<(unsigned)((Bn + 3) / 4), kBlock, 0, st>>>(tok_nll, weights, per_seq, tokscale, Bn, (int)S);
