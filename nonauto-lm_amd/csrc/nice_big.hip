@@ -364,7 +364,6 @@ struct BigArgs {
   int64_t N;
   int S, mask_div, D, K, h, H, HC;
   int act, base;
-  int dbg;              // timing ablations (MIVAE_DBG env): 1 = no weight staging, 2 = no arithmetic, 4 = cycle stamps
   float mu, inv2var, cst;
   // CHAIN
   const T* dz_out;      // (N, D) or null
@@ -556,7 +555,7 @@ __global__ void __launch_bounds__(512) k_big_chain(BigArgs a) {
     }
     if (MODE == M_CHAIN && a.dlogp) dl = a.dlogp[tok / a.S] * m;   // one cotangent per sentence (S = 1: per token)
   }
-  const bool live = (__any(m != 0.f) != 0) && !(a.dbg & 2);
+  const bool live = __any(m != 0.f) != 0;
   if (!block_live(a.mask, a.N, a.S, a.mask_div, lane)) {
     // the whole block is padding: outputs are zeros; the history / d s, d t rows of masked tokens are never read
     if (valid) {
@@ -611,7 +610,7 @@ __global__ void __launch_bounds__(512) k_big_chain(BigArgs a) {
   };
   int nbias = 0;
   for (; nbias < kBiasSlots && nbias < NJ; ++nbias) issue_bias(nbias);
-  ring.init(a.stream, smem, (a.dbg & 1) ? 0 : 2 * Tn + 2, wave, lane);
+  ring.init(a.stream, smem, 2 * Tn + 2, wave, lane);
 
   f32x4 acc[NF];
 #pragma unroll
@@ -1924,7 +1923,6 @@ extern "C" int mivae_nice_big_fwd(const void* z_in, void* z_out, void* x1_hist, 
   a.stream = (const char*)packed_stream; a.bias = (const float*)packed_bias; a.tok_val = tok_val;
   a.N = Bn * S; a.S = (int)S; a.mask_div = (int)mask_div; a.D = (int)D; a.K = (int)K; a.h = g.h; a.H = g.H; a.HC = g.HC;
   a.act = act; a.base = base; a.mu = mu;
-  { const char* e = getenv("MIVAE_DBG"); a.dbg = e ? atoi(e) : 0; }
   a.inv2var = base ? 1.0f / (2.0f * std * std) : 0.f;
   a.cst = base ? logf(std) + 0.5f * kLog2Pi : 0.f;
   const unsigned grid = (unsigned)((a.N + 127) / 128);

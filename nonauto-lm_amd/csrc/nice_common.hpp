@@ -336,7 +336,6 @@ struct StackArgs {
   int S, mask_div, D, K;
   int inverse, base, act;
   int G;                // tasks per staged block
-  int dbg;              // timing ablations (MIVAE_DBG env): 1 = no weight staging, 2 = no arithmetic
   float mu, inv2var, cst;  // base dist: -(z-mu)^2 * inv2var - cst
   // backward only
   const void* dz_out;   // (N, D) or null

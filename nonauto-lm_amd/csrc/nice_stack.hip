@@ -125,13 +125,13 @@ struct Stream {
   char* lds;         // two buffers of G * tb bytes
   int tb, G, ntasks, blk, g;
   const char* cur;
-  int wave, W, lane, off;
+  int wave, W, lane;
 
   __device__ __forceinline__ void init(const char* s, char* l, int tb_, int G_, int n, int wave_, int W_,
-                                       int lane_, int off_) {
+                                       int lane_) {
     src = s; lds = l; tb = tb_; G = G_; ntasks = n; blk = 0; g = G_; cur = l;
-    wave = wave_; W = W_; lane = lane_; off = off_;
-    if (!off) stage_region(src, lds, (n < G_ ? n : G_) * tb_, wave, W, lane);
+    wave = wave_; W = W_; lane = lane_;
+    stage_region(src, lds, (n < G_ ? n : G_) * tb_, wave, W, lane);
   }
   // LDS address of the next task region (call once per task, by every wave of the block)
   __device__ __forceinline__ const char* next() {
@@ -139,7 +139,7 @@ struct Stream {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();   // block `blk` has landed for every wave; the other buffer is free again
       const int first = (blk + 1) * G;
-      if (first < ntasks && !off) {
+      if (first < ntasks) {
         const int cnt = ntasks - first < G ? ntasks - first : G;
         stage_region(src + (int64_t)first * tb, lds + ((blk + 1) & 1) * G * tb, cnt * tb, wave, W, lane);
       }
@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(LB) k_stack_fwd(StackArgs a) {
     }
   }
   // a tile whose tokens are all padding (or out of range) produces zeros: skip its arithmetic
-  const bool live = (__any(m != 0.f) != 0) && !(a.dbg & 2);
+  const bool live = __any(m != 0.f) != 0;
   const T* zrow = reinterpret_cast<const T*>(a.z_in) + tok * a.D;
   // masked tokens are computed on zeros: every output of such a token is multiplied by the mask
   // anyway (couplings.py:159-161), and zeros keep exp() finite at padding positions.
@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(LB) k_stack_fwd(StackArgs a) {
   const int HC = g.HC;
   const int tbf = (int)g.tbf;
   Stream st;
-  st.init(a.packed, smem, 2 * tbf, a.G, a.K * HC, wave, W, lane, a.dbg & 1);
+  st.init(a.packed, smem, 2 * tbf, a.G, a.K * HC, wave, W, lane);
   // x1 (the half the steps transform) is parked in a per-tile LDS area shared by the two roles
   float* stash = reinterpret_cast<float*>(smem + 2 * a.G * 2 * tbf) + tile * HT * 1024 + lane * 4;
   if (role == 0) {
@@ -393,7 +393,7 @@ template <class P, int ACT, typename T, int HT, int NKS>
 __device__ __forceinline__ void bwd_chunk(const char* buf, const float* tail, int act, int lane, int hh,
                                           const typename P::BF (&x0f)[NKS], const f32x16 (&dout)[HT],
                                           f32x16 (&dx0)[HT], T* __restrict__ Gt, T* __restrict__ Ht,
-                                          int row0, unsigned loff, int dbg = 0) {
+                                          int row0, unsigned loff) {
   const typename P::AF* w1 = reinterpret_cast<const typename P::AF*>(buf) + lane;
   typename P::AF f1[NKS], f2[HT * P::NS], f3[HT * P::NS];
   load_frags<P, NKS>(w1, f1);
@@ -410,10 +410,10 @@ __device__ __forceinline__ void bwd_chunk(const char* buf, const float* tail, in
   ReduceFromAcc<P, HT, 0>::run(f2, dout, dh);   // independent of the activation: overlaps its VALU work
   f32x16 dact;
   act_tile_fd<ACT, P::KS == 16>(act, hid, dact);
-  if (!(dbg & 4)) store_tile_t<T>(Ht, row0, loff, hid);
+  store_tile_t<T>(Ht, row0, loff, hid);
 #pragma unroll
   for (int r = 0; r < 16; ++r) dh[r] *= dact[r];
-  if (!(dbg & 4)) store_tile_t<T>(Gt, row0, loff, dh);
+  store_tile_t<T>(Gt, row0, loff, dh);
   AccumFromAcc<P, HT, 0>::run(f3, dh, dx0);
 }
 
@@ -502,7 +502,7 @@ __global__ void __launch_bounds__(LB) k_stack_bwd(StackArgs a) {
   const int tbb = (int)g.tbb;
   // LDS: [2 stream buffers of G * tbb][per-wave dt stash: HT tiles x 4 KiB]
   Stream st;
-  st.init(a.packed + g.off_b, smem, tbb, a.G, a.K * 3 * HC, wave, W, lane, a.dbg & 1);
+  st.init(a.packed + g.off_b, smem, tbb, a.G, a.K * 3 * HC, wave, W, lane);
   float* stash = reinterpret_cast<float*>(smem + 2 * a.G * tbb) + wave * HT * 1024 + lane * 4;
   if (!active) {
     // tile past the padded token range: keep the block's barrier / staging cadence only
@@ -560,7 +560,7 @@ __global__ void __launch_bounds__(LB) k_stack_bwd(StackArgs a) {
         for (int c = 0; c < HC; ++c) {
           buf = st.next();
           bwd_chunk<P, ACT, T, HT, NKS>(buf, reinterpret_cast<const float*>(buf + tbb - kTailBytes), a.act, lane, hh,
-                                        x0f, dcur, dx0, Gt, Ht, 32 * c, loffH, a.dbg);
+                                        x0f, dcur, dx0, Gt, Ht, 32 * c, loffH);
         }
       }
     }
@@ -812,7 +812,6 @@ static int run_stack(const char* name, bool bwd, StackArgs a, int64_t Bn, int h,
   MIVAE_REQUIRE(h >= 1 && H >= 1 && a.D == 2 * h, "%s: D must be 2*h (D=%d h=%d)", name, a.D, h);
   MIVAE_REQUIRE(a.S >= 1 && a.mask_div >= 1 && Bn >= 0, "%s: bad shape", name);
   a.act = act;
-  { const char* e = getenv("MIVAE_DBG"); a.dbg = e ? atoi(e) : 0; }
   a.g = make_geom(h, H, a.K, dtype == MIVAE_BF16);
   if (a.g.HT > 4) {
     mivae_set_error("%s: fused path supports D <= 256 (got D=%d); use the composed path", name, a.D);

@@ -1766,12 +1766,16 @@ extern "C" int mivae_lce_bwd_dh(const void* h, const void* W, const void* Wtp, c
   if (!dlogits && pipelined) {
     if (E == 32) { if (smoothing > 0.f) k_lce_dh<2, true><<<grid, 256, 0, st>>>(a); else k_lce_dh<2, false><<<grid, 256, 0, st>>>(a); }
     else { if (smoothing > 0.f) k_lce_dh<4, true><<<grid, 256, 0, st>>>(a); else {
+#ifdef MIVAE_LCE_ABLATION   // timing ablations of DESIGN.md section 6 (wrong results by construction): a build of their own only
       static const int dbg = getenv("MIVAE_LCE_DBG") ? atoi(getenv("MIVAE_LCE_DBG")) : 0;
       switch (dbg) {
 #define DBGCASE(n) case n: k_lce_dh<4, false, n><<<grid, 256, 0, st>>>(a); break;
         DBGCASE(1) DBGCASE(3) DBGCASE(4) DBGCASE(7) DBGCASE(15) DBGCASE(23) DBGCASE(31) DBGCASE(12) DBGCASE(20)
         default: k_lce_dh<4, false><<<grid, 256, 0, st>>>(a); break;
       }
+#else
+      k_lce_dh<4, false><<<grid, 256, 0, st>>>(a);
+#endif
     } }
   } else
   switch (E) {

@@ -39,7 +39,7 @@ calls = {
 if slabs:
     calls["lce_dw"] = lambda: L.call("mivae_lce_dw", L.ptr(h), L.ptr(wp), L.ptr(tokens), L.ptr(aux[0]), L.ptr(aux[1]),
                                      L.ptr(dper), L.ptr(part), B, S, E, V, 0.0, L.stream())
-out = {"shape": [B, S, E, V], "dbg": os.environ.get("MIVAE_LCE_DBG", "0")}
+out = {"shape": [B, S, E, V], "dbg": os.environ.get("MIVAE_LCE_DBG", "0")}   # (read by -DMIVAE_LCE_ABLATION builds only)
 side = torch.cuda.Stream()
 for name, fn in calls.items():
     with torch.cuda.stream(side):

@@ -22,5 +22,5 @@ tokens = bench.synthetic_tokens(B, S, ragged, 13).to(dev)
 auto = bench.FAMILY.get(cfg) == "auto"
 t = bench.flow_kernel_times(model, tokens, torch.bfloat16, reps=50, graph=True, family="auto" if auto else "nonauto",
                             loss_kernels=False)
-print(json.dumps({"config": cfg, "bwd_par": os.environ.get("MIVAE_NICE_BWD_PAR", "1"), "dbg": os.environ.get("MIVAE_DBG", "0"),
+print(json.dumps({"config": cfg, "bwd_par": os.environ.get("MIVAE_NICE_BWD_PAR", "1"),
                   **{k: round(v["avg_us"], 2) for k, v in t.items() if k.startswith("nice")}}))
