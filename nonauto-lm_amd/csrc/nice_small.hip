@@ -13,24 +13,7 @@ namespace {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_cvoid_t;
 
-// ---- one-launch backward with in-kernel weight gradients (small stacks) ------------------------------
-// For the stacks whose backward is latency- rather than MFMA-bound (bf16, h <= 32, H <= 64, K <= 4: BASELINE C2 / C4)
-// the work is re-split: the K x 2 coupling nets only depend on x0, so a block of 2K waves gives every (step, net) its
-// own wave for a 32-token tile and the nets run side by side instead of one after another.
-//   phase 1  every wave recomputes ITS net's hidden layer (value + derivative) from x0 with its weights held in
-//            registers for the whole kernel (no LDS staging, no per-task barrier); the s-net waves finish s_k and
-//            publish exp(s_k) in LDS;                                                              -- barrier A
-//   chain    every wave walks the affine chain down to its own step on the published exponentials (K x 16 fmuls
-//            per lane, redundantly) and forms its d s_k / d t_k in registers;
-//   phase 2  d hid = W2^T d out, d pre = d hid act', d x0 partial = W1^T d pre (accumulator -> B operand);
-//   phase 3  weight gradients of the wave's own net, tokens as the contraction: hid, d pre, d out and x0 are parked as
-//            [token][feature] bf16 images in the wave's LDS (8-byte slots XOR-swizzled: packed writes and the
-//            transposing reads are both conflict free) and come back through ds_read_b64_tr_b16 as the A / B
-//            fragments of dW1 += d pre x0^T, dW2^T += hid d out^T; bias gradients ride in one more accumulator tile
-//            against selector columns;                                                              -- barrier B
-//   reduce   the 2K partial d x0 tiles are summed in wave order and stored with the upstream x0 cotangent.
-// Accumulators live across the block's tiles and are dumped once, in k_dw_partial's format: k_dw_reduce folds the
-// per-block partials in fixed order.  No Gt / Ht / dSt / x0t side outputs, no second pass over the tokens.
+// ---- [token][feature] bf16 images in LDS: written from accumulator tiles, read back through transposing reads -----
 constexpr int kImgBytes = 2048;   // 32 tokens x 32 features bf16, 64-byte rows
 
 __device__ __forceinline__ int img_off(int row, int slot) { return row * 64 + 8 * (slot ^ ((row >> 1) & 7)); }
@@ -111,7 +94,7 @@ __global__ void __launch_bounds__(512) k_stack_bwd_par(StackArgs a, int ntiles, 
   ImgLane L;
   L.init(lane);
   // this wave's weights: fragments of the packed backward stream (k_nice_pack), tasks (phase, c): 0 = [W1n s][W2p s],
-  // 1 / 2 = s / t net [W1n][W2Tp][W1Tp]; 16 KB per wave, L2-resident, fetched per tile
+  // 1 / 2 = s / t net [W1n][W2Tp][W1Tp]; 16 KB per wave, read once (below) and kept in registers
   const char* pk = a.packed + g.off_b + (int64_t)(a.K - 1 - k) * 3 * HC * g.tbb;
   const bf16x8* f0 = reinterpret_cast<const bf16x8*>(pk) + lane;
   const int tstride = (int)(g.tbb / 16);
