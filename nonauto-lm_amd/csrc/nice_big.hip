@@ -1110,7 +1110,8 @@ __global__ void __launch_bounds__(512) k_big_nets(NetsArgs a) {
 // stay in registers as B fragments -- and a block of 8 waves (128 hidden units) walks a slab of 32-token tiles staged
 // in LDS.  For every tile it RECOMPUTES pre = x0 W1^T + b1 and dh = d out W2 (tokens x hidden), applies the
 // activation and its derivative, and accumulates dW1^T = x0^T d pre and dW2 = d out^T hid with the tokens as the
-// contraction (transposing LDS reads give the [feature][token] fragments).  ~150 registers: two waves per SIMD.
+// contraction (transposing LDS reads give the [feature][token] fragments).  ~250 registers at h = 128 (64 of them the two
+// double-buffered fragment sets): two waves per SIMD, one block per CU.
 struct DwBigArgs {
   const T* z_in;        // (N, D): x0 = z_in[:, :h]
   const T* dSdT;        // (K, 2, N, h)
