@@ -66,9 +66,9 @@ static __host__ __device__ int64_t stream_items(const BigGeom& g, int st) {
 // ---- small ALU helpers ---------------------------------------------------------------------------------
 // GELU (nn/activation.py:9-16) for bf16 operands: gelu(x) = max(x, 0) - |x| Phi(-|x|), Phi(-u) = 2^(u q(u) - 1),
 // q = cubic least-squares fit on [0, 5]; max abs error 1.2e-5 in fp32 arithmetic (the result is rounded to bf16
-// for the second MFMA, 4e-3 relative).  Written stage by stage over the 16 accumulator registers so that the 16
-// dependent chains interleave (a lone wave pays the VALU dependent-issue latency otherwise); v_med3_f32 instead of
-// fmin / fmax avoids the canonicalising v_max the IEEE forms cost.
+// for the second MFMA, 4e-3 relative).  act_pair / act_pair_d / act_pair_fd below evaluate it stage by stage over the
+// eight accumulator registers of a 32-wide hidden chunk (independent chains interleave), the polynomials on whole
+// vectors (v_pk_fma_f32); v_med3_f32 instead of fmin / fmax avoids the canonicalising v_max the IEEE forms cost.
 // max(x, 0) as ONE instruction: v_med3_f32 with a finite upper bound (fmaxf and med3 with an infinite bound lower to
 // v_max(x, x) + v_max).  NOT inline asm: hipcc pads no MFMA -> VALU hazard wait states around an asm statement, and an
 // asm v_max reading a fresh MFMA result returned the accumulator without the last product (found the hard way).
@@ -81,105 +81,6 @@ constexpr float kGq3 = 0.004080009517455981f, kGq2 = -0.045314069231662556f, kGq
 // two-exponential form Phi + x phi(x) it replaces: 4.8e-5; bf16 rounding of the product that consumes it: 2e-3).
 constexpr float kLn2f = 0.6931471805599453f;
 constexpr float kGr3 = 4.f * kGq3 * kLn2f, kGr2 = 3.f * kGq2 * kLn2f, kGr1 = 2.f * kGq1 * kLn2f, kGr0 = kGq0 * kLn2f;
-__device__ __forceinline__ void gelu_tile(f32x16& x) {
-  f32x16 a, q;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) a[r] = __builtin_amdgcn_fmed3f(fabsf(x[r]), 0.f, 5.0f);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) q[r] = fmaf(kGq3, a[r], kGq2);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) q[r] = fmaf(q[r], a[r], kGq1);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) q[r] = fmaf(q[r], a[r], kGq0);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) q[r] = fmaf(q[r], a[r], -1.0f);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) q[r] = __builtin_amdgcn_exp2f(q[r]);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) a[r] = relu1(x[r]);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) x[r] = fmaf(-fabsf(x[r]), q[r], a[r]);
-}
-// value and derivative: d/dx = Phi(x) + x phi(x)
-__device__ __forceinline__ void gelu_tile_fd(f32x16& x, f32x16& d) {
-  f32x16 a, q, e;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) a[r] = __builtin_amdgcn_fmed3f(fabsf(x[r]), 0.f, 5.0f);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) q[r] = fmaf(kGq3, a[r], kGq2);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) e[r] = fmaf(kGr3, a[r], kGr2);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) q[r] = fmaf(q[r], a[r], kGq1);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) e[r] = fmaf(e[r], a[r], kGr1);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) q[r] = fmaf(q[r], a[r], kGq0);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) e[r] = fmaf(e[r], a[r], kGr0);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) q[r] = fmaf(q[r], a[r], -1.0f);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) q[r] = __builtin_amdgcn_exp2f(q[r]);      // Phi(-|x|)
-#pragma unroll
-  for (int r = 0; r < 16; ++r) e[r] = fmaf(q[r], e[r] * a[r], q[r]);       // G
-#pragma unroll
-  for (int r = 0; r < 16; ++r) d[r] = x[r] > 0.f ? 1.0f - e[r] : e[r];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) a[r] = relu1(x[r]);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) x[r] = fmaf(-fabsf(x[r]), q[r], a[r]);
-}
-// derivative only (the backward through the nets does not need the activation value)
-__device__ __forceinline__ void gelu_tile_d(const f32x16& x, f32x16& d) {
-  f32x16 a, q, e;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) a[r] = __builtin_amdgcn_fmed3f(fabsf(x[r]), 0.f, 5.0f);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) q[r] = fmaf(kGq3, a[r], kGq2);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) e[r] = fmaf(kGr3, a[r], kGr2);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) q[r] = fmaf(q[r], a[r], kGq1);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) e[r] = fmaf(e[r], a[r], kGr1);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) q[r] = fmaf(q[r], a[r], kGq0);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) e[r] = fmaf(e[r], a[r], kGr0);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) q[r] = fmaf(q[r], a[r], -1.0f);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) q[r] = __builtin_amdgcn_exp2f(q[r]);      // Phi(-|x|)
-#pragma unroll
-  for (int r = 0; r < 16; ++r) e[r] = fmaf(q[r], e[r] * a[r], q[r]);       // G
-#pragma unroll
-  for (int r = 0; r < 16; ++r) d[r] = x[r] > 0.f ? 1.0f - e[r] : e[r];
-}
-
-template <int ACT>
-__device__ __forceinline__ void big_act(int act, f32x16& a) {
-  if constexpr (ACT == ACT_GELU) gelu_tile(a);
-  else act_tile<-1, true>(act, a);
-}
-template <int ACT>
-__device__ __forceinline__ void big_act_fd(int act, f32x16& a, f32x16& d) {
-  if constexpr (ACT == ACT_GELU) gelu_tile_fd(a, d);
-  else act_tile_fd<-1, true>(act, a, d);
-}
-
-// 32 consecutive floats from LDS -> accumulator layout (broadcast ds_read_b128)
-__device__ __forceinline__ f32x16 lds_bias_tile(const float* B, int hh) {
-  f32x16 a;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(B + 8 * q + 4 * hh);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) a[4 * q + i] = v[i];
-  }
-  return a;
-}
-
 // does any token of this block's 128-token range carry mask != 0?  Evaluated redundantly by every wave (two mask
 // loads per lane): no LDS, no barrier.
 __device__ __forceinline__ bool block_live(const int64_t* mask, int64_t N, int S, int mask_div, int lane) {
@@ -196,18 +97,6 @@ __device__ __forceinline__ bool block_live(const int64_t* mask, int64_t N, int S
     }
   }
   return __any(any) != 0;
-}
-
-// LLVM SchedGroupMask bits for __builtin_amdgcn_sched_group_barrier
-#define SG_VALU 0x002
-#define SG_MFMA 0x008
-#define SG_DS_READ 0x100
-
-// derivative of the activation only
-template <int ACT>
-__device__ __forceinline__ void big_act_d(int act, f32x16& a, f32x16& d) {
-  if constexpr (ACT == ACT_GELU) gelu_tile_d(a, d);
-  else act_tile_fd<-1, true>(act, a, d);
 }
 
 template <int N>
@@ -440,14 +329,12 @@ __device__ __forceinline__ void act_pair(int act, f32x4& lo, f32x4& hi) {
     f32x8v x = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}, a, q;
 #pragma unroll
     for (int r = 0; r < 8; ++r) a[r] = __builtin_amdgcn_fmed3f(fabsf(x[r]), 0.f, 5.0f);
+    q = kGq3 * a + kGq2;          // whole-vector cubic: v_pk_fma_f32 (see act_pair_d)
+    q = q * a + kGq1;
+    q = q * a + kGq0;
+    q = q * a - 1.0f;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) q[r] = fmaf(kGq3, a[r], kGq2);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) q[r] = fmaf(q[r], a[r], kGq1);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) q[r] = fmaf(q[r], a[r], kGq0);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) q[r] = __builtin_amdgcn_exp2f(fmaf(q[r], a[r], -1.0f));
+    for (int r = 0; r < 8; ++r) q[r] = __builtin_amdgcn_exp2f(q[r]);
 #pragma unroll
     for (int r = 0; r < 8; ++r) x[r] = fmaf(-fabsf(x[r]), q[r], relu1(x[r]));
     lo = f32x4{x[0], x[1], x[2], x[3]}; hi = f32x4{x[4], x[5], x[6], x[7]};
@@ -467,22 +354,19 @@ __device__ __forceinline__ void act_pair_d(int act, const f32x4& lo, const f32x4
     f32x8v x = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}, a, q, e, d;
 #pragma unroll
     for (int r = 0; r < 8; ++r) a[r] = __builtin_amdgcn_fmed3f(fabsf(x[r]), 0.f, 5.0f);
+    // the two cubics on whole vectors: v_pk_fma_f32, two elements per instruction (this phase runs between the MFMA
+    // phases, where the packed form is a gain; the file is built without SLP vectorisation for the MFMA-paced loops)
+    q = kGq3 * a + kGq2;
+    e = kGr3 * a + kGr2;
+    q = q * a + kGq1;
+    e = e * a + kGr1;
+    q = q * a + kGq0;
+    e = e * a + kGr0;
+    q = q * a - 1.0f;
+    e = e * a;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) q[r] = fmaf(kGq3, a[r], kGq2);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) e[r] = fmaf(kGr3, a[r], kGr2);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) q[r] = fmaf(q[r], a[r], kGq1);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) e[r] = fmaf(e[r], a[r], kGr1);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) q[r] = fmaf(q[r], a[r], kGq0);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) e[r] = fmaf(e[r], a[r], kGr0);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) q[r] = __builtin_amdgcn_exp2f(fmaf(q[r], a[r], -1.0f));   // Phi(-|x|)
-#pragma unroll
-    for (int r = 0; r < 8; ++r) e[r] = fmaf(q[r], e[r] * a[r], q[r]);                       // G (see gelu_tile_fd)
+    for (int r = 0; r < 8; ++r) q[r] = __builtin_amdgcn_exp2f(q[r]);                          // Phi(-|x|)
+    e = q * e + q;                                                                             // G (see kGr3 above)
 #pragma unroll
     for (int r = 0; r < 8; ++r) d[r] = x[r] > 0.f ? 1.0f - e[r] : e[r];
     dlo = f32x4{d[0], d[1], d[2], d[3]}; dhi = f32x4{d[4], d[5], d[6], d[7]};
@@ -502,22 +386,19 @@ __device__ __forceinline__ void act_pair_fd(int act, f32x4& lo, f32x4& hi, f32x4
     f32x8v x = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}, a, q, e, d;
 #pragma unroll
     for (int r = 0; r < 8; ++r) a[r] = __builtin_amdgcn_fmed3f(fabsf(x[r]), 0.f, 5.0f);
+    // the two cubics on whole vectors: v_pk_fma_f32, two elements per instruction (this phase runs between the MFMA
+    // phases, where the packed form is a gain; the file is built without SLP vectorisation for the MFMA-paced loops)
+    q = kGq3 * a + kGq2;
+    e = kGr3 * a + kGr2;
+    q = q * a + kGq1;
+    e = e * a + kGr1;
+    q = q * a + kGq0;
+    e = e * a + kGr0;
+    q = q * a - 1.0f;
+    e = e * a;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) q[r] = fmaf(kGq3, a[r], kGq2);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) e[r] = fmaf(kGr3, a[r], kGr2);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) q[r] = fmaf(q[r], a[r], kGq1);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) e[r] = fmaf(e[r], a[r], kGr1);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) q[r] = fmaf(q[r], a[r], kGq0);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) e[r] = fmaf(e[r], a[r], kGr0);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) q[r] = __builtin_amdgcn_exp2f(fmaf(q[r], a[r], -1.0f));   // Phi(-|x|)
-#pragma unroll
-    for (int r = 0; r < 8; ++r) e[r] = fmaf(q[r], e[r] * a[r], q[r]);                       // G (see gelu_tile_fd)
+    for (int r = 0; r < 8; ++r) q[r] = __builtin_amdgcn_exp2f(q[r]);                          // Phi(-|x|)
+    e = q * e + q;                                                                             // G (see kGr3 above)
 #pragma unroll
     for (int r = 0; r < 8; ++r) d[r] = x[r] > 0.f ? 1.0f - e[r] : e[r];
 #pragma unroll
