@@ -490,7 +490,7 @@ __global__ void __launch_bounds__(512) k_big_chain(BigArgs a) {
   } else {
     load_tiles<NF>(zrow + h, on, h, g, x1);
   }
-  float ld = 0.f;
+  f32x4 ld4 = {0.f, 0.f, 0.f, 0.f};   // log-det partial sums, one per accumulator register
 
   RingT ring;
   float* bias_lds = reinterpret_cast<float*>(smem + R * ITEM);
@@ -677,49 +677,41 @@ __global__ void __launch_bounds__(512) k_big_chain(BigArgs a) {
           if (nn == 0) {
             if (a.x1_hist) store_tiles<NF>(a.x1_hist + ((int64_t)k * a.N + tok) * h, valid, h, g, x1);
 #pragma unroll
-            for (int v = 0; v < NF; ++v) {
-              const f32x4 bt = lds4(b2 + 16 * v);
+            for (int v = 0; v < NF; ++v) {     // whole-vector arithmetic: v_pk_add / v_pk_mul, two elements per instruction
+              const f32x4 s4 = acc[v] + lds4(b2 + 16 * v);
+              const f32x4 t4 = s4 * 1.44269504088896341f;
+              f32x4 e4;
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const float s = acc[v][r] + bt[r];
-                x1[v][r] *= fast_exp(s);
-                ld += s;
-                acc[v][r] = 0.f;
-              }
+              for (int r = 0; r < 4; ++r) e4[r] = __builtin_amdgcn_exp2f(t4[r]);
+              x1[v] *= e4;
+              if constexpr (HT <= 4) ld4 += s4; else ld4[0] += (s4[0] + s4[1]) + (s4[2] + s4[3]);   // (h = 256: no registers for four sums)
+              acc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
           } else {
 #pragma unroll
             for (int v = 0; v < NF; ++v) {
-              const f32x4 bt = lds4(b2 + 16 * v);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                x1[v][r] = (x1[v][r] + (acc[v][r] + bt[r])) * m;
-                acc[v][r] = 0.f;
-              }
+              x1[v] = (x1[v] + (acc[v] + lds4(b2 + 16 * v))) * m;
+              acc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
           }
         } else if constexpr (MODE == M_INV) {
           if (nn == 0) {   // t first: x1 -= t
 #pragma unroll
             for (int v = 0; v < NF; ++v) {
-              const f32x4 bt = lds4(b2 + 16 * v);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                x1[v][r] -= acc[v][r] + bt[r];
-                acc[v][r] = 0.f;
-              }
+              x1[v] -= acc[v] + lds4(b2 + 16 * v);
+              acc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
           } else {         // then x1 = x1 exp(-s) m
 #pragma unroll
             for (int v = 0; v < NF; ++v) {
-              const f32x4 bt = lds4(b2 + 16 * v);
+              const f32x4 s4 = acc[v] + lds4(b2 + 16 * v);
+              const f32x4 t4 = s4 * -1.44269504088896341f;
+              f32x4 e4;
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const float s = acc[v][r] + bt[r];
-                x1[v][r] = (x1[v][r] * fast_exp(-s)) * m;
-                ld -= s;
-                acc[v][r] = 0.f;
-              }
+              for (int r = 0; r < 4; ++r) e4[r] = __builtin_amdgcn_exp2f(t4[r]);
+              x1[v] = (x1[v] * e4) * m;
+              if constexpr (HT <= 4) ld4 -= s4; else ld4[0] -= (s4[0] + s4[1]) + (s4[2] + s4[3]);
+              acc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
           }
         }
@@ -766,6 +758,7 @@ __global__ void __launch_bounds__(512) k_big_chain(BigArgs a) {
     } else {
       base = 0.f;
     }
+    const float ld = (ld4[0] + ld4[1]) + (ld4[2] + ld4[3]);
     float tv = (ld + base) * m;
     tv += __shfl_xor(tv, 16, 64);
     tv += __shfl_xor(tv, 32, 64);
