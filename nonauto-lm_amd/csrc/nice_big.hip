@@ -575,20 +575,38 @@ __global__ void __launch_bounds__(512) k_big_chain(BigArgs a) {
         } else if (on && ft < h) {
           RowIO<T, 4>::load(xh + ft, xp);
         }
-        const f32x4 bt = lds4(b2 + 16 * v);
-        float ds[4], dt[4];
+        if constexpr (HT <= 4) {
+          // whole-vector arithmetic (v_pk_mul / v_pk_fma: two elements per instruction)
+          const f32x4 g1 = x1[v] * m;
+          const f32x4 t4 = (acc[v] + lds4(b2 + 16 * v)) * 1.44269504088896341f;
+          f32x4 e4;
+  #pragma unroll
+          for (int r = 0; r < 4; ++r) e4[r] = __builtin_amdgcn_exp2f(t4[r]);
+          const f32x4 ge = g1 * e4;
+          const f32x4 ds4 = ge * f32x4{xp[0], xp[1], xp[2], xp[3]} + dl;
+          x1[v] = ge;
+          acc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (valid && ft < h) {
+            const float ds[4] = {ds4[0], ds4[1], ds4[2], ds4[3]}, dt[4] = {g1[0], g1[1], g1[2], g1[3]};
+            RowIO<T, 4>::store(dS + ft, ds);
+            RowIO<T, 4>::store(dT + ft, dt);
+          }
+        } else {   // h = 256: the vector temporaries cost registers the kernel does not have (C5: 1.09 -> 1.24 ms)
+          const f32x4 bt = lds4(b2 + 16 * v);
+          float ds[4], dt[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float g1 = x1[v][r] * m;
-          const float ge = g1 * fast_exp(acc[v][r] + bt[r]);
-          dt[r] = g1;
-          ds[r] = ge * xp[r] + dl;
-          x1[v][r] = ge;
-          acc[v][r] = 0.f;
-        }
-        if (valid && ft < h) {
-          RowIO<T, 4>::store(dS + ft, ds);
-          RowIO<T, 4>::store(dT + ft, dt);
+          for (int r = 0; r < 4; ++r) {
+            const float g1 = x1[v][r] * m;
+            const float ge = g1 * fast_exp(acc[v][r] + bt[r]);
+            dt[r] = g1;
+            ds[r] = ge * xp[r] + dl;
+            x1[v][r] = ge;
+            acc[v][r] = 0.f;
+          }
+          if (valid && ft < h) {
+            RowIO<T, 4>::store(dS + ft, ds);
+            RowIO<T, 4>::store(dT + ft, dt);
+          }
         }
       }
     }
