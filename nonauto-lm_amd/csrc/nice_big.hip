@@ -911,8 +911,7 @@ __global__ void __launch_bounds__(512) k_big_nets(NetsArgs a) {
     if constexpr (SAVE) {
       f32x4 hlo = pre[0], hhi = pre[1];
       act_pair_fd<ACT>(a.act, hlo, hhi, dlo, dhi);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { dlo[r] *= dh[0][r]; dhi[r] *= dh[1][r]; }
+      dlo *= dh[0]; dhi *= dh[1];
       if (valid && j1 < NJ) {
         const int64_t at = (((int64_t)kn_of(j1) * HC + c1) * a.N + tok) * 32 + 8 * g;
         *reinterpret_cast<bf16x8*>(a.hbuf + at) = pair_to_b(hlo, hhi);
@@ -920,8 +919,7 @@ __global__ void __launch_bounds__(512) k_big_nets(NetsArgs a) {
       }
     } else {
       act_pair_d<ACT>(a.act, pre[0], pre[1], dlo, dhi);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { dlo[r] *= dh[0][r]; dhi[r] *= dh[1][r]; }
+      dlo *= dh[0]; dhi *= dh[1];
     }
     return pair_to_b(dlo, dhi);
   };
