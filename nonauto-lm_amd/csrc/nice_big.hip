@@ -363,12 +363,14 @@ __device__ __forceinline__ void act_pair_d(int act, const f32x4& lo, const f32x4
     q = q * a + kGq0;
     e = e * a + kGr0;
     q = q * a - 1.0f;
-    e = e * a;
+    e = e * a + 1.0f;
 #pragma unroll
     for (int r = 0; r < 8; ++r) q[r] = __builtin_amdgcn_exp2f(q[r]);                          // Phi(-|x|)
-    e = q * e + q;                                                                             // G (see kGr3 above)
+    e = 0.5f - q * e;                                                                          // 1/2 - G (see kGr3 above)
+    // gelu'(x) = x > 0 ? 1 - G : G = 1/2 + copysign(1/2 - G, x): one v_bfi_b32 instead of compare, subtract and select
 #pragma unroll
-    for (int r = 0; r < 8; ++r) d[r] = x[r] > 0.f ? 1.0f - e[r] : e[r];
+    for (int r = 0; r < 8; ++r) e[r] = __builtin_copysignf(e[r], x[r]);   // (1/2 - G >= 0: G <= 1/2 on u >= 0)
+    d = e + 0.5f;
     dlo = f32x4{d[0], d[1], d[2], d[3]}; dhi = f32x4{d[4], d[5], d[6], d[7]};
   } else {
     f32x16 t, d;
@@ -395,12 +397,14 @@ __device__ __forceinline__ void act_pair_fd(int act, f32x4& lo, f32x4& hi, f32x4
     q = q * a + kGq0;
     e = e * a + kGr0;
     q = q * a - 1.0f;
-    e = e * a;
+    e = e * a + 1.0f;
 #pragma unroll
     for (int r = 0; r < 8; ++r) q[r] = __builtin_amdgcn_exp2f(q[r]);                          // Phi(-|x|)
-    e = q * e + q;                                                                             // G (see kGr3 above)
+    e = 0.5f - q * e;                                                                          // 1/2 - G (see kGr3 above)
+    // gelu'(x) = x > 0 ? 1 - G : G = 1/2 + copysign(1/2 - G, x): one v_bfi_b32 instead of compare, subtract and select
 #pragma unroll
-    for (int r = 0; r < 8; ++r) d[r] = x[r] > 0.f ? 1.0f - e[r] : e[r];
+    for (int r = 0; r < 8; ++r) e[r] = __builtin_copysignf(e[r], x[r]);   // (1/2 - G >= 0: G <= 1/2 on u >= 0)
+    d = e + 0.5f;
 #pragma unroll
     for (int r = 0; r < 8; ++r) x[r] = fmaf(-fabsf(x[r]), q[r], relu1(x[r]));
     lo = f32x4{x[0], x[1], x[2], x[3]}; hi = f32x4{x[4], x[5], x[6], x[7]};
